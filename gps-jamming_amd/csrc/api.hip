@@ -1,0 +1,424 @@
+// C-ABI of libgpsjam_hip.so (see include/gpsjam.h): context, device memory, stopwatch and the
+// host-buffer entry points that stage numpy arrays to HBM around the *_dev kernels.
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "gj_common.h"
+
+namespace gj {
+
+constexpr int kWindowFloats = 2 * 4096;   // periodic Hann tables for N = 16..4096 at offset N-16
+
+int ensure_workspace(gj_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return GJ_OK;
+    bytes = align_up(bytes + bytes / 8, 1 << 20);
+    // the old arena may still be in use by kernels queued on the stream
+    GJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return fail(ctx, GJ_ERR_NOMEM, "workspace of %zu bytes", bytes);
+    ctx->ws = static_cast<unsigned char*>(p);
+    ctx->ws_bytes = bytes;
+    return GJ_OK;
+}
+
+int ensure_stage(gj_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->stage_bytes) return GJ_OK;
+    bytes = align_up(bytes, 1 << 20);
+    GJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->stage) (void)hipFree(ctx->stage);
+    ctx->stage = nullptr;
+    ctx->stage_bytes = 0;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return fail(ctx, GJ_ERR_NOMEM, "staging buffer of %zu bytes", bytes);
+    ctx->stage = static_cast<unsigned char*>(p);
+    ctx->stage_bytes = bytes;
+    return GJ_OK;
+}
+
+static float* g_window_dummy = nullptr;
+const float* window_table(gj_ctx* ctx, int n) {
+    (void)g_window_dummy;
+    return reinterpret_cast<const float*>(ctx->d_twiddle + kTwiddleTable) + (n - 16);
+}
+
+// small device scratch for results of the host-buffer entry points (lives behind the tables)
+static unsigned char* result_scratch(gj_ctx* ctx) {
+    return reinterpret_cast<unsigned char*>(ctx->d_twiddle + kTwiddleTable) + kWindowFloats * sizeof(float);
+}
+constexpr size_t kResultScratch = 4096;
+
+}   // namespace gj
+
+using namespace gj;
+
+extern "C" {
+
+int gj_version(void) { return GJ_VERSION; }
+
+const char* gj_strerror(int status) {
+    switch (status) {
+        case GJ_OK: return "ok";
+        case GJ_ERR_INVALID: return "invalid argument";
+        case GJ_ERR_HIP: return "HIP runtime error";
+        case GJ_ERR_NOMEM: return "out of memory";
+        case GJ_ERR_NODEVICE: return "no such GPU";
+        case GJ_ERR_UNSUPPORTED: return "unsupported size or parameter";
+        case GJ_ERR_CAPACITY: return "output buffer too small";
+        default: return "unknown status";
+    }
+}
+
+const char* gj_last_error(gj_ctx* ctx) { return ctx ? ctx->last_error : "null context"; }
+
+int gj_device_count(int* count) {
+    if (!count) return GJ_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return GJ_OK;
+}
+
+int gj_create(int device_id, gj_ctx** out) {
+    if (!out) return GJ_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return GJ_ERR_NODEVICE;
+    gj_ctx* ctx = new (std::nothrow) gj_ctx();
+    if (!ctx) return GJ_ERR_NOMEM;
+    ctx->device = device_id;
+    auto bail = [&](int code) {
+        gj_destroy(ctx);
+        return code;
+    };
+    if (hipSetDevice(device_id) != hipSuccess) return bail(GJ_ERR_HIP);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(GJ_ERR_HIP);
+    ctx->stream = ctx->own_stream;
+    if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) return bail(GJ_ERR_HIP);
+    // constant tables: W_4096^m, periodic Hann windows, result scratch
+    const size_t bytes = kTwiddleTable * sizeof(cf) + kWindowFloats * sizeof(float) + kResultScratch;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return bail(GJ_ERR_NOMEM);
+    ctx->d_twiddle = static_cast<cf*>(p);
+    std::vector<unsigned char> host(bytes, 0);
+    cf* tw = reinterpret_cast<cf*>(host.data());
+    for (int m = 0; m < kTwiddleTable; ++m) {
+        const double a = -2.0 * M_PI * (double)m / (double)kTwiddleTable;
+        tw[m] = cf{(float)std::cos(a), (float)std::sin(a)};
+    }
+    float* win = reinterpret_cast<float*>(host.data() + kTwiddleTable * sizeof(cf));
+    for (int nn = 16; nn <= 4096; nn *= 2)
+        for (int k = 0; k < nn; ++k) win[nn - 16 + k] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * (double)k / (double)nn));
+    if (hipMemcpy(p, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return bail(GJ_ERR_HIP);
+    *out = ctx;
+    return GJ_OK;
+}
+
+int gj_destroy(gj_ctx* ctx) {
+    if (!ctx) return GJ_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->stage) (void)hipFree(ctx->stage);
+    if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return GJ_OK;
+}
+
+int gj_set_stream(gj_ctx* ctx, void* hip_stream) {
+    if (!ctx) return GJ_ERR_INVALID;
+    Guard g(ctx);
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return GJ_OK;
+}
+
+int gj_synchronize(gj_ctx* ctx) {
+    if (!ctx) return GJ_ERR_INVALID;
+    Guard g(ctx);
+    GJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GJ_OK;
+}
+
+int gj_device_info(gj_ctx* ctx, char* name, size_t name_cap, int* compute_units, uint64_t* hbm_bytes) {
+    if (!ctx) return GJ_ERR_INVALID;
+    Guard g(ctx);
+    hipDeviceProp_t prop;
+    GJ_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_cap) snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return GJ_OK;
+}
+
+int gj_reserve(gj_ctx* ctx, size_t workspace_bytes) {
+    if (!ctx) return GJ_ERR_INVALID;
+    Guard g(ctx);
+    return ensure_workspace(ctx, workspace_bytes);
+}
+
+int gj_malloc(gj_ctx* ctx, size_t bytes, void** dptr) {
+    if (!ctx || !dptr) return GJ_ERR_INVALID;
+    Guard g(ctx);
+    *dptr = nullptr;
+    if (bytes == 0) return GJ_OK;
+    if (hipMalloc(dptr, bytes) != hipSuccess) return fail(ctx, GJ_ERR_NOMEM, "hipMalloc(%zu)", bytes);
+    return GJ_OK;
+}
+
+int gj_free(gj_ctx* ctx, void* dptr) {
+    if (!ctx) return GJ_ERR_INVALID;
+    Guard g(ctx);
+    if (dptr) {
+        GJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        GJ_HIP(ctx, hipFree(dptr));
+    }
+    return GJ_OK;
+}
+
+int gj_memcpy_h2d(gj_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    if (!ctx || (bytes && (!dst_dev || !src_host))) return GJ_ERR_INVALID;
+    Guard g(ctx);
+    if (bytes) {
+        GJ_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+        GJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return GJ_OK;
+}
+
+int gj_memcpy_d2h(gj_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+    if (!ctx || (bytes && (!dst_host || !src_dev))) return GJ_ERR_INVALID;
+    Guard g(ctx);
+    if (bytes) {
+        GJ_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        GJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return GJ_OK;
+}
+
+int gj_timer_start(gj_ctx* ctx) {
+    if (!ctx) return GJ_ERR_INVALID;
+    Guard g(ctx);
+    GJ_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    return GJ_OK;
+}
+
+int gj_timer_stop(gj_ctx* ctx, float* elapsed_ms) {
+    if (!ctx || !elapsed_ms) return GJ_ERR_INVALID;
+    Guard g(ctx);
+    GJ_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    GJ_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
+    GJ_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev_start, ctx->ev_stop));
+    return GJ_OK;
+}
+
+// ---------------------------------------------------------------- sizes
+size_t gj_chunk_count(size_t nbytes, size_t chunk_bytes) {
+    return chunk_bytes ? (nbytes + chunk_bytes - 1) / chunk_bytes : 0;
+}
+
+size_t gj_welch_rows(size_t nbytes, size_t chunk_samples, int nperseg) {
+    if (chunk_samples == 0 || nperseg <= 0) return 0;
+    const size_t chunk_bytes = 2 * chunk_samples;
+    const size_t full = nbytes / chunk_bytes;
+    const size_t rem = nbytes - full * chunk_bytes;
+    return full + ((rem >= (size_t)2 * nperseg) ? 1 : 0);   // widmo_plot.py:31
+}
+
+size_t gj_welch_workspace(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int nperseg) {
+    return ctx ? welch_workspace(ctx, nbytes, chunk_samples, nperseg) : 0;
+}
+
+size_t gj_xcorr_workspace(gj_ctx* ctx, int n_ant, size_t n_samples, int n_pairs) {
+    return xcorr_workspace(ctx, n_ant, n_samples, n_pairs);
+}
+
+// ---------------------------------------------------------------- device entry points
+#define GJ_ENTER(ctx)                 \
+    if (!(ctx)) return GJ_ERR_INVALID; \
+    Guard guard__(ctx)
+
+int gj_chunk_power_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
+                       float* d_power) {
+    GJ_ENTER(ctx);
+    if (nbytes && (!d_iq || !d_power)) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    return launch_chunk_power(ctx, d_iq, nbytes, chunk_bytes, eps, flags, d_power);
+}
+
+int gj_power_threshold_dev(gj_ctx* ctx, const float* d_power, size_t n, float pct, float rise_db, float* d_stats,
+                           uint8_t* d_mask) {
+    GJ_ENTER(ctx);
+    if (!d_power || !d_stats) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    return launch_power_threshold(ctx, d_power, n, pct, rise_db, d_stats, d_mask);
+}
+
+int gj_welch_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_samples, int nperseg, double fs, int flags,
+                 float* d_psd, float* d_psd_db) {
+    GJ_ENTER(ctx);
+    if (nbytes && (!d_iq || !d_psd)) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    return launch_welch(ctx, d_iq, nbytes, chunk_samples, nperseg, fs, flags, d_psd, d_psd_db);
+}
+
+int gj_byte_histogram_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_samples, int nperseg, int stride,
+                          uint64_t* d_hist) {
+    GJ_ENTER(ctx);
+    if (!d_hist || (nbytes && !d_iq)) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    return launch_histogram(ctx, d_iq, nbytes, chunk_samples, nperseg, stride,
+                            reinterpret_cast<unsigned long long*>(d_hist));
+}
+
+int gj_amp_stats_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, float threshold, gj_amp_stats* d_out) {
+    GJ_ENTER(ctx);
+    if (!d_out || (nbytes && !d_iq)) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    return launch_amp_stats(ctx, d_iq, nbytes, threshold, d_out);
+}
+
+int gj_onset_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, int noise_samples, int window, float factor,
+                 gj_onset* d_out) {
+    GJ_ENTER(ctx);
+    if (!d_out || (nbytes && !d_iq)) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    return launch_onset(ctx, d_iq, nbytes, noise_samples, window, factor, d_out);
+}
+
+int gj_xcorr_lags_dev(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, int n_ant, const int64_t* d_starts,
+                      size_t n_samples, const int32_t* pairs, int n_pairs, int32_t* d_lags, float* d_peaks) {
+    GJ_ENTER(ctx);
+    if (!d_iq || !nbytes || !d_starts || !pairs || !d_lags || !d_peaks) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    return launch_xcorr(ctx, d_iq, nbytes, n_ant, d_starts, n_samples, pairs, n_pairs, d_lags, d_peaks);
+}
+
+int gj_synth_u8_dev(gj_ctx* ctx, const gj_synth_params* params, int64_t first_sample, size_t n_samples, uint8_t* d_out) {
+    GJ_ENTER(ctx);
+    if (!params || (n_samples && !d_out)) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    return launch_synth(ctx, *params, first_sample, n_samples, d_out);
+}
+
+// ---------------------------------------------------------------- host-buffer entry points
+// Stage the capture into HBM (grow-only staging arena), run the same kernels, copy the small
+// results back.  kernel_ms excludes the copies.
+static int stage_in(gj_ctx* ctx, const uint8_t* host, size_t nbytes, size_t offset = 0) {
+    int rc = ensure_stage(ctx, offset + align_up(nbytes, 256) + 256);
+    if (rc) return rc;
+    if (nbytes) GJ_HIP(ctx, hipMemcpyAsync(ctx->stage + offset, host, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    return GJ_OK;
+}
+
+static int fetch(gj_ctx* ctx, void* host, const void* dev, size_t bytes) {
+    if (bytes) GJ_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GJ_OK;
+}
+
+#define GJ_TIMED(ctx, ms, stmt)                                                        \
+    do {                                                                               \
+        GJ_HIP(ctx, hipEventRecord((ctx)->ev_start, (ctx)->stream));                   \
+        int rc__ = (stmt);                                                             \
+        if (rc__) return rc__;                                                         \
+        GJ_HIP(ctx, hipEventRecord((ctx)->ev_stop, (ctx)->stream));                    \
+        GJ_HIP(ctx, hipEventSynchronize((ctx)->ev_stop));                              \
+        float t__ = 0.f;                                                               \
+        GJ_HIP(ctx, hipEventElapsedTime(&t__, (ctx)->ev_start, (ctx)->ev_stop));       \
+        if (ms) *(ms) = t__;                                                           \
+    } while (0)
+
+int gj_chunk_power_u8(gj_ctx* ctx, const uint8_t* iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
+                      float* power, size_t power_cap, size_t* n_out, float* kernel_ms) {
+    GJ_ENTER(ctx);
+    if (chunk_bytes == 0) return fail(ctx, GJ_ERR_INVALID, "chunk_bytes must be > 0");
+    const size_t n = gj_chunk_count(nbytes, chunk_bytes);
+    if (n_out) *n_out = n;
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (n == 0) return GJ_OK;
+    if (!iq || !power) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    if (power_cap < n) return fail(ctx, GJ_ERR_CAPACITY, "power buffer holds %zu, need %zu", power_cap, n);
+    const size_t off_out = align_up(nbytes, 256);
+    int rc = ensure_stage(ctx, off_out + n * sizeof(float) + 256);
+    if (rc) return rc;
+    rc = stage_in(ctx, iq, nbytes);
+    if (rc) return rc;
+    float* d_power = reinterpret_cast<float*>(ctx->stage + off_out);
+    GJ_TIMED(ctx, kernel_ms, launch_chunk_power(ctx, ctx->stage, nbytes, chunk_bytes, eps, flags, d_power));
+    return fetch(ctx, power, d_power, n * sizeof(float));
+}
+
+int gj_welch_u8(gj_ctx* ctx, const uint8_t* iq, size_t nbytes, size_t chunk_samples, int nperseg, double fs, int flags,
+                float* psd, float* psd_db, size_t cap_floats, size_t* rows_out, float* kernel_ms) {
+    GJ_ENTER(ctx);
+    const size_t rows = gj_welch_rows(nbytes, chunk_samples, nperseg);
+    if (rows_out) *rows_out = rows;
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (nperseg < 16 || nperseg > 4096 || (nperseg & (nperseg - 1)))
+        return fail(ctx, GJ_ERR_UNSUPPORTED, "nperseg must be a power of two in [16, 4096]");
+    if (rows == 0) return GJ_OK;
+    if (!iq || !psd) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    const size_t nfl = rows * (size_t)nperseg;
+    if (cap_floats < nfl) return fail(ctx, GJ_ERR_CAPACITY, "psd buffer holds %zu floats, need %zu", cap_floats, nfl);
+    const size_t off_out = align_up(nbytes, 256);
+    int rc = ensure_stage(ctx, off_out + 2 * nfl * sizeof(float) + 256);
+    if (rc) return rc;
+    rc = stage_in(ctx, iq, nbytes);
+    if (rc) return rc;
+    float* d_psd = reinterpret_cast<float*>(ctx->stage + off_out);
+    float* d_db = psd_db ? d_psd + nfl : nullptr;
+    GJ_TIMED(ctx, kernel_ms, launch_welch(ctx, ctx->stage, nbytes, chunk_samples, nperseg, fs, flags, d_psd, d_db));
+    if (psd_db) GJ_HIP(ctx, hipMemcpyAsync(psd_db, d_db, nfl * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    return fetch(ctx, psd, d_psd, nfl * sizeof(float));
+}
+
+int gj_amp_stats_u8(gj_ctx* ctx, const uint8_t* iq, size_t nbytes, float threshold, gj_amp_stats* out, float* kernel_ms) {
+    GJ_ENTER(ctx);
+    if (!out || (nbytes && !iq)) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    int rc = stage_in(ctx, iq, nbytes);
+    if (rc) return rc;
+    gj_amp_stats* d_out = reinterpret_cast<gj_amp_stats*>(result_scratch(ctx));
+    GJ_TIMED(ctx, kernel_ms, launch_amp_stats(ctx, ctx->stage, nbytes, threshold, d_out));
+    return fetch(ctx, out, d_out, sizeof(gj_amp_stats));
+}
+
+int gj_onset_u8(gj_ctx* ctx, const uint8_t* iq, size_t nbytes, int noise_samples, int window, float factor, gj_onset* out,
+                float* kernel_ms) {
+    GJ_ENTER(ctx);
+    if (!out || (nbytes && !iq)) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    int rc = stage_in(ctx, iq, nbytes);
+    if (rc) return rc;
+    gj_onset* d_out = reinterpret_cast<gj_onset*>(result_scratch(ctx));
+    GJ_TIMED(ctx, kernel_ms, launch_onset(ctx, ctx->stage, nbytes, noise_samples, window, factor, d_out));
+    return fetch(ctx, out, d_out, sizeof(gj_onset));
+}
+
+int gj_xcorr_lags_u8(gj_ctx* ctx, const uint8_t* const* slices, int n_ant, size_t n_samples, const int32_t* pairs,
+                     int n_pairs, int32_t* lags, float* peaks, float* kernel_ms) {
+    GJ_ENTER(ctx);
+    if (!slices || !pairs || !lags || !peaks) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    if (n_ant < 1 || n_ant > GJ_MAX_ANTENNAS) return fail(ctx, GJ_ERR_INVALID, "n_ant must be 1..%d", GJ_MAX_ANTENNAS);
+    if (n_pairs < 1 || (size_t)n_pairs * 8 + 256 > kResultScratch) return fail(ctx, GJ_ERR_INVALID, "bad n_pairs");
+    const size_t slot = align_up(2 * n_samples, 256);
+    int rc = ensure_stage(ctx, slot * n_ant + 256);
+    if (rc) return rc;
+    const uint8_t* d_ptrs[GJ_MAX_ANTENNAS];
+    size_t nbytes[GJ_MAX_ANTENNAS];
+    for (int a = 0; a < n_ant; ++a) {
+        if (!slices[a]) return fail(ctx, GJ_ERR_INVALID, "null slice %d", a);
+        GJ_HIP(ctx, hipMemcpyAsync(ctx->stage + slot * a, slices[a], 2 * n_samples, hipMemcpyHostToDevice, ctx->stream));
+        d_ptrs[a] = ctx->stage + slot * a;
+        nbytes[a] = 2 * n_samples;
+    }
+    unsigned char* sc = result_scratch(ctx);
+    int64_t* d_starts = reinterpret_cast<int64_t*>(sc);   // zeros: slices start at their first sample
+    int32_t* d_lags = reinterpret_cast<int32_t*>(sc + 128);
+    float* d_peaks = reinterpret_cast<float*>(sc + 128 + 4 * (size_t)n_pairs);
+    GJ_HIP(ctx, hipMemsetAsync(d_starts, 0, 128, ctx->stream));
+    GJ_TIMED(ctx, kernel_ms,
+             launch_xcorr(ctx, d_ptrs, nbytes, n_ant, d_starts, n_samples, pairs, n_pairs, d_lags, d_peaks));
+    GJ_HIP(ctx, hipMemcpyAsync(peaks, d_peaks, 4 * (size_t)n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+    return fetch(ctx, lags, d_lags, 4 * (size_t)n_pairs);
+}
+
+}   // extern "C"

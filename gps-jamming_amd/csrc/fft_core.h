@@ -1,0 +1,211 @@
+// Block FFT core for gfx950: one 256-thread workgroup transforms 4096 complex points per
+// step = (4096/N) independent N-point FFTs, 16 points per thread held in VGPRs, Stockham
+// autosort passes of radix 16 (then one 2/4/8 pass when log2 N is not a multiple of 4),
+// LDS exchange between passes with one pad slot per 16 points (bank-conflict-free
+// ds_write_b64, 2-way ds_read_b64 -- see tools/lds_bank_sim.py).
+//
+// The arithmetic and the index maps in this header are plain C++ so that
+// tests/host_fft_emul.cpp can run the exact same code on the CPU, one "thread" at a time,
+// against numpy's FFT.  Nothing here is a CPU fallback for the product: the kernels that
+// include this header only exist as gfx950 code objects.
+//
+// Replaces the pocketfft calls under scipy.signal.welch (skrypty/widmo_plot.py:48) and
+// scipy.signal.correlate (skrypty/triangulateTDOA.py:86).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GJ_HD __host__ __device__ __forceinline__
+#else
+#define GJ_HD inline
+#endif
+
+namespace gj {
+
+struct alignas(8) cf {
+    float x, y;
+};
+
+GJ_HD cf cmul(cf a, cf b) { return cf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+GJ_HD cf cadd(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
+GJ_HD cf csub(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
+GJ_HD cf mul_mj(cf a) { return cf{a.y, -a.x}; }   // a * (-j)
+GJ_HD cf mul_pj(cf a) { return cf{-a.y, a.x}; }   // a * (+j)
+
+constexpr int kPointsPerThread = 16;
+constexpr int kBlockThreads = 256;
+constexpr int kBlockPoints = kPointsPerThread * kBlockThreads;   // 4096
+constexpr int kTwiddleTable = 4096;                              // W_4096^m, m = 0..4095
+
+constexpr int fft_npass(int n) {
+    int p = 0;
+    while (n >= 16) { n /= 16; ++p; }
+    return p + (n > 1 ? 1 : 0);
+}
+constexpr int fft_radix(int n, int pass) {
+    for (int i = 0; i < pass; ++i) n /= 16;
+    return n >= 16 ? 16 : n;
+}
+constexpr int fft_ns(int n, int pass) {   // product of the radices of the passes before `pass`
+    int ns = 1;
+    for (int i = 0; i < pass; ++i) ns *= fft_radix(n, i);
+    return ns;
+}
+
+// ---- small DFTs, forward sign (W = exp(-2 pi i / R)), in place, natural order out -------
+GJ_HD void dft2(cf& a, cf& b) {
+    cf t = a;
+    a = cadd(t, b);
+    b = csub(t, b);
+}
+
+GJ_HD void dft4(cf& x0, cf& x1, cf& x2, cf& x3) {
+    cf t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = csub(x1, x3);
+    x0 = cadd(t0, t2);
+    x2 = csub(t0, t2);
+    x1 = cadd(t1, mul_mj(t3));
+    x3 = cadd(t1, mul_pj(t3));
+}
+
+constexpr float kSqrtHalf = 0.70710678118654752440f;
+constexpr float kCosPi8 = 0.92387953251128675613f;
+constexpr float kSinPi8 = 0.38268343236508977173f;
+
+GJ_HD cf mul_w8_1(cf a) { return cf{(a.x + a.y) * kSqrtHalf, (a.y - a.x) * kSqrtHalf}; }    // * W8^1
+GJ_HD cf mul_w8_3(cf a) { return cf{(a.y - a.x) * kSqrtHalf, -(a.x + a.y) * kSqrtHalf}; }   // * W8^3
+
+template <int R>
+GJ_HD void dft(cf (&a)[R]);
+
+template <>
+GJ_HD void dft<2>(cf (&a)[2]) { dft2(a[0], a[1]); }
+
+template <>
+GJ_HD void dft<4>(cf (&a)[4]) { dft4(a[0], a[1], a[2], a[3]); }
+
+template <>
+GJ_HD void dft<8>(cf (&a)[8]) {
+    // n = n1 + 2 n2, k = 4 k1 + k2 :  radix-4 over n2, twiddle W8^(n1 k2), radix-2 over n1
+    dft4(a[0], a[2], a[4], a[6]);   // n1 = 0 : A0[k2] in a[2 k2]
+    dft4(a[1], a[3], a[5], a[7]);   // n1 = 1 : A1[k2] in a[2 k2 + 1]
+    a[3] = mul_w8_1(a[3]);
+    a[5] = mul_mj(a[5]);
+    a[7] = mul_w8_3(a[7]);
+    cf r[8];
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+        r[k2] = cadd(a[2 * k2], a[2 * k2 + 1]);
+        r[k2 + 4] = csub(a[2 * k2], a[2 * k2 + 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = r[i];
+}
+
+template <>
+GJ_HD void dft<16>(cf (&a)[16]) {
+    // n = n1 + 4 n2, k = 4 k1 + k2 :  radix-4 over n2, twiddle W16^(n1 k2), radix-4 over n1
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) dft4(a[n1], a[n1 + 4], a[n1 + 8], a[n1 + 12]);   // A[n1][k2] in a[n1 + 4 k2]
+    const cf w1{kCosPi8, -kSinPi8}, w3{kSinPi8, -kCosPi8};
+    a[5] = cmul(a[5], w1);          // n1 = 1, k2 = 1 : W16^1
+    a[9] = mul_w8_1(a[9]);          // n1 = 1, k2 = 2 : W16^2
+    a[13] = cmul(a[13], w3);        // n1 = 1, k2 = 3 : W16^3
+    a[6] = mul_w8_1(a[6]);          // n1 = 2, k2 = 1 : W16^2
+    a[10] = mul_mj(a[10]);          // n1 = 2, k2 = 2 : W16^4
+    a[14] = mul_w8_3(a[14]);        // n1 = 2, k2 = 3 : W16^6
+    a[7] = cmul(a[7], w3);          // n1 = 3, k2 = 1 : W16^3
+    a[11] = mul_w8_3(a[11]);        // n1 = 3, k2 = 2 : W16^6
+    a[15] = cmul(a[15], cf{-kCosPi8, kSinPi8});   // n1 = 3, k2 = 3 : W16^9 = -W16^1
+    cf r[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+        cf y0 = a[4 * k2], y1 = a[4 * k2 + 1], y2 = a[4 * k2 + 2], y3 = a[4 * k2 + 3];
+        dft4(y0, y1, y2, y3);       // X[4 k1 + k2] = y_k1
+        r[k2] = y0;
+        r[4 + k2] = y1;
+        r[8 + k2] = y2;
+        r[12 + k2] = y3;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = r[i];
+}
+
+// LDS element index (8-byte elements) of logical point i of a transform whose region
+// starts at `base`.
+// Additive padding (one spare slot per 16) rather than an XOR swizzle: every address a thread
+// touches in one exchange is then "thread base + compile-time constant", so the 16 scatter
+// and 16 gather addresses fold into the DS instructions' immediate offsets instead of
+// occupying 64 loop-invariant VGPRs.  Writes are conflict free, reads 2-way
+// (tools/lds_bank_sim.py).
+GJ_HD int lds_slot(int base, int i) { return base + i + (i >> 4); }
+constexpr int lds_span(int n) { return n + n / 16; }   // slots one N-point transform occupies
+
+// One Stockham pass over the 16 register-resident points of thread `jl` (0 <= jl < N/16).
+// v[s] holds in[jl + (N/16) s] on entry.  On exit the logical output of butterfly u,
+// leg t sits in v[u + t*(16/R)] and belongs at index out_index<N,PASS>(jl, u, t) of the
+// next pass' input (or IS X[jl + (N/16)(u + t*(16/R))] after the last pass).
+// tw[u*(R-1) + t-1] = W_(Ns R)^(t * ((jl + (N/16) u) mod Ns)), unused when PASS == 0.
+template <int N, int PASS>
+GJ_HD void fft_pass(cf (&v)[16], const cf* tw) {
+    constexpr int R = fft_radix(N, PASS);
+    constexpr int G = 16 / R;   // butterflies per thread
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        cf a[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) a[t] = v[u + t * G];
+        if (PASS > 0) {
+#pragma unroll
+            for (int t = 1; t < R; ++t) a[t] = cmul(a[t], tw[u * (R - 1) + t - 1]);
+        }
+        dft<R>(a);
+#pragma unroll
+        for (int t = 0; t < R; ++t) v[u + t * G] = a[t];
+    }
+}
+
+template <int N, int PASS>
+GJ_HD int out_index(int jl, int u, int t) {
+    constexpr int R = fft_radix(N, PASS);
+    constexpr int NS = fft_ns(N, PASS);
+    const int q = jl + (N / 16) * u;
+    const int k = q & (NS - 1);
+    return (q - k) * R + k + t * NS;
+}
+
+// index into the W_4096 table of the twiddle of butterfly u, leg t of thread jl
+template <int N, int PASS>
+GJ_HD int twiddle_index(int jl, int u, int t) {
+    constexpr int R = fft_radix(N, PASS);
+    constexpr int NS = fft_ns(N, PASS);
+    const int k = (jl + (N / 16) * u) & (NS - 1);
+    return (t * k * (kTwiddleTable / (NS * R))) & (kTwiddleTable - 1);
+}
+
+template <int N, int PASS>
+GJ_HD void load_twiddles(cf* tw, const cf* table, int jl) {
+    constexpr int R = fft_radix(N, PASS);
+    constexpr int G = 16 / R;
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+#pragma unroll
+        for (int t = 1; t < R; ++t) tw[u * (R - 1) + t - 1] = table[twiddle_index<N, PASS>(jl, u, t)];
+}
+
+template <int N, int PASS>
+GJ_HD void lds_scatter(const cf (&v)[16], cf* lds, int base, int jl) {
+    constexpr int R = fft_radix(N, PASS);
+    constexpr int G = 16 / R;
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+#pragma unroll
+        for (int t = 0; t < R; ++t) lds[lds_slot(base, out_index<N, PASS>(jl, u, t))] = v[u + t * G];
+}
+
+template <int N>
+GJ_HD void lds_gather(cf (&v)[16], const cf* lds, int base, int jl) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) v[s] = lds[lds_slot(base, jl + (N / 16) * s)];
+}
+
+}   // namespace gj

@@ -1,0 +1,544 @@
+// Streaming scans over a uint8 I/Q capture resident in HBM (gfx950).
+//   K1  chunk power + noise-floor threshold   (GpsJammerApp/app/worker.py:216-264)
+//   K3  amplitude statistics                  (skrypty/triangulateRSSI.py:29-31,65-68)
+//   K4  interference onset                    (skrypty/triangulateTDOA.py:37-49)
+//       byte histogram                        (skrypty/widmo_plot.py:35,85)
+// All of them are HBM-bound: 2 bytes per I/Q sample read once with 16-byte-per-lane
+// coalesced loads, integer arithmetic on the packed bytes (v_dot4_u32_u8), wave shuffles
+// + one LDS hop for the block reduction.  Sums of squares are exact integers:
+//   (I-127.5)^2 + (Q-127.5)^2 = ((2I-255)^2 + (2Q-255)^2) / 4.
+#include "gj_common.h"
+
+namespace gj {
+
+constexpr int kScanThreads = 256;
+constexpr size_t kScanTile = 65536;   // bytes per workgroup step
+
+__device__ __forceinline__ void acc_moments(const uint4& q, unsigned& s2, unsigned& s1) {
+    s2 = __builtin_amdgcn_udot4(q.x, q.x, s2, false);
+    s2 = __builtin_amdgcn_udot4(q.y, q.y, s2, false);
+    s2 = __builtin_amdgcn_udot4(q.z, q.z, s2, false);
+    s2 = __builtin_amdgcn_udot4(q.w, q.w, s2, false);
+    s1 = __builtin_amdgcn_udot4(q.x, 0x01010101u, s1, false);
+    s1 = __builtin_amdgcn_udot4(q.y, 0x01010101u, s1, false);
+    s1 = __builtin_amdgcn_udot4(q.z, 0x01010101u, s1, false);
+    s1 = __builtin_amdgcn_udot4(q.w, 0x01010101u, s1, false);
+}
+
+// sum u^2 and sum u over the bytes [begin, end) of `p`, whole workgroup cooperating;
+// result valid in thread 0.
+__device__ __forceinline__ void block_byte_moments(const uint8_t* __restrict__ p, size_t begin, size_t end,
+                                                   unsigned long long& s2_out, unsigned long long& s1_out) {
+    __shared__ unsigned long long red[2][kScanThreads / 64];
+    const int tid = threadIdx.x;
+    unsigned s2 = 0, s1 = 0;
+    size_t a0 = (begin + 15) & ~size_t(15);
+    size_t a1 = end & ~size_t(15);
+    if (a0 > a1) { a0 = end; a1 = end; }
+    // ragged head / tail: at most 15 bytes each
+    if (begin + tid < a0) { unsigned u = p[begin + tid]; s2 += u * u; s1 += u; }
+    if (a1 + tid < end && a1 >= a0) { unsigned u = p[a1 + tid]; s2 += u * u; s1 += u; }
+    const uint4* v = reinterpret_cast<const uint4*>(p + a0);
+    const size_t nvec = (a1 - a0) >> 4;
+    size_t i = tid;
+    for (; i + 3 * kScanThreads < nvec; i += 4 * kScanThreads) {
+        uint4 w0 = v[i], w1 = v[i + kScanThreads], w2 = v[i + 2 * kScanThreads], w3 = v[i + 3 * kScanThreads];
+        acc_moments(w0, s2, s1); acc_moments(w1, s2, s1); acc_moments(w2, s2, s1); acc_moments(w3, s2, s1);
+    }
+    for (; i < nvec; i += kScanThreads) {
+        uint4 w0 = v[i];
+        acc_moments(w0, s2, s1);
+    }
+    unsigned long long t2 = wave_sum_u64(s2), t1 = wave_sum_u64(s1);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = t2; red[1][tid >> 6] = t1; }
+    __syncthreads();
+    if (tid == 0) {
+        s2_out = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        s1_out = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float power_from_moments(unsigned long long s2, unsigned long long s1, size_t npairs,
+                                                    float eps) {
+    // sum (2u-255)^2 over 2*npairs bytes
+    const long long S = 4ll * (long long)s2 - 1020ll * (long long)s1 + 65025ll * (long long)(2 * npairs);
+    const float mean = (float)((double)S / (4.0 * (double)npairs));
+    return mean + eps;
+}
+
+__global__ __launch_bounds__(kScanThreads) void chunk_power_kernel(const uint8_t* __restrict__ iq, size_t nbytes,
+                                                                   size_t chunk_bytes, unsigned tiles_per_chunk,
+                                                                   float eps, int flags, float* __restrict__ power,
+                                                                   unsigned long long* __restrict__ acc) {
+    const size_t c = blockIdx.x / tiles_per_chunk;
+    const unsigned t = blockIdx.x % tiles_per_chunk;
+    const size_t off = c * chunk_bytes;
+    const size_t len = (nbytes - off < chunk_bytes) ? nbytes - off : chunk_bytes;
+    const size_t npairs = len >> 1;
+    if ((flags & GJ_CP_ODD_CHUNK_ZERO) && ((len & 1) || len == 0)) {
+        if (t == 0 && threadIdx.x == 0) power[c] = 0.0f;
+        return;
+    }
+    if (npairs == 0) {
+        if (t == 0 && threadIdx.x == 0) power[c] = __builtin_nanf("");
+        return;
+    }
+    const size_t use_end = off + 2 * npairs;
+    size_t b = off + (size_t)t * kScanTile;
+    size_t e = b + kScanTile;
+    if (e > use_end) e = use_end;
+    if (b > e) b = e;
+    unsigned long long s2 = 0, s1 = 0;
+    block_byte_moments(iq, b, e, s2, s1);
+    if (threadIdx.x == 0) {
+        if (tiles_per_chunk == 1) {
+            power[c] = power_from_moments(s2, s1, npairs, eps);
+        } else {
+            atomicAdd(&acc[2 * c], s2);
+            atomicAdd(&acc[2 * c + 1], s1);
+        }
+    }
+}
+
+__global__ void chunk_power_finalize_kernel(const unsigned long long* __restrict__ acc, size_t nchunks, size_t nbytes,
+                                            size_t chunk_bytes, float eps, int flags, float* __restrict__ power) {
+    const size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    const size_t off = c * chunk_bytes;
+    const size_t len = (nbytes - off < chunk_bytes) ? nbytes - off : chunk_bytes;
+    const size_t npairs = len >> 1;
+    if ((flags & GJ_CP_ODD_CHUNK_ZERO) && ((len & 1) || len == 0)) return;   // already written
+    if (npairs == 0) return;
+    power[c] = power_from_moments(acc[2 * c], acc[2 * c + 1], npairs, eps);
+}
+
+int launch_chunk_power(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
+                       float* d_power) {
+    if (chunk_bytes == 0) return fail(ctx, GJ_ERR_INVALID, "chunk_bytes must be > 0");
+    const size_t nchunks = gj_chunk_count(nbytes, chunk_bytes);
+    if (nchunks == 0) return GJ_OK;
+    const size_t tiles = (chunk_bytes + kScanTile - 1) / kScanTile;
+    if (nchunks * tiles > 0x7fffffffull) return fail(ctx, GJ_ERR_UNSUPPORTED, "too many tiles");
+    unsigned long long* acc = nullptr;
+    if (tiles > 1) {
+        int rc = ensure_workspace(ctx, nchunks * 16);
+        if (rc) return rc;
+        acc = reinterpret_cast<unsigned long long*>(ctx->ws);
+        GJ_HIP(ctx, hipMemsetAsync(acc, 0, nchunks * 16, ctx->stream));
+    }
+    hipLaunchKernelGGL(chunk_power_kernel, dim3((unsigned)(nchunks * tiles)), dim3(kScanThreads), 0, ctx->stream, d_iq,
+                       nbytes, chunk_bytes, (unsigned)tiles, eps, flags, d_power, acc);
+    GJ_LAUNCH_CHECK(ctx);
+    if (tiles > 1) {
+        hipLaunchKernelGGL(chunk_power_finalize_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0,
+                           ctx->stream, acc, nchunks, nbytes, chunk_bytes, eps, flags, d_power);
+        GJ_LAUNCH_CHECK(ctx);
+    }
+    return GJ_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// noise floor: numpy.percentile(power, pct) with the float32 'linear' rule, by radix select
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned float_key(float f) {
+    unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// value of rank `rank` (0-based, ascending, NaNs last) -- whole block must call
+__device__ unsigned block_select(const float* __restrict__ a, size_t n, size_t rank, unsigned* hist /* [256] */,
+                                 unsigned* bc /* [2] */) {
+    unsigned prefix = 0, mask = 0;
+    size_t want = rank;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+            unsigned k = float_key(a[i]);
+            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            size_t cum = 0;
+            unsigned d = 0;
+            for (; d < 256; ++d) {
+                if (cum + hist[d] > want) break;
+                cum += hist[d];
+            }
+            bc[0] = d;
+            bc[1] = (unsigned)(want - cum);
+        }
+        __syncthreads();
+        prefix |= bc[0] << shift;
+        mask |= 255u << shift;
+        want = bc[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+__global__ __launch_bounds__(1024) void power_threshold_kernel(const float* __restrict__ power, size_t n, float pct,
+                                                               float ratio, float* __restrict__ stats,
+                                                               uint8_t* __restrict__ mask) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned bc[2];
+    __shared__ unsigned nan_flag;
+    __shared__ unsigned long long above;
+    __shared__ float thr_s;
+    if (threadIdx.x == 0) { nan_flag = 0; above = 0; }
+    __syncthreads();
+    unsigned has_nan = 0;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) has_nan |= (power[i] != power[i]);
+    if (has_nan) atomicOr(&nan_flag, 1u);
+    // numpy 2.x: q = float32(pct)/float32(100); virtual index = float32(n-1) * q  (all float32)
+    const float q = pct / 100.0f;
+    const float vidx = (float)(n - 1) * q;
+    size_t lo = (size_t)floorf(vidx);
+    if (lo > n - 1) lo = n - 1;
+    const size_t hi = (lo + 1 < n) ? lo + 1 : n - 1;
+    const float g = vidx - (float)lo;
+    const float a = key_float(block_select(power, n, lo, hist, bc));
+    const float b = key_float(block_select(power, n, hi, hist, bc));
+    if (threadIdx.x == 0) {
+        const float d = b - a;
+        float base = (g >= 0.5f) ? (b - d * (1.0f - g)) : (a + d * g);
+        if (nan_flag) base = __builtin_nanf("");
+        if (base <= 0.0f) base = 1.0f;
+        const float thr = base * ratio;
+        stats[0] = base;
+        stats[1] = thr;
+        thr_s = thr;
+    }
+    __syncthreads();
+    const float thr = thr_s;
+    unsigned cnt = 0;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const bool hot = power[i] > thr;
+        cnt += hot;
+        if (mask) mask[i] = hot;
+    }
+    cnt = wave_sum_u32(cnt);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&above, (unsigned long long)cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) stats[2] = (float)above;
+}
+
+int launch_power_threshold(gj_ctx* ctx, const float* d_power, size_t n, float pct, float rise_db, float* d_stats,
+                           uint8_t* d_mask) {
+    if (n == 0) return fail(ctx, GJ_ERR_INVALID, "empty power map");
+    const float ratio = (float)pow(10.0, (double)rise_db / 10.0);
+    hipLaunchKernelGGL(power_threshold_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_power, n, pct, ratio, d_stats,
+                       d_mask);
+    GJ_LAUNCH_CHECK(ctx);
+    return GJ_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// K3 amplitude statistics
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float amp_of(unsigned i8, unsigned q8) {
+    const int vi = 2 * (int)i8 - 255, vq = 2 * (int)q8 - 255;
+    return __fsqrt_rn((float)(vi * vi + vq * vq)) * (1.0f / 255.0f);
+}
+
+constexpr size_t kAmpTileSamples = kScanTile / 2;
+
+struct AmpTile {
+    double sum;
+    long long first;   // absolute sample index or LLONG_MAX
+};
+
+__global__ __launch_bounds__(kScanThreads) void amp_tiles_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
+                                                                 float thr, AmpTile* __restrict__ tiles) {
+    __shared__ double rs[kScanThreads / 64];
+    __shared__ long long rf[kScanThreads / 64];
+    const size_t s0 = (size_t)blockIdx.x * kAmpTileSamples;
+    const size_t s1 = (s0 + kAmpTileSamples < nsamples) ? s0 + kAmpTileSamples : nsamples;
+    const int tid = threadIdx.x;
+    double sum = 0.0;
+    long long first = 0x7fffffffffffffffll;
+    // tiles start at multiples of 64 KiB, so the base is 16-byte aligned when iq is
+    const bool aligned = ((reinterpret_cast<uintptr_t>(iq) & 15) == 0);
+    const size_t nfull = aligned ? ((s1 - s0) >> 3) : 0;   // groups of 8 samples = 16 bytes
+    const uint4* v = reinterpret_cast<const uint4*>(iq + 2 * s0);
+    for (size_t gidx = tid; gidx < nfull; gidx += kScanThreads) {
+        const uint4 w = v[gidx];
+        const unsigned ws[4] = {w.x, w.y, w.z, w.w};
+        float part = 0.f;
+        const long long base = (long long)(s0 + gidx * 8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a0 = amp_of(ws[k] & 255u, (ws[k] >> 8) & 255u);
+            const float a1 = amp_of((ws[k] >> 16) & 255u, ws[k] >> 24);
+            part += a0;
+            part += a1;
+            if (a0 > thr && base + 2 * k < first) first = base + 2 * k;
+            if (a1 > thr && base + 2 * k + 1 < first) first = base + 2 * k + 1;
+        }
+        sum += (double)part;
+    }
+    for (size_t s = s0 + nfull * 8 + tid; s < s1; s += kScanThreads) {
+        const float a = amp_of(iq[2 * s], iq[2 * s + 1]);
+        sum += (double)a;
+        if (a > thr && (long long)s < first) first = (long long)s;
+    }
+    sum = wave_sum_f64(sum);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const long long o = __shfl_xor(first, off, 64);
+        first = o < first ? o : first;
+    }
+    if ((tid & 63) == 0) { rs[tid >> 6] = sum; rf[tid >> 6] = first; }
+    __syncthreads();
+    if (tid == 0) {
+        AmpTile t;
+        t.sum = ((rs[0] + rs[1]) + (rs[2] + rs[3]));
+        long long f = rf[0];
+        for (int k = 1; k < 4; ++k) f = rf[k] < f ? rf[k] : f;
+        t.first = f;
+        tiles[blockIdx.x] = t;
+    }
+}
+
+__device__ double block_sum_f64(double v, double* sh /* [blockDim/64] */) {
+    v = wave_sum_f64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (unsigned k = 0; k < blockDim.x / 64; ++k) t += sh[k];
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void amp_finalize_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
+                                                            const AmpTile* __restrict__ tiles, size_t ntiles,
+                                                            gj_amp_stats* __restrict__ out) {
+    __shared__ double sh[16];
+    __shared__ long long first_s;
+    if (threadIdx.x == 0) first_s = 0x7fffffffffffffffll;
+    __syncthreads();
+    long long f = 0x7fffffffffffffffll;
+    for (size_t t = threadIdx.x; t < ntiles; t += blockDim.x) f = tiles[t].first < f ? tiles[t].first : f;
+    if (f != 0x7fffffffffffffffll) atomicMin(&first_s, f);
+    __syncthreads();
+    const long long first = first_s;
+    if (first == 0x7fffffffffffffffll) {
+        if (threadIdx.x == 0) {
+            out->first_index = -1; out->count = 0; out->sum = 0.0; out->mean = 0.f; out->reserved = 0.f;
+        }
+        return;
+    }
+    const size_t t0 = (size_t)first / kAmpTileSamples;
+    double acc = 0.0;
+    for (size_t t = t0 + 1 + threadIdx.x; t < ntiles; t += blockDim.x) acc += tiles[t].sum;
+    // remainder of the tile that holds the first hit
+    const size_t e0 = ((t0 + 1) * kAmpTileSamples < nsamples) ? (t0 + 1) * kAmpTileSamples : nsamples;
+    for (size_t s = (size_t)first + threadIdx.x; s < e0; s += blockDim.x) acc += (double)amp_of(iq[2 * s], iq[2 * s + 1]);
+    const double total = block_sum_f64(acc, sh);
+    if (threadIdx.x == 0) {
+        const unsigned long long cnt = nsamples - (size_t)first;
+        out->first_index = first;
+        out->count = cnt;
+        out->sum = total;
+        out->mean = (float)(total / (double)cnt);
+        out->reserved = 0.f;
+    }
+}
+
+int launch_amp_stats(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, float threshold, gj_amp_stats* d_out) {
+    const size_t nsamples = nbytes / 2;
+    const size_t ntiles = (nsamples + kAmpTileSamples - 1) / kAmpTileSamples;
+    if (ntiles > 0x7fffffffull) return fail(ctx, GJ_ERR_UNSUPPORTED, "capture too long");
+    int rc = ensure_workspace(ctx, (ntiles + 1) * sizeof(AmpTile));
+    if (rc) return rc;
+    AmpTile* tiles = reinterpret_cast<AmpTile*>(ctx->ws);
+    if (ntiles) {
+        hipLaunchKernelGGL(amp_tiles_kernel, dim3((unsigned)ntiles), dim3(kScanThreads), 0, ctx->stream, d_iq, nsamples,
+                           threshold, tiles);
+        GJ_LAUNCH_CHECK(ctx);
+    }
+    hipLaunchKernelGGL(amp_finalize_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_iq, nsamples, tiles, ntiles, d_out);
+    GJ_LAUNCH_CHECK(ctx);
+    return GJ_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// K4 onset: moving average of |z|^2 against factor x noise, exact integer window sums
+// ---------------------------------------------------------------------------------------
+constexpr int kOnsetOut = 8192;    // moving-average positions per workgroup
+constexpr int kOnsetMaxWin = 8192;
+constexpr int kOnsetLds = kOnsetOut + kOnsetMaxWin;   // u32 words (64 KiB)
+
+struct OnsetScratch {
+    unsigned long long first;   // min index of the moving average above threshold
+    float noise;
+    float thr;
+};
+
+__device__ __forceinline__ unsigned m_of(unsigned i8, unsigned q8) {
+    const int vi = 2 * (int)i8 - 255, vq = 2 * (int)q8 - 255;
+    return (unsigned)(vi * vi + vq * vq);   // = 4 |z|^2
+}
+
+__global__ __launch_bounds__(kScanThreads) void onset_noise_kernel(const uint8_t* __restrict__ iq, int noise_samples,
+                                                                   float factor, OnsetScratch* __restrict__ sc) {
+    unsigned long long s2 = 0, s1 = 0;
+    block_byte_moments(iq, 0, (size_t)2 * noise_samples, s2, s1);
+    if (threadIdx.x == 0) {
+        const long long S = 4ll * (long long)s2 - 1020ll * (long long)s1 + 65025ll * (2ll * noise_samples);
+        float noise = (float)((double)S / (4.0 * (double)noise_samples));
+        if (noise == 0.f) noise = 1e-9f;
+        sc->noise = noise;
+        sc->thr = noise * factor;
+        sc->first = ~0ull;
+    }
+}
+
+__device__ __forceinline__ int onset_pad(int k) { return k + (k >> 5); }   // spreads stride-`per` accesses over banks
+
+__global__ __launch_bounds__(kScanThreads) void onset_scan_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
+                                                                  int window, OnsetScratch* __restrict__ sc) {
+    __shared__ unsigned pre[kOnsetLds + kOnsetLds / 32 + 2];
+    __shared__ unsigned thread_tot[kScanThreads];
+    const size_t nout = nsamples - (size_t)window + 1;   // valid positions
+    const size_t o0 = (size_t)blockIdx.x * kOnsetOut;
+    if (o0 >= nout) return;
+    // everything before this tile already decided?
+    if (__hip_atomic_load(&sc->first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < o0) return;
+    const size_t o1 = (o0 + kOnsetOut < nout) ? o0 + kOnsetOut : nout;
+    const int need = (int)(o1 - o0) + window - 1;   // samples [o0, o0+need)
+    const int tid = threadIdx.x;
+    // (A) coalesced load: pre[1 + k] = 4|z_k|^2
+    const uint16_t* iq16 = reinterpret_cast<const uint16_t*>(iq) + o0;
+    for (int k = tid; k < need; k += kScanThreads) {
+        const unsigned w = iq16[k];
+        pre[onset_pad(k + 1)] = m_of(w & 255u, w >> 8);
+    }
+    if (tid == 0) pre[0] = 0;
+    __syncthreads();
+    // (B) inclusive prefix inside each thread's contiguous span
+    const int per = (need + kScanThreads - 1) / kScanThreads;
+    const int lo = tid * per;
+    const int hi = (lo + per < need) ? lo + per : need;
+    unsigned run = 0;
+    for (int k = lo; k < hi; ++k) {
+        run += pre[onset_pad(k + 1)];
+        pre[onset_pad(k + 1)] = run;
+    }
+    thread_tot[tid] = run;
+    __syncthreads();
+    // (C) exclusive scan of the 256 span totals
+    if (tid < 64) {
+        unsigned t0 = thread_tot[4 * tid], t1 = thread_tot[4 * tid + 1], t2 = thread_tot[4 * tid + 2],
+                 t3 = thread_tot[4 * tid + 3];
+        unsigned tot = t0 + t1 + t2 + t3, inc = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_up(inc, off, 64);
+            if (tid >= off) inc += o;
+        }
+        const unsigned ex = inc - tot;
+        thread_tot[4 * tid] = ex;
+        thread_tot[4 * tid + 1] = ex + t0;
+        thread_tot[4 * tid + 2] = ex + t0 + t1;
+        thread_tot[4 * tid + 3] = ex + t0 + t1 + t2;
+    }
+    __syncthreads();
+    // (D) fold the span offsets in
+    const unsigned add = thread_tot[tid];
+    for (int k = lo; k < hi; ++k) pre[onset_pad(k + 1)] += add;
+    __syncthreads();
+    const double thr = (double)sc->thr;
+    const double scale = 0.25 / (double)window;
+    unsigned long long best = ~0ull;
+    const int nloc = (int)(o1 - o0);
+    for (int k = tid; k < nloc; k += kScanThreads) {
+        const unsigned S = pre[onset_pad(k + window)] - pre[onset_pad(k)];
+        if ((double)S * scale > thr) { best = o0 + k; break; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off, 64);
+        best = o < best ? o : best;
+    }
+    if ((tid & 63) == 0 && best != ~0ull) atomicMin(&sc->first, best);
+}
+
+__global__ void onset_finalize_kernel(const OnsetScratch* __restrict__ sc, int window, int valid, gj_onset* __restrict__ out) {
+    if (!valid) {
+        out->start_index = -1; out->noise_power = 0.f; out->threshold = 0.f;
+        return;
+    }
+    out->start_index = (sc->first == ~0ull) ? -1 : (long long)sc->first + window / 2;
+    out->noise_power = sc->noise;
+    out->threshold = sc->thr;
+}
+
+int launch_onset(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, int noise_samples, int window, float factor,
+                 gj_onset* d_out) {
+    if (noise_samples <= 0 || window <= 0) return fail(ctx, GJ_ERR_INVALID, "noise_samples and window must be > 0");
+    if (window > kOnsetMaxWin) return fail(ctx, GJ_ERR_UNSUPPORTED, "window > %d", kOnsetMaxWin);
+    if ((reinterpret_cast<uintptr_t>(d_iq) & 1) != 0) return fail(ctx, GJ_ERR_INVALID, "capture must be 2-byte aligned");
+    const size_t nsamples = nbytes / 2;
+    int rc = ensure_workspace(ctx, sizeof(OnsetScratch));
+    if (rc) return rc;
+    OnsetScratch* sc = reinterpret_cast<OnsetScratch*>(ctx->ws);
+    const int valid = nsamples >= (size_t)noise_samples + (size_t)window;   // triangulateTDOA.py:39
+    if (valid) {
+        hipLaunchKernelGGL(onset_noise_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_iq, noise_samples, factor, sc);
+        GJ_LAUNCH_CHECK(ctx);
+        const size_t nout = nsamples - window + 1;
+        const size_t ntiles = (nout + kOnsetOut - 1) / kOnsetOut;
+        if (ntiles > 0x7fffffffull) return fail(ctx, GJ_ERR_UNSUPPORTED, "capture too long");
+        hipLaunchKernelGGL(onset_scan_kernel, dim3((unsigned)ntiles), dim3(kScanThreads), 0, ctx->stream, d_iq, nsamples,
+                           window, sc);
+        GJ_LAUNCH_CHECK(ctx);
+    }
+    hipLaunchKernelGGL(onset_finalize_kernel, dim3(1), dim3(1), 0, ctx->stream, sc, window, valid, d_out);
+    GJ_LAUNCH_CHECK(ctx);
+    return GJ_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// byte histogram of raw_chunk[::stride] for every chunk the waterfall keeps
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void histogram_kernel(const uint8_t* __restrict__ iq, size_t nbytes, size_t chunk_bytes,
+                                                        size_t min_bytes, int stride, size_t per_chunk, size_t total,
+                                                        unsigned long long* __restrict__ hist) {
+    __shared__ unsigned h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t c = i / per_chunk, k = i % per_chunk;
+        const size_t off = c * chunk_bytes;
+        const size_t len = (nbytes - off < chunk_bytes) ? nbytes - off : chunk_bytes;
+        if (len < min_bytes) continue;
+        const size_t p = k * (size_t)stride;
+        if (p < len) atomicAdd(&h[iq[off + p]], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+int launch_histogram(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_samples, int nperseg, int stride,
+                     unsigned long long* d_hist) {
+    if (stride <= 0 || chunk_samples == 0) return fail(ctx, GJ_ERR_INVALID, "bad stride/chunk");
+    GJ_HIP(ctx, hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), ctx->stream));
+    const size_t chunk_bytes = 2 * chunk_samples;
+    const size_t nchunks = (nbytes + chunk_bytes - 1) / chunk_bytes;
+    if (nchunks == 0) return GJ_OK;
+    const size_t per_chunk = (chunk_bytes + stride - 1) / stride;
+    const size_t total = nchunks * per_chunk;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(histogram_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_iq, nbytes, chunk_bytes,
+                       (size_t)2 * nperseg, stride, per_chunk, total, d_hist);
+    GJ_LAUNCH_CHECK(ctx);
+    return GJ_OK;
+}
+
+}   // namespace gj

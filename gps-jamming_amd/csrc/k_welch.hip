@@ -1,0 +1,248 @@
+// K2: fused uint8 unpack + periodic-Hann Welch PSD (gfx950).
+// Replaces skrypty/widmo_plot.py:38-52 including scipy.signal.welch(..., nperseg=N,
+// return_onesided=False) (widmo_plot.py:48; scipy/signal/_spectral_py.py _spectral_helper).
+//
+// One 256-thread workgroup owns a run of consecutive segments of one 1-s chunk.  Per step it
+// transforms 4096 points = 4096/N overlapping segments: every thread pulls its 16 samples
+// straight from the uint8 stream (2-byte loads, 128 B per wave instruction; the 50 % overlap
+// re-read is served by L2), applies unpack and window (one FMA + one multiply per component), runs the
+// register-resident Stockham passes of fft_core.h with LDS exchanges, and accumulates
+// |X[k]|^2 in 16 VGPRs for the bins it ends up holding.  Per-segment mean removal
+// (detrend='constant') is applied in the frequency domain: the periodic Hann window has
+// only three non-zero DFT bins (N/2 at 0, -N/4 at +-1), so
+//     FFT(w (v - m)) = FFT(w v) - m W   touches bins 0, 1, N-1 only,
+// with m = (exact integer sum of the segment)/N from a wave-shuffle reduction.
+// Work in integer LSB units v = 2u-255 (= 255 x); 1/255^2, 1/(fs sum w^2) and 1/nseg are
+// folded into the finalize kernel, which also sums the per-workgroup partial spectra in a
+// fixed order (deterministic), applies fftshift and writes the optional dB row.
+#include "gj_common.h"
+
+namespace gj {
+
+struct WelchGeom {
+    unsigned long long chunk_samples;
+    unsigned nchunks;     // rows kept
+    unsigned splits;      // workgroups per chunk
+    unsigned nseg_full;   // segments in a full chunk
+    unsigned nseg_last;   // segments in the last kept chunk
+};
+
+template <int N>
+struct WelchBins {   // (thread, slot) that ends up holding bin k
+    static constexpr int TF = N / 16;
+    static constexpr int jl(int k) { return k % TF; }
+    static constexpr int slot(int k) { return k / TF; }
+};
+
+template <int N, int PASS>
+__device__ __forceinline__ void welch_passes(cf (&v)[16], cf* lds, int base, int jl, const cf (&tw)[3][15]) {
+    constexpr int NP = fft_npass(N);
+    fft_pass<N, PASS>(v, tw[PASS]);
+    if constexpr (PASS + 1 < NP) {
+        lds_scatter<N, PASS>(v, lds, base, jl);
+        __syncthreads();
+        lds_gather<N>(v, lds, base, jl);
+        __syncthreads();
+        welch_passes<N, PASS + 1>(v, lds, base, jl, tw);
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(kBlockThreads, 2) void welch_kernel(const uint8_t* __restrict__ iq, WelchGeom g,
+                                                              const cf* __restrict__ twtab,
+                                                              const float* __restrict__ wintab,
+                                                              float* __restrict__ partial) {
+    constexpr int TF = N / 16, B = kBlockPoints / N, NP = fft_npass(N);
+    constexpr int WPF = (TF >= 64) ? TF / 64 : 1;   // waves per transform
+    __shared__ cf lds[lds_span(kBlockPoints)];
+    __shared__ int wsum[2][B][WPF][2];
+    const int tid = threadIdx.x;
+    const int b = tid / TF, jl = tid % TF;
+    const unsigned c = blockIdx.x / g.splits, part = blockIdx.x % g.splits;
+    const unsigned nseg = (c + 1 == g.nchunks) ? g.nseg_last : g.nseg_full;
+    const unsigned seg_lo = (unsigned)((unsigned long long)part * nseg / g.splits);
+    const unsigned seg_hi = (unsigned)((unsigned long long)(part + 1) * nseg / g.splits);
+
+    cf tw[3][15];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int k = 0; k < 15; ++k) tw[p][k] = cf{1.f, 0.f};
+    if constexpr (NP > 1) load_twiddles<N, 1>(tw[1], twtab, jl);
+    if constexpr (NP > 2) load_twiddles<N, 2>(tw[2], twtab, jl);
+
+    float win[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) win[s] = wintab[jl + TF * s];
+    float acc[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = 0.f;
+
+    const uint16_t* chunk16 = reinterpret_cast<const uint16_t*>(iq) + (size_t)c * g.chunk_samples;
+    const unsigned nsteps = (seg_hi - seg_lo + B - 1) / B;
+    for (unsigned it = 0; it < nsteps; ++it) {
+        const unsigned seg = seg_lo + it * B + b;
+        const bool active = seg < seg_hi;
+        const uint16_t* src = chunk16 + (size_t)(active ? seg : seg_lo) * (N / 2) + jl;
+        cf v[16];
+        unsigned packed = 0;   // sum I in bits 0..15, sum Q in bits 16..31 (16 * 255 < 65536)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const unsigned u = src[TF * s];
+            const float fi = (float)(u & 255u), fq = (float)(u >> 8);
+            v[s].x = fmaf(fi, 2.0f, -255.0f) * win[s];   // w (2u - 255)
+            v[s].y = fmaf(fq, 2.0f, -255.0f) * win[s];
+            packed += (u & 255u) | ((u >> 8) << 16);
+        }
+        int si = (int)(packed & 0xffffu), sq = (int)(packed >> 16);
+        if constexpr (TF >= 64) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                si += __shfl_xor(si, off, 64);
+                sq += __shfl_xor(sq, off, 64);
+            }
+            if ((tid & 63) == 0) {
+                wsum[it & 1][b][(tid >> 6) % WPF][0] = si;
+                wsum[it & 1][b][(tid >> 6) % WPF][1] = sq;
+            }
+        } else {
+#pragma unroll
+            for (int off = TF / 2; off > 0; off >>= 1) {
+                si += __shfl_xor(si, off, 64);
+                sq += __shfl_xor(sq, off, 64);
+            }
+        }
+
+        welch_passes<N, 0>(v, lds, b * lds_span(N), jl, tw);
+
+        // detrend in the frequency domain on bins 0, 1, N-1
+        if constexpr (TF >= 64) {
+            if (jl <= 1 || jl == TF - 1) {
+                si = 0; sq = 0;
+#pragma unroll
+                for (int k = 0; k < WPF; ++k) { si += wsum[it & 1][b][k][0]; sq += wsum[it & 1][b][k][1]; }
+            }
+        }
+        const float Sx = (float)(2 * si - 255 * N), Sy = (float)(2 * sq - 255 * N);
+        if (jl == WelchBins<N>::jl(0)) {
+            v[WelchBins<N>::slot(0)].x -= 0.5f * Sx;
+            v[WelchBins<N>::slot(0)].y -= 0.5f * Sy;
+        }
+        if (jl == WelchBins<N>::jl(1)) {
+            v[WelchBins<N>::slot(1)].x += 0.25f * Sx;
+            v[WelchBins<N>::slot(1)].y += 0.25f * Sy;
+        }
+        if (jl == WelchBins<N>::jl(N - 1)) {
+            v[WelchBins<N>::slot(N - 1)].x += 0.25f * Sx;
+            v[WelchBins<N>::slot(N - 1)].y += 0.25f * Sy;
+        }
+        if (active) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc[s] = fmaf(v[s].x, v[s].x, fmaf(v[s].y, v[s].y, acc[s]));
+        }
+    }
+    float* out = partial + ((size_t)blockIdx.x * B + b) * N + jl;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) out[TF * s] = acc[s];
+}
+
+__global__ __launch_bounds__(256) void welch_finalize_kernel(const float* __restrict__ partial, int n, unsigned per_chunk,
+                                                             unsigned nchunks, float scale_full, float scale_last,
+                                                             int shift, float* __restrict__ psd,
+                                                             float* __restrict__ psd_db) {
+    const unsigned c = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float* p = partial + (size_t)c * per_chunk * n + k;
+    float s = 0.f;
+    for (unsigned i = 0; i < per_chunk; ++i) s += p[(size_t)i * n];
+    const float val = s * ((c + 1 == nchunks) ? scale_last : scale_full);
+    const int o = shift ? ((k + n / 2) & (n - 1)) : k;
+    psd[(size_t)c * n + o] = val;
+    if (psd_db) psd_db[(size_t)c * n + o] = 10.0f * log10f(val + 1e-15f);
+}
+
+struct WelchPlan {
+    WelchGeom g;
+    size_t rows;
+    int batch;
+    size_t ws_bytes;
+    double scale_full, scale_last;
+};
+
+static bool welch_plan(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int nperseg, double fs, WelchPlan& pl) {
+    if (nperseg < 16 || nperseg > 4096 || (nperseg & (nperseg - 1))) return false;
+    if (chunk_samples < (size_t)nperseg) return false;
+    pl.rows = gj_welch_rows(nbytes, chunk_samples, nperseg);
+    pl.batch = kBlockPoints / nperseg;
+    pl.g.chunk_samples = chunk_samples;
+    pl.g.nchunks = (unsigned)pl.rows;
+    const size_t step = nperseg / 2;
+    pl.g.nseg_full = (unsigned)((chunk_samples - nperseg) / step + 1);
+    size_t last_len = chunk_samples;
+    if (pl.rows) {
+        const size_t total = nbytes / 2;
+        const size_t rem = total - (pl.rows - 1) * chunk_samples;
+        last_len = rem < chunk_samples ? rem : chunk_samples;
+    }
+    pl.g.nseg_last = (unsigned)((last_len - nperseg) / step + 1);
+    // enough workgroups to fill 256 CUs several times over, at least ~2 steps each
+    size_t want = pl.rows ? (size_t)(16 * ctx->num_cus + pl.rows - 1) / pl.rows : 1;
+    size_t cap = pl.g.nseg_full / (2 * (size_t)pl.batch);
+    if (cap < 1) cap = 1;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    pl.g.splits = (unsigned)want;
+    pl.ws_bytes = pl.rows * want * (size_t)kBlockPoints * sizeof(float);
+    const double sw2 = 0.375 * nperseg;   // sum of the squared periodic Hann window
+    pl.scale_full = 1.0 / (fs * sw2 * 65025.0 * (double)pl.g.nseg_full);
+    pl.scale_last = 1.0 / (fs * sw2 * 65025.0 * (double)pl.g.nseg_last);
+    return true;
+}
+
+size_t welch_workspace(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int nperseg) {
+    WelchPlan pl;
+    if (!welch_plan(ctx, nbytes, chunk_samples, nperseg, 1.0, pl)) return 0;
+    return pl.ws_bytes;
+}
+
+extern const float* window_table(gj_ctx* ctx, int n);
+
+template <int N>
+static void welch_launch(gj_ctx* ctx, const uint8_t* d_iq, const WelchPlan& pl, float* partial) {
+    hipLaunchKernelGGL(welch_kernel<N>, dim3(pl.g.nchunks * pl.g.splits), dim3(kBlockThreads), 0, ctx->stream, d_iq,
+                       pl.g, ctx->d_twiddle, window_table(ctx, N), partial);
+}
+
+int launch_welch(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_samples, int nperseg, double fs,
+                 int flags, float* d_psd, float* d_psd_db) {
+    WelchPlan pl;
+    if (!(fs > 0.0)) return fail(ctx, GJ_ERR_INVALID, "fs must be > 0");
+    if (!welch_plan(ctx, nbytes, chunk_samples, nperseg, fs, pl))
+        return fail(ctx, GJ_ERR_UNSUPPORTED, "nperseg must be a power of two in [16, 4096] and <= chunk_samples");
+    if ((reinterpret_cast<uintptr_t>(d_iq) & 1) != 0) return fail(ctx, GJ_ERR_INVALID, "capture must be 2-byte aligned");
+    if (pl.rows == 0) return GJ_OK;
+    if ((unsigned long long)pl.g.nchunks * pl.g.splits > 0x7fffffffull) return fail(ctx, GJ_ERR_UNSUPPORTED, "too many chunks");
+    int rc = ensure_workspace(ctx, pl.ws_bytes);
+    if (rc) return rc;
+    float* partial = reinterpret_cast<float*>(ctx->ws);
+    switch (nperseg) {
+        case 16: welch_launch<16>(ctx, d_iq, pl, partial); break;
+        case 32: welch_launch<32>(ctx, d_iq, pl, partial); break;
+        case 64: welch_launch<64>(ctx, d_iq, pl, partial); break;
+        case 128: welch_launch<128>(ctx, d_iq, pl, partial); break;
+        case 256: welch_launch<256>(ctx, d_iq, pl, partial); break;
+        case 512: welch_launch<512>(ctx, d_iq, pl, partial); break;
+        case 1024: welch_launch<1024>(ctx, d_iq, pl, partial); break;
+        case 2048: welch_launch<2048>(ctx, d_iq, pl, partial); break;
+        default: welch_launch<4096>(ctx, d_iq, pl, partial); break;
+    }
+    GJ_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(welch_finalize_kernel, dim3((nperseg + 255) / 256, pl.g.nchunks), dim3(256), 0, ctx->stream,
+                       partial, nperseg, pl.g.splits * (unsigned)pl.batch, pl.g.nchunks, (float)pl.scale_full,
+                       (float)pl.scale_last, (flags & GJ_WELCH_SHIFT) ? 1 : 0, d_psd, d_psd_db);
+    GJ_LAUNCH_CHECK(ctx);
+    return GJ_OK;
+}
+
+}   // namespace gj

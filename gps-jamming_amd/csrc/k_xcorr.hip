@@ -1,0 +1,303 @@
+// K5: pairwise TDOA cross-correlation lag (gfx950).
+// Replaces scipy.signal.correlate(sig1, sig0, 'full') + argmax|.| - (N-1)
+// (skrypty/triangulateTDOA.py:80-89; scipy/signal/_signaltools.py fftconvolve).
+//
+// Linear correlation through a zero-padded circular one of length L = 2^p >= 2N-1 (any
+// length >= 2N-1 gives the same correlation values; scipy picks next_fast_len, we pick the
+// next power of two).  L = L1 x 4096 four-step FFT out of HBM/L2 built from the block FFT
+// of fft_core.h:
+//   forward  : columns (length L1, stride 4096; unpack + zero-pad fused) -> twiddle W_L^(k1 n2)
+//              -> rows (length 4096, contiguous)            spectrum stored as Z[k1][k2], k = k1 + L1 k2
+//   inverse  : conj(C) = conj(Z_j) Z_i fused into the row pass -> twiddle -> column pass with
+//              |.|^2 + arg-max fused (the correlation itself is never written).
+// The inverse uses ifft(C) = conj(fft(conj C))/L, and |.| is conjugation-invariant.
+// Tie rule of numpy.argmax (first maximum in 'full' order m = lag + N-1) is kept.
+#include "gj_common.h"
+
+namespace gj {
+
+constexpr int kRow = 4096;   // L2: contiguous row length
+
+struct XcParams {
+    const uint8_t* iq[GJ_MAX_ANTENNAS];
+    unsigned long long nsamples[GJ_MAX_ANTENNAS];
+    int pair_i[GJ_MAX_ANTENNAS * GJ_MAX_ANTENNAS / 2 + 8];
+    int pair_j[GJ_MAX_ANTENNAS * GJ_MAX_ANTENNAS / 2 + 8];
+    unsigned long long n;   // slice length in samples
+    unsigned long long L;   // FFT length
+    int L1;
+    int n_ant, n_pairs;
+};
+constexpr int kMaxPairs = GJ_MAX_ANTENNAS * GJ_MAX_ANTENNAS / 2 + 8;
+
+struct XcCand {
+    float val;
+    int m;
+};
+
+__device__ __forceinline__ cf twiddle_big(unsigned long long m, unsigned long long L) {
+    // exp(-2 pi i m / L), m < L <= 2^24: the ratio is exact in float
+    float s, c;
+    sincospif(-2.0f * ((float)m / (float)L), &s, &c);
+    return cf{c, s};
+}
+
+template <int N, int PASS>
+__device__ __forceinline__ void xc_passes(cf (&v)[16], cf* lds, int base, int jl, const cf* twtab) {
+    constexpr int NP = fft_npass(N);
+    cf tw[15];
+    if constexpr (PASS > 0) load_twiddles<N, PASS>(tw, twtab, jl);
+    fft_pass<N, PASS>(v, tw);
+    if constexpr (PASS + 1 < NP) {
+        lds_scatter<N, PASS>(v, lds, base, jl);
+        __syncthreads();
+        lds_gather<N>(v, lds, base, jl);
+        __syncthreads();
+        xc_passes<N, PASS + 1>(v, lds, base, jl, twtab);
+    }
+}
+
+__global__ void xc_prepare_kernel(XcParams P, const long long* __restrict__ starts, long long* __restrict__ eff,
+                                  int* __restrict__ valid) {
+    const int a = threadIdx.x;
+    if (a >= P.n_ant) return;
+    const long long s = starts[a];
+    const bool ok = s >= 0 && (unsigned long long)s + P.n <= P.nsamples[a];
+    valid[a] = ok;
+    eff[a] = ok ? s : 0;
+}
+
+// ---- column pass: transforms of length L1 over rows, a tile of 4096/L1 adjacent columns ----
+// MODE 0: forward, input = uint8 slice (zero-padded), output Y[a][k1][n2] * W_L^(k1 n2)
+// MODE 1: inverse tail, input = D[p][k1][n2], output = per-workgroup arg-max candidate
+template <int L1, int MODE>
+__global__ __launch_bounds__(kBlockThreads) void xc_cols_kernel(XcParams P, const long long* __restrict__ eff,
+                                                                const int* __restrict__ valid,
+                                                                const cf* __restrict__ twtab, cf* __restrict__ buf,
+                                                                XcCand* __restrict__ cand) {
+    constexpr int TF = L1 / 16, B = kBlockPoints / L1;
+    constexpr int RS = lds_span(L1) + 1;   // LDS region stride: b-fastest lanes land on different banks
+    __shared__ cf lds[B * RS + 16];
+    __shared__ XcCand red[kBlockThreads / 64];
+    const int tid = threadIdx.x;
+    const int b = tid % B, jl = tid / B;
+    const int t = blockIdx.y;   // antenna (MODE 0) or pair (MODE 1)
+    const int n2 = blockIdx.x * B + b;
+    cf v[16];
+    if constexpr (MODE == 0) {
+        const bool ok = valid[t] != 0;
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(P.iq[t]) + (ok ? eff[t] : 0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const unsigned long long n = (unsigned long long)(jl + TF * s) * kRow + n2;
+            if (ok && n < P.n) {
+                const unsigned u = src[n];
+                v[s] = cf{(float)(2 * (int)(u & 255u) - 255), (float)(2 * (int)(u >> 8) - 255)};
+            } else {
+                v[s] = cf{0.f, 0.f};
+            }
+        }
+    } else {
+        const cf* src = buf + (size_t)t * P.L;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) v[s] = src[(size_t)(jl + TF * s) * kRow + n2];
+    }
+    xc_passes<L1, 0>(v, lds, b * RS, jl, twtab);
+    if constexpr (MODE == 0) {
+        cf* dst = buf + (size_t)t * P.L;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int k1 = jl + TF * s;
+            dst[(size_t)k1 * kRow + n2] = cmul(v[s], twiddle_big((unsigned long long)k1 * n2, P.L));
+        }
+    } else {
+        float best = -1.f;
+        int best_m = 0x7fffffff;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const unsigned long long n = (unsigned long long)(jl + TF * s) * kRow + n2;
+            long long m;
+            if (n < P.n) m = (long long)n + (long long)P.n - 1;                 // lag = n >= 0
+            else if (n > P.L - P.n) m = (long long)n - (long long)P.L + (long long)P.n - 1;   // lag = n - L < 0
+            else continue;
+            const float val = v[s].x * v[s].x + v[s].y * v[s].y;
+            if (val > best || (val == best && (int)m < best_m)) { best = val; best_m = (int)m; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(best, off, 64);
+            const int om = __shfl_xor(best_m, off, 64);
+            if (ov > best || (ov == best && om < best_m)) { best = ov; best_m = om; }
+        }
+        if ((tid & 63) == 0) red[tid >> 6] = XcCand{best, best_m};
+        __syncthreads();
+        if (tid == 0) {
+            XcCand r = red[0];
+            for (int k = 1; k < kBlockThreads / 64; ++k)
+                if (red[k].val > r.val || (red[k].val == r.val && red[k].m < r.m)) r = red[k];
+            cand[(size_t)t * gridDim.x + blockIdx.x] = r;
+        }
+    }
+}
+
+// ---- row pass: contiguous 4096-point transforms --------------------------------------------
+// MODE 0: forward, in place on Y[a] -> Z[a]
+// MODE 1: inverse head, input conj(Z_j) * Z_i, output D[p][k1][n2] * W_L^(k1 n2)
+template <int MODE>
+__global__ __launch_bounds__(kBlockThreads) void xc_rows_kernel(XcParams P, const cf* __restrict__ twtab,
+                                                                cf* __restrict__ spec, cf* __restrict__ dbuf) {
+    constexpr int N = kRow, TF = N / 16;
+    __shared__ cf lds[lds_span(kBlockPoints)];
+    const int jl = threadIdx.x;
+    const int r = blockIdx.x;   // k1
+    const int t = blockIdx.y;
+    cf v[16];
+    if constexpr (MODE == 0) {
+        const cf* src = spec + (size_t)t * P.L + (size_t)r * N;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) v[s] = src[jl + TF * s];
+    } else {
+        const cf* zi = spec + (size_t)P.pair_i[t] * P.L + (size_t)r * N;
+        const cf* zj = spec + (size_t)P.pair_j[t] * P.L + (size_t)r * N;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const cf a = zj[jl + TF * s], bb = zi[jl + TF * s];
+            v[s] = cf{a.x * bb.x + a.y * bb.y, a.x * bb.y - a.y * bb.x};   // conj(a) * b
+        }
+    }
+    xc_passes<N, 0>(v, lds, 0, jl, twtab);
+    if constexpr (MODE == 0) {
+        cf* dst = spec + (size_t)t * P.L + (size_t)r * N;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) dst[jl + TF * s] = v[s];
+    } else {
+        cf* dst = dbuf + (size_t)t * P.L + (size_t)r * N;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int n2 = jl + TF * s;
+            dst[n2] = cmul(v[s], twiddle_big((unsigned long long)r * n2, P.L));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void xc_finalize_kernel(XcParams P, const XcCand* __restrict__ cand, unsigned ncand,
+                                                          const int* __restrict__ valid, int* __restrict__ lags,
+                                                          float* __restrict__ peaks) {
+    __shared__ XcCand red[256];
+    const int p = blockIdx.x;
+    XcCand r{-1.f, 0x7fffffff};
+    for (unsigned k = threadIdx.x; k < ncand; k += blockDim.x) {
+        const XcCand c = cand[(size_t)p * ncand + k];
+        if (c.val > r.val || (c.val == r.val && c.m < r.m)) r = c;
+    }
+    red[threadIdx.x] = r;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const XcCand c = red[threadIdx.x + off];
+            XcCand& mine = red[threadIdx.x];
+            if (c.val > mine.val || (c.val == mine.val && c.m < mine.m)) mine = c;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const bool ok = valid[P.pair_i[p]] && valid[P.pair_j[p]];
+        lags[p] = ok ? red[0].m - (int)(P.n - 1) : GJ_LAG_INVALID;
+        // inputs were 2(u-127.5): |c| = sqrt(val) / L / 4
+        peaks[p] = ok ? sqrtf(red[0].val) * (0.25f / (float)P.L) : 0.f;
+    }
+}
+
+static unsigned long long xc_fft_len(size_t n) {
+    unsigned long long L = 65536;
+    while (L < 2ull * n - 1) L <<= 1;
+    return L;
+}
+
+size_t xcorr_workspace(gj_ctx*, int n_ant, size_t n_samples, int n_pairs) {
+    if (n_samples == 0) return 0;
+    const unsigned long long L = xc_fft_len(n_samples);
+    const size_t ncand = (size_t)(L / kBlockPoints);
+    return (size_t)(n_ant + n_pairs) * L * sizeof(cf) + (size_t)n_pairs * ncand * sizeof(XcCand) + 4096;
+}
+
+template <int L1>
+static void xc_launch_cols(gj_ctx* ctx, int mode, const XcParams& P, int count, const long long* eff, const int* valid,
+                           cf* buf, XcCand* cand) {
+    const dim3 grid((unsigned)(P.L / kBlockPoints), (unsigned)count);
+    if (mode == 0)
+        hipLaunchKernelGGL((xc_cols_kernel<L1, 0>), grid, dim3(kBlockThreads), 0, ctx->stream, P, eff, valid,
+                           ctx->d_twiddle, buf, cand);
+    else
+        hipLaunchKernelGGL((xc_cols_kernel<L1, 1>), grid, dim3(kBlockThreads), 0, ctx->stream, P, eff, valid,
+                           ctx->d_twiddle, buf, cand);
+}
+
+static void xc_cols(gj_ctx* ctx, int mode, const XcParams& P, int count, const long long* eff, const int* valid, cf* buf,
+                    XcCand* cand) {
+    switch (P.L1) {
+        case 16: xc_launch_cols<16>(ctx, mode, P, count, eff, valid, buf, cand); break;
+        case 32: xc_launch_cols<32>(ctx, mode, P, count, eff, valid, buf, cand); break;
+        case 64: xc_launch_cols<64>(ctx, mode, P, count, eff, valid, buf, cand); break;
+        case 128: xc_launch_cols<128>(ctx, mode, P, count, eff, valid, buf, cand); break;
+        case 256: xc_launch_cols<256>(ctx, mode, P, count, eff, valid, buf, cand); break;
+        case 512: xc_launch_cols<512>(ctx, mode, P, count, eff, valid, buf, cand); break;
+        case 1024: xc_launch_cols<1024>(ctx, mode, P, count, eff, valid, buf, cand); break;
+        case 2048: xc_launch_cols<2048>(ctx, mode, P, count, eff, valid, buf, cand); break;
+        default: xc_launch_cols<4096>(ctx, mode, P, count, eff, valid, buf, cand); break;
+    }
+}
+
+int launch_xcorr(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, int n_ant, const int64_t* d_starts,
+                 size_t n_samples, const int32_t* pairs, int n_pairs, int32_t* d_lags, float* d_peaks) {
+    if (n_ant < 1 || n_ant > GJ_MAX_ANTENNAS) return fail(ctx, GJ_ERR_INVALID, "n_ant must be 1..%d", GJ_MAX_ANTENNAS);
+    if (n_pairs < 1 || n_pairs > kMaxPairs) return fail(ctx, GJ_ERR_INVALID, "n_pairs must be 1..%d", kMaxPairs);
+    if (n_samples < 1) return fail(ctx, GJ_ERR_INVALID, "n_samples must be >= 1");
+    if (n_samples > (1ull << 23)) return fail(ctx, GJ_ERR_UNSUPPORTED, "slice longer than 2^23 samples");
+    XcParams P;
+    memset(&P, 0, sizeof(P));
+    for (int a = 0; a < n_ant; ++a) {
+        if (reinterpret_cast<uintptr_t>(d_iq[a]) & 1) return fail(ctx, GJ_ERR_INVALID, "capture must be 2-byte aligned");
+        P.iq[a] = d_iq[a];
+        P.nsamples[a] = nbytes[a] / 2;
+    }
+    for (int p = 0; p < n_pairs; ++p) {
+        const int i = pairs[2 * p], j = pairs[2 * p + 1];
+        if (i < 0 || j < 0 || i >= n_ant || j >= n_ant) return fail(ctx, GJ_ERR_INVALID, "pair %d out of range", p);
+        P.pair_i[p] = i;
+        P.pair_j[p] = j;
+    }
+    P.n = n_samples;
+    P.L = xc_fft_len(n_samples);
+    P.L1 = (int)(P.L / kRow);
+    P.n_ant = n_ant;
+    P.n_pairs = n_pairs;
+    const size_t need = xcorr_workspace(ctx, n_ant, n_samples, n_pairs);
+    int rc = ensure_workspace(ctx, need);
+    if (rc) return rc;
+    const size_t ncand = (size_t)(P.L / kBlockPoints);
+    cf* spec = reinterpret_cast<cf*>(ctx->ws);
+    cf* dbuf = spec + (size_t)n_ant * P.L;
+    XcCand* cand = reinterpret_cast<XcCand*>(dbuf + (size_t)n_pairs * P.L);
+    long long* eff = reinterpret_cast<long long*>(cand + (size_t)n_pairs * ncand);
+    int* valid = reinterpret_cast<int*>(eff + GJ_MAX_ANTENNAS);
+
+    hipLaunchKernelGGL(xc_prepare_kernel, dim3(1), dim3(64), 0, ctx->stream, P, (const long long*)d_starts, eff, valid);
+    GJ_LAUNCH_CHECK(ctx);
+    xc_cols(ctx, 0, P, n_ant, eff, valid, spec, nullptr);
+    GJ_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL((xc_rows_kernel<0>), dim3((unsigned)P.L1, (unsigned)n_ant), dim3(kBlockThreads), 0, ctx->stream,
+                       P, ctx->d_twiddle, spec, dbuf);
+    GJ_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL((xc_rows_kernel<1>), dim3((unsigned)P.L1, (unsigned)n_pairs), dim3(kBlockThreads), 0,
+                       ctx->stream, P, ctx->d_twiddle, spec, dbuf);
+    GJ_LAUNCH_CHECK(ctx);
+    xc_cols(ctx, 1, P, n_pairs, eff, valid, dbuf, cand);
+    GJ_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(xc_finalize_kernel, dim3((unsigned)n_pairs), dim3(256), 0, ctx->stream, P, cand, (unsigned)ncand,
+                       valid, d_lags, d_peaks);
+    GJ_LAUNCH_CHECK(ctx);
+    return GJ_OK;
+}
+
+}   // namespace gj

@@ -1,0 +1,280 @@
+"""gpsjam -- host side of the MI355X jamming-detection DSP path.
+
+``Device`` owns one ``gj_ctx`` (one GPU) and exposes the C-ABI of
+``libgpsjam_hip.so`` in two flavours:
+
+* host arrays in, numpy results out (``chunk_power``, ``welch``, ``amp_stats``,
+  ``onset``, ``xcorr_lags``) -- what the drop-in modules under ``skrypty/`` and
+  ``GpsJammerApp/app/`` call;
+* device pointers in / out (``*_dev``) on a caller-supplied HIP stream -- what
+  ``bench.py`` and the one-capture-per-GPU driver (``gpsjam.sharded``) call with torch
+  tensors.
+
+Nothing in this package computes on the CPU: without the HIP library every call
+raises ``GpsJamLibraryError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import (AmpStats, GpsJamError, GpsJamLibraryError, Onset, SynthParams,  # noqa: F401
+                   GJ_LAG_INVALID, GJ_MAX_ANTENNAS)
+
+__all__ = ["Device", "DevBuf", "GpsJamError", "GpsJamLibraryError", "device_count",
+           "library_path", "as_u8"]
+
+
+def library_path() -> str:
+    return _ffi.LIB_PATH
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _ffi.load().gj_device_count(C.byref(n))
+    return n.value
+
+
+def as_u8(raw) -> np.ndarray:
+    """Contiguous uint8 view of bytes / bytearray / memoryview / ndarray."""
+    if isinstance(raw, np.ndarray):
+        if raw.dtype != np.uint8:
+            raise TypeError("raw I/Q must be uint8")
+        return np.ascontiguousarray(raw).reshape(-1)
+    return np.frombuffer(raw, dtype=np.uint8)
+
+
+def _ptr(x) -> int:
+    """Device address of a torch tensor / DevBuf / int."""
+    if x is None:
+        return 0
+    if isinstance(x, int):
+        return x
+    if isinstance(x, DevBuf):
+        return x.ptr
+    if hasattr(x, "data_ptr"):
+        return int(x.data_ptr())
+    raise TypeError(f"not a device buffer: {type(x)!r}")
+
+
+class DevBuf:
+    """Device allocation owned by a Device (for callers without torch)."""
+
+    def __init__(self, dev: "Device", nbytes: int):
+        self.dev, self.nbytes = dev, int(nbytes)
+        p = C.c_void_p()
+        dev._check(dev._lib.gj_malloc(dev._ctx, self.nbytes, C.byref(p)))
+        self.ptr = p.value or 0
+
+    def upload(self, host: np.ndarray, offset: int = 0):
+        host = np.ascontiguousarray(host)
+        if offset + host.nbytes > self.nbytes:
+            raise ValueError("upload exceeds the device buffer")
+        self.dev._check(self.dev._lib.gj_memcpy_h2d(self.dev._ctx, self.ptr + offset,
+                                                    host.ctypes.data, host.nbytes))
+        return self
+
+    def download(self, dtype=np.uint8, count: Optional[int] = None, offset: int = 0) -> np.ndarray:
+        dt = np.dtype(dtype)
+        if count is None:
+            count = (self.nbytes - offset) // dt.itemsize
+        out = np.empty(count, dt)
+        self.dev._check(self.dev._lib.gj_memcpy_d2h(self.dev._ctx, out.ctypes.data,
+                                                    self.ptr + offset, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.dev._lib.gj_free(self.dev._ctx, self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Device:
+    def __init__(self, index: int = 0):
+        self._lib = _ffi.load()
+        ctx = C.c_void_p()
+        rc = self._lib.gj_create(int(index), C.byref(ctx))
+        if rc != 0:
+            raise GpsJamError(rc, f"gj_create({index}): " + self._lib.gj_strerror(rc).decode())
+        self._ctx = ctx
+        self.index = int(index)
+        self.last_kernel_ms = 0.0
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc: int):
+        if rc != 0:
+            detail = self._lib.gj_last_error(self._ctx).decode(errors="replace")
+            raise GpsJamError(rc, f"{self._lib.gj_strerror(rc).decode()}: {detail}")
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.gj_destroy(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        name = C.create_string_buffer(256)
+        cus, mem = C.c_int(0), C.c_uint64(0)
+        self._check(self._lib.gj_device_info(self._ctx, name, 256, C.byref(cus), C.byref(mem)))
+        return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": mem.value}
+
+    def set_stream(self, stream_handle: Optional[int]):
+        """Run on an external HIP stream (``torch.cuda.current_stream().cuda_stream``)."""
+        self._check(self._lib.gj_set_stream(self._ctx, stream_handle or None))
+
+    def synchronize(self):
+        self._check(self._lib.gj_synchronize(self._ctx))
+
+    def reserve(self, nbytes: int):
+        self._check(self._lib.gj_reserve(self._ctx, int(nbytes)))
+
+    def alloc(self, nbytes: int) -> DevBuf:
+        return DevBuf(self, nbytes)
+
+    def timer_start(self):
+        self._check(self._lib.gj_timer_start(self._ctx))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float(0)
+        self._check(self._lib.gj_timer_stop(self._ctx, C.byref(ms)))
+        return ms.value
+
+    # ------------------------------------------------------------------ host arrays
+    def chunk_power(self, raw, chunk_bytes: int = 65536, eps: float = 1e-10,
+                    odd_chunk_zero: bool = False) -> np.ndarray:
+        raw = as_u8(raw)
+        n = self._lib.gj_chunk_count(raw.size, chunk_bytes)
+        out = np.empty(n, np.float32)
+        n_out, ms = C.c_size_t(0), C.c_float(0)
+        self._check(self._lib.gj_chunk_power_u8(
+            self._ctx, raw.ctypes.data, raw.size, chunk_bytes, eps,
+            _ffi.GJ_CP_ODD_CHUNK_ZERO if odd_chunk_zero else 0, out.ctypes.data, out.size,
+            C.byref(n_out), C.byref(ms)))
+        self.last_kernel_ms = ms.value
+        return out[:n_out.value]
+
+    def welch(self, raw, chunk_samples: int = 2048000, nperseg: int = 1024, fs: float = 2.048e6,
+              shift: bool = True, want_db: bool = True):
+        """(psd[rows, nperseg], psd_db[rows, nperseg] | None), float32."""
+        raw = as_u8(raw)
+        rows = self._lib.gj_welch_rows(raw.size, chunk_samples, nperseg)
+        psd = np.empty((rows, nperseg), np.float32)
+        db = np.empty((rows, nperseg), np.float32) if want_db else None
+        rows_out, ms = C.c_size_t(0), C.c_float(0)
+        self._check(self._lib.gj_welch_u8(
+            self._ctx, raw.ctypes.data, raw.size, chunk_samples, nperseg, fs,
+            _ffi.GJ_WELCH_SHIFT if shift else 0, psd.ctypes.data,
+            db.ctypes.data if want_db else None, psd.size, C.byref(rows_out), C.byref(ms)))
+        self.last_kernel_ms = ms.value
+        return psd, db
+
+    def amp_stats(self, raw, threshold: float) -> AmpStats:
+        raw = as_u8(raw)
+        out, ms = AmpStats(), C.c_float(0)
+        self._check(self._lib.gj_amp_stats_u8(self._ctx, raw.ctypes.data, raw.size, threshold,
+                                              C.byref(out), C.byref(ms)))
+        self.last_kernel_ms = ms.value
+        return out
+
+    def onset(self, raw, noise_samples: int = 200000, window: int = 1000,
+              factor: float = 50.0) -> Onset:
+        raw = as_u8(raw)
+        out, ms = Onset(), C.c_float(0)
+        self._check(self._lib.gj_onset_u8(self._ctx, raw.ctypes.data, raw.size, noise_samples,
+                                          window, factor, C.byref(out), C.byref(ms)))
+        self.last_kernel_ms = ms.value
+        return out
+
+    def xcorr_lags(self, slices: Sequence, pairs: Sequence[Sequence[int]]):
+        """lags[p], peaks[p] for pairs (i, j): lag of slice j relative to slice i
+        (= argmax|correlate(slice_j, slice_i, 'full')| - (N-1))."""
+        arrs = [as_u8(s) for s in slices]
+        n = arrs[0].size // 2
+        if any(a.size != 2 * n for a in arrs):
+            raise ValueError("slices must have equal length")
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        flat = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1))
+        npairs = flat.size // 2
+        lags = np.empty(npairs, np.int32)
+        peaks = np.empty(npairs, np.float32)
+        ms = C.c_float(0)
+        self._check(self._lib.gj_xcorr_lags_u8(
+            self._ctx, ptrs, len(arrs), n, flat.ctypes.data_as(C.POINTER(C.c_int32)), npairs,
+            lags.ctypes.data_as(C.POINTER(C.c_int32)), peaks.ctypes.data_as(C.POINTER(C.c_float)),
+            C.byref(ms)))
+        self.last_kernel_ms = ms.value
+        return lags, peaks
+
+    # ------------------------------------------------------------------ device pointers
+    def chunk_count(self, nbytes: int, chunk_bytes: int) -> int:
+        return self._lib.gj_chunk_count(nbytes, chunk_bytes)
+
+    def welch_rows(self, nbytes: int, chunk_samples: int, nperseg: int) -> int:
+        return self._lib.gj_welch_rows(nbytes, chunk_samples, nperseg)
+
+    def welch_workspace(self, nbytes: int, chunk_samples: int, nperseg: int) -> int:
+        return self._lib.gj_welch_workspace(self._ctx, nbytes, chunk_samples, nperseg)
+
+    def xcorr_workspace(self, n_ant: int, n_samples: int, n_pairs: int) -> int:
+        return self._lib.gj_xcorr_workspace(self._ctx, n_ant, n_samples, n_pairs)
+
+    def chunk_power_dev(self, d_iq, nbytes, chunk_bytes, d_power, eps=1e-10, flags=0):
+        self._check(self._lib.gj_chunk_power_dev(self._ctx, _ptr(d_iq), nbytes, chunk_bytes, eps,
+                                                 flags, _ptr(d_power)))
+
+    def power_threshold_dev(self, d_power, n, d_stats, d_mask=None, pct=5.0, rise_db=6.0):
+        self._check(self._lib.gj_power_threshold_dev(self._ctx, _ptr(d_power), n, pct, rise_db,
+                                                     _ptr(d_stats), _ptr(d_mask) or None))
+
+    def welch_dev(self, d_iq, nbytes, chunk_samples, nperseg, fs, d_psd, d_psd_db=None, shift=True):
+        self._check(self._lib.gj_welch_dev(self._ctx, _ptr(d_iq), nbytes, chunk_samples, nperseg,
+                                           fs, _ffi.GJ_WELCH_SHIFT if shift else 0, _ptr(d_psd),
+                                           _ptr(d_psd_db) or None))
+
+    def byte_histogram_dev(self, d_iq, nbytes, chunk_samples, nperseg, stride, d_hist):
+        self._check(self._lib.gj_byte_histogram_dev(self._ctx, _ptr(d_iq), nbytes, chunk_samples,
+                                                    nperseg, stride, _ptr(d_hist)))
+
+    def amp_stats_dev(self, d_iq, nbytes, threshold, d_out):
+        self._check(self._lib.gj_amp_stats_dev(self._ctx, _ptr(d_iq), nbytes, threshold, _ptr(d_out)))
+
+    def onset_dev(self, d_iq, nbytes, noise_samples, window, factor, d_out):
+        self._check(self._lib.gj_onset_dev(self._ctx, _ptr(d_iq), nbytes, noise_samples, window,
+                                           factor, _ptr(d_out)))
+
+    def xcorr_lags_dev(self, d_iqs, nbytes_list, d_starts, n_samples, pairs, d_lags, d_peaks):
+        n_ant = len(d_iqs)
+        ptrs = (C.c_void_p * n_ant)(*[_ptr(p) for p in d_iqs])
+        sizes = (C.c_size_t * n_ant)(*[int(b) for b in nbytes_list])
+        flat = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1))
+        self._check(self._lib.gj_xcorr_lags_dev(
+            self._ctx, ptrs, sizes, n_ant, _ptr(d_starts), n_samples,
+            flat.ctypes.data_as(C.POINTER(C.c_int32)), flat.size // 2, _ptr(d_lags), _ptr(d_peaks)))
+
+    def synth_dev(self, spec, n_samples: int, d_out, first_sample: int = 0):
+        """Fill d_out[2*n_samples] with the capture described by a synth.StreamSpec."""
+        p = SynthParams(spec.key_noise, spec.key_common, spec.delay, spec.jam_start,
+                        min(spec.jam_end, (1 << 62)), spec.noise_k, spec.jam_k, spec.dc_i_q8,
+                        spec.dc_q_q8)
+        self._check(self._lib.gj_synth_u8_dev(self._ctx, C.byref(p), first_sample, n_samples,
+                                              _ptr(d_out)))

@@ -1,0 +1,110 @@
+"""ctypes binding of libgpsjam_hip.so (include/gpsjam.h).
+
+There is no CPU fallback: if the shared library is missing or cannot be loaded the
+import of anything that needs it raises ``GpsJamLibraryError`` with the build hint.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libgpsjam_hip.so")
+
+
+class GpsJamLibraryError(RuntimeError):
+    pass
+
+
+class GpsJamError(RuntimeError):
+    def __init__(self, status: int, text: str):
+        super().__init__(f"gpsjam: {text} (status {status})")
+        self.status = status
+
+
+class AmpStats(C.Structure):
+    _fields_ = [("first_index", C.c_int64), ("count", C.c_uint64), ("sum", C.c_double),
+                ("mean", C.c_float), ("reserved", C.c_float)]
+
+
+class Onset(C.Structure):
+    _fields_ = [("start_index", C.c_int64), ("noise_power", C.c_float),
+                ("threshold", C.c_float)]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("key_noise", C.c_uint64), ("key_common", C.c_uint64), ("delay", C.c_int64),
+                ("jam_start", C.c_int64), ("jam_end", C.c_int64), ("noise_k", C.c_int32),
+                ("jam_k", C.c_int32), ("dc_i_q8", C.c_int32), ("dc_q_q8", C.c_int32)]
+
+
+GJ_CP_ODD_CHUNK_ZERO = 1
+GJ_WELCH_SHIFT = 1
+GJ_MAX_ANTENNAS = 16
+GJ_LAG_INVALID = -(1 << 31)
+
+_vp, _sz, _i, _f, _d = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double
+_pf, _psz = C.POINTER(C.c_float), C.POINTER(C.c_size_t)
+
+# name -> (restype, argtypes); every symbol include/gpsjam.h declares
+SIGNATURES = {
+    "gj_version": (_i, []),
+    "gj_strerror": (C.c_char_p, [_i]),
+    "gj_last_error": (C.c_char_p, [_vp]),
+    "gj_device_count": (_i, [C.POINTER(_i)]),
+    "gj_create": (_i, [_i, C.POINTER(_vp)]),
+    "gj_destroy": (_i, [_vp]),
+    "gj_set_stream": (_i, [_vp, _vp]),
+    "gj_synchronize": (_i, [_vp]),
+    "gj_device_info": (_i, [_vp, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(C.c_uint64)]),
+    "gj_reserve": (_i, [_vp, _sz]),
+    "gj_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "gj_free": (_i, [_vp, _vp]),
+    "gj_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "gj_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "gj_timer_start": (_i, [_vp]),
+    "gj_timer_stop": (_i, [_vp, _pf]),
+    "gj_chunk_count": (_sz, [_sz, _sz]),
+    "gj_chunk_power_dev": (_i, [_vp, _vp, _sz, _sz, _f, _i, _vp]),
+    "gj_chunk_power_u8": (_i, [_vp, _vp, _sz, _sz, _f, _i, _vp, _sz, _psz, _pf]),
+    "gj_power_threshold_dev": (_i, [_vp, _vp, _sz, _f, _f, _vp, _vp]),
+    "gj_welch_rows": (_sz, [_sz, _sz, _i]),
+    "gj_welch_dev": (_i, [_vp, _vp, _sz, _sz, _i, _d, _i, _vp, _vp]),
+    "gj_welch_u8": (_i, [_vp, _vp, _sz, _sz, _i, _d, _i, _vp, _vp, _sz, _psz, _pf]),
+    "gj_welch_workspace": (_sz, [_vp, _sz, _sz, _i]),
+    "gj_byte_histogram_dev": (_i, [_vp, _vp, _sz, _sz, _i, _i, _vp]),
+    "gj_amp_stats_dev": (_i, [_vp, _vp, _sz, _f, _vp]),
+    "gj_amp_stats_u8": (_i, [_vp, _vp, _sz, _f, C.POINTER(AmpStats), _pf]),
+    "gj_onset_dev": (_i, [_vp, _vp, _sz, _i, _i, _f, _vp]),
+    "gj_onset_u8": (_i, [_vp, _vp, _sz, _i, _i, _f, C.POINTER(Onset), _pf]),
+    "gj_xcorr_lags_dev": (_i, [_vp, C.POINTER(_vp), _psz, _i, _vp, _sz, C.POINTER(C.c_int32), _i,
+                               _vp, _vp]),
+    "gj_xcorr_lags_u8": (_i, [_vp, C.POINTER(_vp), _i, _sz, C.POINTER(C.c_int32), _i,
+                              C.POINTER(C.c_int32), _pf, _pf]),
+    "gj_xcorr_workspace": (_sz, [_vp, _i, _sz, _i]),
+    "gj_synth_u8_dev": (_i, [_vp, C.POINTER(SynthParams), C.c_int64, _sz, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle with typed signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GpsJamLibraryError(
+            f"{LIB_PATH} not found: build it with `make -C {os.path.dirname(LIB_PATH)}` "
+            "(hipcc --offload-arch=gfx950) or `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "There is no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise GpsJamLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,194 @@
+/* gpsjam.h -- C-ABI of libgpsjam_hip.so: the MI355X (gfx950) implementation of the
+ * jamming-detection DSP path of mfkiwl/GPS-JAMMING.
+ *
+ * The reference has no FFI for this path (it is numpy/scipy called from Python); the
+ * entry points below are what its Python call sites bind through ctypes instead of
+ * numpy/scipy.  Each one names the reference code it replaces (path:line relative to the
+ * reference root).  INTEGRATION.md shows the ctypes stubs a maintainer adds.
+ *
+ * Conventions
+ *  - every function returns GJ_OK (0) or a negative gj_status; gj_strerror() gives text,
+ *    gj_last_error() the detailed message of the last failure on a context;
+ *  - plain pointers and sizes only; the caller owns every buffer;
+ *  - one opaque gj_ctx per GPU; calls on one context are serialised by an internal
+ *    mutex, different contexts are independent; the library may be entered from several
+ *    host threads (the GUI's QThread, its HTTP handler thread, its triangulation thread);
+ *  - "*_dev" functions take DEVICE pointers, enqueue on the context's stream and return
+ *    without synchronising (results land in device memory; no host synchronisation, no
+ *    allocation when the workspace has been reserved) -- this is what bench.py times;
+ *  - "*_u8" functions take HOST buffers (numpy arrays), stage them to HBM, run the same
+ *    kernels, copy the small results back and return synchronously, reporting the
+ *    kernel-only time measured with HIP events on the context's stream.
+ *  - samples are interleaved unsigned 8-bit I,Q,I,Q,... (RTL-SDR, README.md:95); one
+ *    "sample" = one I/Q pair = 2 bytes.
+ */
+#ifndef GPSJAM_H
+#define GPSJAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GJ_VERSION 100 /* 0.1.0 */
+
+typedef struct gj_ctx gj_ctx;
+
+typedef enum gj_status {
+    GJ_OK = 0,
+    GJ_ERR_INVALID = -1,     /* bad argument */
+    GJ_ERR_HIP = -2,         /* a HIP runtime call failed (see gj_last_error) */
+    GJ_ERR_NOMEM = -3,       /* device or host allocation failed */
+    GJ_ERR_NODEVICE = -4,    /* no such GPU */
+    GJ_ERR_UNSUPPORTED = -5, /* size / parameter outside what the kernels implement */
+    GJ_ERR_CAPACITY = -6     /* caller's output buffer too small */
+} gj_status;
+
+/* ---------------------------------------------------------------- context ---------- */
+int gj_version(void);
+const char* gj_strerror(int status);
+const char* gj_last_error(gj_ctx* ctx);
+int gj_device_count(int* count);
+int gj_create(int device_id, gj_ctx** out);
+int gj_destroy(gj_ctx* ctx); /* idempotent on NULL */
+/* Borrow an external HIP stream (e.g. torch.cuda.current_stream().cuda_stream);
+ * NULL restores the context's own stream. */
+int gj_set_stream(gj_ctx* ctx, void* hip_stream);
+int gj_synchronize(gj_ctx* ctx);
+int gj_device_info(gj_ctx* ctx, char* name, size_t name_cap, int* compute_units,
+                   uint64_t* hbm_bytes);
+/* Pre-size the internal workspace so that later *_dev calls allocate nothing. */
+int gj_reserve(gj_ctx* ctx, size_t workspace_bytes);
+
+/* device memory for callers that do not bring their own allocator (torch) */
+int gj_malloc(gj_ctx* ctx, size_t bytes, void** dptr);
+int gj_free(gj_ctx* ctx, void* dptr);
+int gj_memcpy_h2d(gj_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int gj_memcpy_d2h(gj_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* HIP-event stopwatch on the context's stream (what bench.py's roofline uses) */
+int gj_timer_start(gj_ctx* ctx);
+int gj_timer_stop(gj_ctx* ctx, float* elapsed_ms); /* synchronises on the stop event */
+
+/* ------------------------------------------------- K1: per-chunk power scan --------- */
+/* Replaces the loop of GPSAnalysisThread.precalculate_power_profile
+ * (GpsJammerApp/app/worker.py:216-230) and analyze_chunk_power
+ * (GpsJammerApp/app/checkIfJamming.py:7-20, with GJ_CP_ODD_CHUNK_ZERO, eps = 0).
+ * power[c] = mean over the I/Q pairs of chunk c of (I-127.5)^2+(Q-127.5)^2, + eps.
+ * The ragged tail chunk is included; a trailing odd byte is dropped (worker.py:226);
+ * a chunk without a complete pair gives NaN (numpy mean of empty) unless the flag below
+ * is set.  The chunk sum is accumulated as an exact integer and rounded once. */
+#define GJ_CP_ODD_CHUNK_ZERO 1 /* odd-sized or empty chunk -> 0.0 (checkIfJamming.py:12-13) */
+size_t gj_chunk_count(size_t nbytes, size_t chunk_bytes);
+int gj_chunk_power_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes,
+                       float eps, int flags, float* d_power /* [gj_chunk_count] */);
+int gj_chunk_power_u8(gj_ctx* ctx, const uint8_t* iq, size_t nbytes, size_t chunk_bytes,
+                      float eps, int flags, float* power, size_t power_cap, size_t* n_out,
+                      float* kernel_ms);
+
+/* Noise floor + threshold (worker.py:241-248): baseline = numpy.percentile(power, pct)
+ * with numpy's float32 'linear' rule, 1.0 if <= 0; threshold = baseline * 10^(rise_db/10);
+ * mask[c] = power[c] > threshold.  d_stats = {baseline, threshold, count_above}. */
+int gj_power_threshold_dev(gj_ctx* ctx, const float* d_power, size_t n, float pct,
+                           float rise_db, float* d_stats /* [3] */, uint8_t* d_mask /* [n] or NULL */);
+
+/* ------------------------------------------------- K2: Welch PSD waterfall ---------- */
+/* Replaces the chunk body of analyze_full_file (skrypty/widmo_plot.py:26-54) including
+ * its scipy.signal.welch(x, fs, nperseg=N, return_onesided=False) call (:48):
+ * per chunk of chunk_samples I/Q pairs: x = ((I-127.5) + j(Q-127.5))/127.5, periodic Hann,
+ * 50 % overlap, per-segment mean removal, |FFT|^2 averaged over the segments,
+ * scale 1/(fs*sum(w^2)); a trailing partial chunk is kept when it holds at least
+ * nperseg samples (widmo_plot.py:31).  nperseg: power of two, 16..4096.
+ * Output rows are float32[nperseg]; GJ_WELCH_SHIFT applies numpy.fft.fftshift (:51);
+ * d_psd_db (optional) receives 10*log10(psd + 1e-15) (:52). */
+#define GJ_WELCH_SHIFT 1
+size_t gj_welch_rows(size_t nbytes, size_t chunk_samples, int nperseg);
+int gj_welch_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_samples,
+                 int nperseg, double fs, int flags, float* d_psd /* [rows*nperseg] */,
+                 float* d_psd_db /* [rows*nperseg] or NULL */);
+int gj_welch_u8(gj_ctx* ctx, const uint8_t* iq, size_t nbytes, size_t chunk_samples,
+                int nperseg, double fs, int flags, float* psd, float* psd_db, size_t cap_floats,
+                size_t* rows_out, float* kernel_ms);
+/* workspace bytes gj_welch_dev needs for this input (for gj_reserve) */
+size_t gj_welch_workspace(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int nperseg);
+
+/* raw-byte histogram of every `stride`-th byte (widmo_plot.py:35,85: stride 100,
+ * 256 bins).  Strided per chunk exactly like raw_chunk[::100]. */
+int gj_byte_histogram_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_samples,
+                          int nperseg, int stride, uint64_t* d_hist /* [256] */);
+
+/* ------------------------------------------------- K3: amplitude statistics --------- */
+/* Replaces read_iq_data + np.abs + find_change_point + np.mean(amp[idx:])
+ * (skrypty/triangulateRSSI.py:29-31,37-40,65-68): amp = |((I-127.5) + j(Q-127.5))/127.5|,
+ * first index with amp > threshold, mean of amp from that index to the end. */
+typedef struct gj_amp_stats {
+    int64_t first_index; /* -1: nothing above the threshold (or empty input) */
+    uint64_t count;      /* samples from first_index to the end */
+    double sum;          /* sum of amp over those samples */
+    float mean;          /* (float)(sum / count) -- the reference's avg_amplitude */
+    float reserved;
+} gj_amp_stats;
+int gj_amp_stats_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, float threshold,
+                     gj_amp_stats* d_out);
+int gj_amp_stats_u8(gj_ctx* ctx, const uint8_t* iq, size_t nbytes, float threshold,
+                    gj_amp_stats* out, float* kernel_ms);
+
+/* ------------------------------------------------- K4: interference onset ----------- */
+/* Replaces find_interference_start (skrypty/triangulateTDOA.py:37-49) on
+ * z = (I-127.5) + j(Q-127.5): noise = mean |z|^2 over the first noise_samples
+ * (1e-9 if 0), moving average of |z|^2 over `window` samples ('valid'), first index
+ * above noise*factor, + window/2; -1 when none or the stream is shorter than
+ * noise_samples + window.  Window sums are exact integers. window <= 8192. */
+typedef struct gj_onset {
+    int64_t start_index; /* -1 = not found */
+    float noise_power;
+    float threshold;
+} gj_onset;
+int gj_onset_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, int noise_samples, int window,
+                 float factor, gj_onset* d_out);
+int gj_onset_u8(gj_ctx* ctx, const uint8_t* iq, size_t nbytes, int noise_samples, int window,
+                float factor, gj_onset* out, float* kernel_ms);
+
+/* ------------------------------------------------- K5: TDOA cross-correlation ------- */
+/* Replaces signal.correlate(sig1, sig0, 'full') + argmax|.| - (N-1)
+ * (skrypty/triangulateTDOA.py:80-89) for every requested antenna pair.
+ * d_iq[a] is antenna a's capture in HBM, nbytes[a] its length; the slice of antenna a is
+ * the n_samples I/Q pairs starting at d_starts[a] (DEVICE array, e.g. written by
+ * gj_onset_dev; a negative or out-of-range start marks the antenna invalid).
+ * pairs = {i0,j0,i1,j1,...}: lag of antenna j relative to antenna i
+ * (= correlate(slice_j, slice_i)), positive when j is delayed.  FFT length is the next
+ * power of two >= 2*n_samples-1 (four-step, in HBM/L2).  Outputs (device):
+ * lags[p] (INT32_MIN if an antenna of the pair is invalid), peaks[p] = max |c|. */
+#define GJ_MAX_ANTENNAS 16
+#define GJ_LAG_INVALID INT32_MIN
+int gj_xcorr_lags_dev(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, int n_ant,
+                      const int64_t* d_starts, size_t n_samples, const int32_t* pairs,
+                      int n_pairs, int32_t* d_lags, float* d_peaks);
+int gj_xcorr_lags_u8(gj_ctx* ctx, const uint8_t* const* slices, int n_ant, size_t n_samples,
+                     const int32_t* pairs, int n_pairs, int32_t* lags, float* peaks,
+                     float* kernel_ms);
+size_t gj_xcorr_workspace(gj_ctx* ctx, int n_ant, size_t n_samples, int n_pairs);
+
+/* ------------------------------------------------- synthetic captures --------------- */
+/* Bit-identical to gpsjam/synth.py (integer-only counter-based generator that mirrors
+ * the value distribution of simulate/frontend/weaken_gps.py + add_jammer_and_mix.py). */
+typedef struct gj_synth_params {
+    uint64_t key_noise;  /* per-antenna hash key */
+    uint64_t key_common; /* common-source hash key */
+    int64_t delay;       /* samples by which this antenna sees the source late */
+    int64_t jam_start;   /* source-time sample range [start, end) of the burst */
+    int64_t jam_end;
+    int32_t noise_k; /* fixed-point gains, see synth.gain_k */
+    int32_t jam_k;
+    int32_t dc_i_q8; /* DC offsets in 1/256 LSB */
+    int32_t dc_q_q8;
+} gj_synth_params;
+int gj_synth_u8_dev(gj_ctx* ctx, const gj_synth_params* params, int64_t first_sample,
+                    size_t n_samples, uint8_t* d_out /* [2*n_samples] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPSJAM_H */

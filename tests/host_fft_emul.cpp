@@ -1,0 +1,93 @@
+// CPU emulation of the block-FFT schedule in csrc/fft_core.h: the same header, the same
+// per-thread register arrays, the same LDS scatter/gather index maps, executed one
+// "thread" at a time with an array standing in for LDS.  Checks every supported size
+// against a double-precision O(N^2) DFT.  Built and run by tests/test_fft_core_host.py.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "fft_core.h"
+
+using namespace gj;
+
+static std::vector<cf> g_table;
+
+template <int N, int PASS>
+static void run_passes(std::vector<cf (*)[16]>& regs, std::vector<cf>& lds) {
+    constexpr int TF = N / 16, NP = fft_npass(N);
+    for (int j = 0; j < kBlockThreads; ++j) {
+        const int b = j / TF, jl = j % TF;
+        cf tw[15];
+        for (auto& t : tw) t = cf{0.f, 0.f};
+        if constexpr (PASS > 0) load_twiddles<N, PASS>(tw, g_table.data(), jl);
+        fft_pass<N, PASS>(*regs[j], tw);
+        if constexpr (PASS + 1 < NP) lds_scatter<N, PASS>(*regs[j], lds.data(), b * lds_span(N), jl);
+    }
+    if constexpr (PASS + 1 < NP) {
+        for (int j = 0; j < kBlockThreads; ++j) {
+            const int b = j / TF, jl = j % TF;
+            lds_gather<N>(*regs[j], lds.data(), b * lds_span(N), jl);
+        }
+        run_passes<N, PASS + 1>(regs, lds);
+    }
+}
+
+template <int N>
+static double check() {
+    constexpr int TF = N / 16, B = kBlockPoints / N;
+    std::vector<cf> in(kBlockPoints), lds(kBlockPoints + kBlockPoints / 16 + 64);
+    for (auto& v : in) v = cf{(float)(rand() % 511 - 255), (float)(rand() % 511 - 255)};
+    std::vector<cf> storage(kBlockThreads * 16);
+    std::vector<cf (*)[16]> regs(kBlockThreads);
+    for (int j = 0; j < kBlockThreads; ++j) {
+        regs[j] = reinterpret_cast<cf (*)[16]>(&storage[j * 16]);
+        const int b = j / TF, jl = j % TF;
+        for (int s = 0; s < 16; ++s) (*regs[j])[s] = in[b * N + jl + TF * s];
+    }
+    run_passes<N, 0>(regs, lds);
+    double worst = 0.0;
+    for (int b = 0; b < B; ++b) {
+        double norm = 0.0;
+        std::vector<double> re(N), im(N);
+        for (int k = 0; k < N; ++k) {
+            double sr = 0, si = 0;
+            for (int n = 0; n < N; ++n) {
+                const double ang = -2.0 * M_PI * (double)((long long)k * n % N) / N;
+                const double c = cos(ang), s = sin(ang);
+                sr += in[b * N + n].x * c - in[b * N + n].y * s;
+                si += in[b * N + n].x * s + in[b * N + n].y * c;
+            }
+            re[k] = sr; im[k] = si;
+            norm += sr * sr + si * si;
+        }
+        norm = sqrt(norm / N);
+        for (int j = b * TF; j < (b + 1) * TF; ++j)
+            for (int s = 0; s < 16; ++s) {
+                const int k = (j % TF) + TF * s;
+                const double dr = (*regs[j])[s].x - re[k], di = (*regs[j])[s].y - im[k];
+                const double e = sqrt(dr * dr + di * di) / norm;
+                if (e > worst) worst = e;
+            }
+    }
+    return worst;
+}
+
+int main() {
+    g_table.resize(kTwiddleTable);
+    for (int m = 0; m < kTwiddleTable; ++m) {
+        const double a = -2.0 * M_PI * m / kTwiddleTable;
+        g_table[m] = cf{(float)cos(a), (float)sin(a)};
+    }
+    srand(7);
+    int bad = 0;
+#define CHECK(N)                                                    \
+    {                                                               \
+        const double e = check<N>();                                \
+        printf("N=%5d passes=%d rel_err=%.3e\n", N, fft_npass(N), e); \
+        if (!(e < 2e-6)) ++bad;                                     \
+    }
+    CHECK(16) CHECK(32) CHECK(64) CHECK(128) CHECK(256) CHECK(512) CHECK(1024) CHECK(2048) CHECK(4096)
+    printf(bad ? "FAIL\n" : "OK\n");
+    return bad;
+}
