@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Benchmark of the jamming-detection DSP path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic antenna capture per GPU
+(BASELINE.json configs[1], one stream per rank = configs[4] for N > 1):
+  K1 per-chunk power + 5th-percentile/+6 dB threshold, K2 fused unpack + 4096-pt Welch PSD
+  (1-s chunks), K3 amplitude statistics, K4 onset, K5 2^20-pt FFT cross-correlation of the
+  rank's onset-aligned 2^19-sample slice against the reference antenna's slice (rank 0,
+  broadcast over RCCL), then an RCCL gather of the per-stream result vector to rank 0.
+Captures are generated in HBM before the timed region (2^30 bytes = 536 870 912 I/Q samples
+per GPU, integer-only generator, seeds 1234 + rank) -- inputs are resident when timing starts.
+
+Rank 0 prints ONE JSON line.  ``roofline`` is for the dominant kernel (K2 welch_kernel<4096>
++ its finalize): algorithmic bytes = 2 B x samples per launch, duration from HIP events
+recorded on the launch stream around every K2 launch of the timed steps.  ``cpu_baseline``
+(N = 1 only) times the numpy/scipy oracle (oracle/gpsjam_oracle.py, kind "port") on a
+bounded prefix of the same capture on the host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(REPO, "gps-jamming_amd"), REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy rate
+CAPTURE_BYTES = 1 << 30
+NPERSEG = 4096
+CHUNK_SAMPLES = 2048000
+SLICE = 1 << 19
+DELAYS = (0, 3, -5, 7, -2, 4, -6, 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--capture-bytes", type=int, default=CAPTURE_BYTES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-chunks", type=int, default=24,
+                    help="1-s chunks of the capture given to the CPU oracle (bounded sample)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import gpsjam
+    from gpsjam.sharded import AntennaStream, unpack_results
+    from gpsjam.synth import StreamSpec
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    dev = gpsjam.Device(local_rank)
+    dev.set_stream(torch.cuda.current_stream().cuda_stream)
+    nbytes = args.capture_bytes
+    nsamp = nbytes // 2
+    cap = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    spec = StreamSpec(seed=1234, antenna=rank, delay=DELAYS[rank % len(DELAYS)], jam_start=int(0.4 * nsamp),
+                      jam_end=int(0.7 * nsamp), noise_sigma=6.25, jam_sigma=60.0 * (1.0, 0.7, 0.5, 0.8)[rank % 4])
+    dev.synth_dev(spec, nsamp, cap)
+    stream = AntennaStream(dev, cap, nperseg=NPERSEG, chunk_samples=CHUNK_SAMPLES, slice_samples=SLICE,
+                           rank=rank, world_size=world)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        stream.step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    gathered = None
+    for k in range(args.steps):
+        # the step, with HIP events on the launch stream around the dominant kernel
+        dev.chunk_power_dev(stream.cap, stream.nbytes, stream.chunk_bytes, stream.power)
+        dev.power_threshold_dev(stream.power, stream.n_chunks, stream.stats, stream.mask)
+        ev[k][0].record()
+        dev.welch_dev(stream.cap, stream.nbytes, stream.chunk_samples, stream.nperseg, stream.fs, stream.psd)
+        ev[k][1].record()
+        dev.amp_stats_dev(stream.cap, stream.nbytes, stream.rssi_threshold, stream.amp)
+        dev.onset_dev(stream.cap, stream.nbytes, stream.noise_samples, stream.window, stream.factor, stream.onset)
+        stream.tdoa()
+        from gpsjam.sharded import gather_results
+        gathered = gather_results(stream.pack(), rank, world, 0)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    welch_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+
+    if rank == 0:
+        results = [unpack_results(v) for v in gathered]
+        total_samples = float(nsamp) * world * args.steps
+        value = total_samples / elapsed / 1e6
+        achieved = (nbytes / 1e9) / (welch_ms / 1e3) if welch_ms > 0 else 0.0
+        line = {
+            "metric": "Msamples/s uint8 I/Q through PSD+TDOA xcorr",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: fused uint8->complex64 + 4096-pt Welch PSD + jamming power "
+                                   "threshold on 1 GiB synthetic I/Q per GPU (+ K3 amp stats, K4 onset, "
+                                   "K5 2^20-pt xcorr vs reference antenna, RCCL gather)",
+                       "capture_bytes_per_gpu": nbytes, "nperseg": NPERSEG, "chunk_samples": CHUNK_SAMPLES,
+                       "xcorr_slice": SLICE, "streams": world, "sharding": "one capture per GPU"},
+            "roofline": {"bound": "hbm", "kernel": "welch_kernel<4096> + welch_finalize_kernel",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": welch_ms,
+                         "note": "K2 is FP32-VALU/LDS bound, not HBM bound: see DESIGN.md"},
+            "results": {"lags": [r.lag for r in results], "onsets": [r.onset for r in results],
+                        "jamming_ranges_rank0": results[0].jamming_byte_ranges()[:4],
+                        "baseline_rank0": results[0].baseline, "amp_mean": [r.amp_mean for r in results]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(np, cap, args.cpu_sample_chunks, stream, results[0])
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    dev.close()
+
+
+def cpu_baseline(np, cap, n_chunks, stream, gpu_result):
+    """The oracle (a numpy/scipy port of the reference path) on a bounded prefix of the same
+    capture, single process / single thread, with parity of the GPU results on that prefix."""
+    from oracle import gpsjam_oracle as orc
+    sample_bytes = min(cap.numel(), n_chunks * 2 * CHUNK_SAMPLES)
+    raw = cap[:sample_bytes].cpu().numpy()
+    ns = sample_bytes // 2
+    t0 = time.perf_counter()
+    pm = orc.chunk_power(raw)
+    orc.power_threshold(pm)
+    lin, _, _ = orc.widmo_waterfall(raw, nperseg=NPERSEG)
+    _, avg = orc.rssi_amp_stats(raw, 0.0)
+    z = orc.tdoa_unpack(raw)
+    orc.tdoa_onset(z)
+    n = min(SLICE, ns)
+    orc.xcorr_lag(z[:n], z[:n])
+    dt = time.perf_counter() - t0
+    # parity of the GPU path on the same bytes (not timed)
+    psd = stream.psd[:lin.shape[0]].cpu().numpy()
+    keep = lin > 1e-12
+    psd_err = float(np.max(np.abs(psd[keep] - lin[keep]) / lin[keep]))
+    pm_err = float(np.max(np.abs(gpu_result.power_map[:pm.size] - pm) / pm))
+    return {"value": ns / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"first {sample_bytes} bytes ({ns} samples, {lin.shape[0]} 1-s chunks) of the same capture: "
+                      f"chunk power + threshold + Welch 4096 + amp stats + onset + one 2^19 xcorr, "
+                      f"numpy {np.__version__} single thread, {dt:.2f} s",
+            "parity_on_sample": {"psd_max_rel_err": psd_err, "power_map_max_rel_err": pm_err}}
+
+
+if __name__ == "__main__":
+    main()

@@ -286,8 +286,8 @@ def test_byte_histogram(dev, g2_raw):
 def test_full_size_1gib_properties(dev):
     """BASELINE config 2 size: 2^30 bytes generated in HBM.  K1 against the integer-exact
     restatement on every chunk; K2 rows against the oracle on three chunks (first, one in the
-    jammed span, the ragged last) and against a stand-alone run on those bytes; K3 mean
-    against a float64 sum; conservation: sum_k PSD[k] * fs/N = mean windowed power."""
+    jammed span, the ragged last) and against a stand-alone run on those bytes; K3 sum
+    against a float64 sum on a 64 MiB prefix."""
     nbytes = 1 << 30
     ns = nbytes // 2
     spec = StreamSpec(seed=1234, antenna=0, jam_start=int(0.4 * ns), jam_end=int(0.7 * ns), jam_sigma=40.0)
