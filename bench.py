@@ -69,7 +69,11 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     dev = gpsjam.Device(local_rank)
-    dev.set_stream(torch.cuda.current_stream().cuda_stream)
+    # one explicit HIP stream for everything in the step: the gpsjam kernels, torch's small
+    # packing ops and the events that time the dominant kernel
+    work_stream = torch.cuda.Stream()
+    torch.cuda.set_stream(work_stream)
+    dev.set_stream(work_stream.cuda_stream)
     nbytes = args.capture_bytes
     nsamp = nbytes // 2
     cap = torch.empty(nbytes, dtype=torch.uint8, device="cuda")

@@ -133,10 +133,10 @@ int gj_destroy(gj_ctx* ctx) {
     return GJ_OK;
 }
 
-int gj_set_stream(gj_ctx* ctx, void* hip_stream) {
+int gj_set_stream(gj_ctx* ctx, void* hip_stream, int external) {
     if (!ctx) return GJ_ERR_INVALID;
     Guard g(ctx);
-    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    ctx->stream = external ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
     return GJ_OK;
 }
 

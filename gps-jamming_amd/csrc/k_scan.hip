@@ -375,6 +375,7 @@ constexpr int kOnsetLds = kOnsetOut + kOnsetMaxWin;   // u32 words (64 KiB)
 
 struct OnsetScratch {
     unsigned long long first;   // min index of the moving average above threshold
+    unsigned long long cand;    // first 8-sample block whose coarse upper bound exceeds the threshold
     float noise;
     float thr;
 };
@@ -395,17 +396,106 @@ __global__ __launch_bounds__(kScanThreads) void onset_noise_kernel(const uint8_t
         sc->noise = noise;
         sc->thr = noise * factor;
         sc->first = ~0ull;
+        sc->cand = ~0ull;
     }
 }
 
 __device__ __forceinline__ int onset_pad(int k) { return k + (k >> 5); }   // spreads stride-`per` accesses over banks
+
+// Screening pass (HBM-bound): per 16-byte load one exact sum c8 of 4|z|^2 over 8 samples
+// (v_dot4_u32_u8), then U[j] = sum of the CB = (window+6)/8 + 1 blocks starting at block j.
+// Every window that STARTS inside block j lies inside those blocks and 4|z|^2 >= 0, so
+// U[j] <= threshold proves that no start index in block j crosses the threshold.  Only the
+// first block that fails the proof is handed to the exact scan below.
+constexpr int kCoarseBlocks = 4096;   // 8-sample blocks per workgroup = 64 KiB of capture
+constexpr int kCoarseHalo = (kOnsetMaxWin + 6) / 8 + 1;
+
+__global__ __launch_bounds__(kScanThreads) void onset_coarse_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
+                                                                    int window, OnsetScratch* __restrict__ sc) {
+    __shared__ unsigned pre[kCoarseBlocks + kCoarseHalo + (kCoarseBlocks + kCoarseHalo) / 32 + 8];
+    __shared__ unsigned thread_tot[kScanThreads];
+    const size_t nout = nsamples - (size_t)window + 1;
+    const size_t j0 = (size_t)blockIdx.x * kCoarseBlocks;   // first block of this tile
+    if (8 * j0 >= nout) return;
+    if (__hip_atomic_load(&sc->cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < j0) return;
+    const int cb = (window + 6) / 8 + 1;
+    const int tid = threadIdx.x;
+    const size_t nblk_total = (nsamples + 7) / 8;
+    size_t jend = j0 + kCoarseBlocks;
+    if (8 * jend > nout) jend = (nout + 7) / 8;   // blocks holding a valid start index
+    const int nloc = (int)(jend - j0);
+    const int need = nloc + cb - 1;               // blocks [j0, j0 + need)
+    const uint4* v = reinterpret_cast<const uint4*>(iq);
+    for (int k = tid; k < need; k += kScanThreads) {
+        const size_t j = j0 + k;
+        unsigned c8 = 0;
+        if (j < nblk_total) {
+            if (8 * j + 8 <= nsamples) {
+                const uint4 q = v[j];
+                unsigned s2 = 0, s1 = 0;
+                acc_moments(q, s2, s1);
+                c8 = 4u * s2 - 1020u * s1 + 16u * 65025u;
+            } else {
+                for (size_t n = 8 * j; n < nsamples; ++n) c8 += m_of(iq[2 * n], iq[2 * n + 1]);
+            }
+        }
+        pre[onset_pad(k + 1)] = c8;
+    }
+    if (tid == 0) pre[0] = 0;
+    __syncthreads();
+    const int per = (need + kScanThreads - 1) / kScanThreads;
+    const int lo = tid * per;
+    const int hi = (lo + per < need) ? lo + per : need;
+    unsigned run = 0;
+    for (int k = lo; k < hi; ++k) {
+        run += pre[onset_pad(k + 1)];
+        pre[onset_pad(k + 1)] = run;
+    }
+    thread_tot[tid] = run;
+    __syncthreads();
+    if (tid < 64) {
+        unsigned t0 = thread_tot[4 * tid], t1 = thread_tot[4 * tid + 1], t2 = thread_tot[4 * tid + 2],
+                 t3 = thread_tot[4 * tid + 3];
+        unsigned tot = t0 + t1 + t2 + t3, inc = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_up(inc, off, 64);
+            if (tid >= off) inc += o;
+        }
+        const unsigned ex = inc - tot;
+        thread_tot[4 * tid] = ex;
+        thread_tot[4 * tid + 1] = ex + t0;
+        thread_tot[4 * tid + 2] = ex + t0 + t1;
+        thread_tot[4 * tid + 3] = ex + t0 + t1 + t2;
+    }
+    __syncthreads();
+    const unsigned add = thread_tot[tid];
+    for (int k = lo; k < hi; ++k) pre[onset_pad(k + 1)] += add;
+    __syncthreads();
+    const double thr = (double)sc->thr;
+    const double scale = 0.25 / (double)window;
+    unsigned long long best = ~0ull;
+    for (int k = tid; k < nloc; k += kScanThreads) {
+        const unsigned U = pre[onset_pad(k + cb)] - pre[onset_pad(k)];
+        if ((double)U * scale > thr) { best = j0 + k; break; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off, 64);
+        best = o < best ? o : best;
+    }
+    if ((tid & 63) == 0 && best != ~0ull) atomicMin(&sc->cand, best);
+}
+
 
 __global__ __launch_bounds__(kScanThreads) void onset_scan_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
                                                                   int window, OnsetScratch* __restrict__ sc) {
     __shared__ unsigned pre[kOnsetLds + kOnsetLds / 32 + 2];
     __shared__ unsigned thread_tot[kScanThreads];
     const size_t nout = nsamples - (size_t)window + 1;   // valid positions
-    const size_t o0 = (size_t)blockIdx.x * kOnsetOut;
+    const unsigned long long cand = sc->cand;            // written by the screening kernel before this launch
+    if (cand == ~0ull) return;                           // proven: nothing crosses the threshold
+    const size_t o0 = (size_t)cand * 8 + (size_t)blockIdx.x * kOnsetOut;
     if (o0 >= nout) return;
     // everything before this tile already decided?
     if (__hip_atomic_load(&sc->first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < o0) return;
@@ -468,6 +558,8 @@ __global__ __launch_bounds__(kScanThreads) void onset_scan_kernel(const uint8_t*
     if ((tid & 63) == 0 && best != ~0ull) atomicMin(&sc->first, best);
 }
 
+__global__ void onset_set_cand_kernel(OnsetScratch* __restrict__ sc) { sc->cand = 0; }
+
 __global__ void onset_finalize_kernel(const OnsetScratch* __restrict__ sc, int window, int valid, gj_onset* __restrict__ out) {
     if (!valid) {
         out->start_index = -1; out->noise_power = 0.f; out->threshold = 0.f;
@@ -494,6 +586,14 @@ int launch_onset(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, int noise_samp
         const size_t nout = nsamples - window + 1;
         const size_t ntiles = (nout + kOnsetOut - 1) / kOnsetOut;
         if (ntiles > 0x7fffffffull) return fail(ctx, GJ_ERR_UNSUPPORTED, "capture too long");
+        if ((reinterpret_cast<uintptr_t>(d_iq) & 15) == 0) {
+            const size_t nct = ((nout + 7) / 8 + kCoarseBlocks - 1) / kCoarseBlocks;
+            hipLaunchKernelGGL(onset_coarse_kernel, dim3((unsigned)nct), dim3(kScanThreads), 0, ctx->stream, d_iq,
+                               nsamples, window, sc);
+        } else {
+            hipLaunchKernelGGL(onset_set_cand_kernel, dim3(1), dim3(1), 0, ctx->stream, sc);   // scan everything
+        }
+        GJ_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(onset_scan_kernel, dim3((unsigned)ntiles), dim3(kScanThreads), 0, ctx->stream, d_iq, nsamples,
                            window, sc);
         GJ_LAUNCH_CHECK(ctx);

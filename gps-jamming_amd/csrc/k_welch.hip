@@ -34,16 +34,22 @@ struct WelchBins {   // (thread, slot) that ends up holding bin k
     static constexpr int slot(int k) { return k / TF; }
 };
 
+// Two LDS buffers, used alternately by consecutive exchanges: a thread may scatter into one
+// while slower threads of the workgroup still gather from the other, so ONE barrier per
+// exchange (between scatter and gather) is enough.
 template <int N, int PASS>
-__device__ __forceinline__ void welch_passes(cf (&v)[16], cf* lds, int base, int jl, const cf (&tw)[3][15]) {
+__device__ __forceinline__ void welch_passes(cf (&v)[16], cf* lds0, cf* lds1, unsigned it, int base, int jl,
+                                             const cf (&tw)[3][15]) {
     constexpr int NP = fft_npass(N);
     fft_pass<N, PASS>(v, tw[PASS]);
     if constexpr (PASS + 1 < NP) {
+        // exchanges per segment: NP-1.  Even count -> parity of PASS; odd count -> parity of (it + PASS)
+        const bool second = ((NP - 1) % 2 == 0) ? (PASS & 1) : ((it + PASS) & 1);
+        cf* lds = second ? lds1 : lds0;
         lds_scatter<N, PASS>(v, lds, base, jl);
         __syncthreads();
         lds_gather<N>(v, lds, base, jl);
-        __syncthreads();
-        welch_passes<N, PASS + 1>(v, lds, base, jl, tw);
+        welch_passes<N, PASS + 1>(v, lds0, lds1, it, base, jl, tw);
     }
 }
 
@@ -54,7 +60,8 @@ __global__ __launch_bounds__(kBlockThreads, 2) void welch_kernel(const uint8_t* 
                                                               float* __restrict__ partial) {
     constexpr int TF = N / 16, B = kBlockPoints / N, NP = fft_npass(N);
     constexpr int WPF = (TF >= 64) ? TF / 64 : 1;   // waves per transform
-    __shared__ cf lds[lds_span(kBlockPoints)];
+    __shared__ cf lds0[lds_span(kBlockPoints)];
+    __shared__ cf lds1[lds_span(kBlockPoints)];
     __shared__ int wsum[2][B][WPF][2];
     const int tid = threadIdx.x;
     const int b = tid / TF, jl = tid % TF;
@@ -80,19 +87,32 @@ __global__ __launch_bounds__(kBlockThreads, 2) void welch_kernel(const uint8_t* 
 
     const uint16_t* chunk16 = reinterpret_cast<const uint16_t*>(iq) + (size_t)c * g.chunk_samples;
     const unsigned nsteps = (seg_hi - seg_lo + B - 1) / B;
+    // raw samples of the NEXT step are fetched while the current one is transformed
+    unsigned raw[16];
+    {
+        const unsigned seg0 = (seg_lo + b < seg_hi) ? seg_lo + b : seg_lo;
+        const uint16_t* src = chunk16 + (size_t)seg0 * (N / 2) + jl;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) raw[s] = src[TF * s];
+    }
     for (unsigned it = 0; it < nsteps; ++it) {
         const unsigned seg = seg_lo + it * B + b;
         const bool active = seg < seg_hi;
-        const uint16_t* src = chunk16 + (size_t)(active ? seg : seg_lo) * (N / 2) + jl;
         cf v[16];
         unsigned packed = 0;   // sum I in bits 0..15, sum Q in bits 16..31 (16 * 255 < 65536)
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const unsigned u = src[TF * s];
+            const unsigned u = raw[s];
             const float fi = (float)(u & 255u), fq = (float)(u >> 8);
             v[s].x = fmaf(fi, 2.0f, -255.0f) * win[s];   // w (2u - 255)
             v[s].y = fmaf(fq, 2.0f, -255.0f) * win[s];
             packed += (u & 255u) | ((u >> 8) << 16);
+        }
+        {
+            const unsigned nxt = seg + B;
+            const uint16_t* src = chunk16 + (size_t)((nxt < seg_hi) ? nxt : seg_lo) * (N / 2) + jl;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) raw[s] = src[TF * s];
         }
         int si = (int)(packed & 0xffffu), sq = (int)(packed >> 16);
         if constexpr (TF >= 64) {
@@ -113,7 +133,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void welch_kernel(const uint8_t* 
             }
         }
 
-        welch_passes<N, 0>(v, lds, b * lds_span(N), jl, tw);
+        welch_passes<N, 0>(v, lds0, lds1, it, b * lds_span(N), jl, tw);
 
         // detrend in the frequency domain on bins 0, 1, N-1
         if constexpr (TF >= 64) {

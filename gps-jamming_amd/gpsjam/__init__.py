@@ -138,9 +138,10 @@ class Device:
         self._check(self._lib.gj_device_info(self._ctx, name, 256, C.byref(cus), C.byref(mem)))
         return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": mem.value}
 
-    def set_stream(self, stream_handle: Optional[int]):
-        """Run on an external HIP stream (``torch.cuda.current_stream().cuda_stream``)."""
-        self._check(self._lib.gj_set_stream(self._ctx, stream_handle or None))
+    def set_stream(self, stream_handle: Optional[int], external: bool = True):
+        """Run on an external HIP stream (``torch.cuda.current_stream().cuda_stream``; 0 is
+        the legacy default stream).  ``external=False`` returns to the context's own stream."""
+        self._check(self._lib.gj_set_stream(self._ctx, stream_handle or None, 1 if external else 0))
 
     def synchronize(self):
         self._check(self._lib.gj_synchronize(self._ctx))

@@ -54,7 +54,7 @@ SIGNATURES = {
     "gj_device_count": (_i, [C.POINTER(_i)]),
     "gj_create": (_i, [_i, C.POINTER(_vp)]),
     "gj_destroy": (_i, [_vp]),
-    "gj_set_stream": (_i, [_vp, _vp]),
+    "gj_set_stream": (_i, [_vp, _vp, _i]),
     "gj_synchronize": (_i, [_vp]),
     "gj_device_info": (_i, [_vp, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(C.c_uint64)]),
     "gj_reserve": (_i, [_vp, _sz]),

@@ -53,9 +53,10 @@ const char* gj_last_error(gj_ctx* ctx);
 int gj_device_count(int* count);
 int gj_create(int device_id, gj_ctx** out);
 int gj_destroy(gj_ctx* ctx); /* idempotent on NULL */
-/* Borrow an external HIP stream (e.g. torch.cuda.current_stream().cuda_stream);
- * NULL restores the context's own stream. */
-int gj_set_stream(gj_ctx* ctx, void* hip_stream);
+/* external != 0: run on the caller's HIP stream `hip_stream` (e.g.
+ * torch.cuda.current_stream().cuda_stream; NULL then means the legacy default stream);
+ * external == 0: back to the context's own non-blocking stream. */
+int gj_set_stream(gj_ctx* ctx, void* hip_stream, int external);
 int gj_synchronize(gj_ctx* ctx);
 int gj_device_info(gj_ctx* ctx, char* name, size_t name_cap, int* compute_units,
                    uint64_t* hbm_bytes);
