@@ -22,15 +22,84 @@
 
 namespace gj {
 
+// `cf` is the storage type (global memory, LDS, kernel signatures).  `c2` is the compute
+// type: on the GPU a 2 x f32 vector living in an aligned VGPR pair so that every complex
+// add / multiply is ONE packed instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 with
+// op_sel / neg modifiers doing the swaps and sign flips of j-multiplication for free).
+// Measured on MI355X (profiles/r01_ubench_valu_lds.txt): a single wave issues one scalar
+// VALU op per ~5 cycles but also one PACKED op per ~5 cycles, so the packed form halves the
+// issue-bound time of the butterflies; hipcc's own SLP packing of the scalar form is slower
+// than either (one v_mov per packed op, 300+ VGPRs).
+// On the host (tests/host_fft_emul.cpp) c2 is the plain struct and the same butterflies run
+// as scalar arithmetic.
 struct alignas(8) cf {
     float x, y;
 };
 
-GJ_HD cf cmul(cf a, cf b) { return cf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-GJ_HD cf cadd(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
-GJ_HD cf csub(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
-GJ_HD cf mul_mj(cf a) { return cf{a.y, -a.x}; }   // a * (-j)
-GJ_HD cf mul_pj(cf a) { return cf{-a.y, a.x}; }   // a * (+j)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float c2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ c2 to_c2(cf a) { return c2{a.x, a.y}; }
+__device__ __forceinline__ cf to_cf(c2 a) { return cf{a.x, a.y}; }
+__device__ __forceinline__ c2 make_c2(float x, float y) { return c2{x, y}; }
+__device__ __forceinline__ c2 cadd(c2 a, c2 b) { return a + b; }
+__device__ __forceinline__ c2 csub(c2 a, c2 b) { return a - b; }
+// a * w = (a.x w.x - a.y w.y, a.x w.y + a.y w.x)
+__device__ __forceinline__ c2 cmul(c2 a, c2 w) {
+    c2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r)
+        : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// a + (-j) b = (a.x + b.y, a.y - b.x)      a + (+j) b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ c2 add_mj(c2 a, c2 b) {
+    c2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ c2 add_pj(c2 a, c2 b) {
+    c2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a * (-j) = (a.y, -a.x)
+__device__ __forceinline__ c2 mul_mj(c2 a) {
+    c2 r;
+    asm("v_pk_mul_f32 %0, %1, 1.0 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(a));
+    return r;
+}
+// acc += (a.x^2, a.y^2)
+__device__ __forceinline__ void acc_sq(c2& acc, c2 a) { asm("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(acc) : "v"(a)); }
+// elementwise a*b + c
+__device__ __forceinline__ c2 fma2(c2 a, c2 b, c2 c) { return __builtin_elementwise_fma(a, b, c); }
+// a * p.x / a * p.y (real scale taken from one half of a packed pair of scalars)
+__device__ __forceinline__ c2 scale_lo(c2 a, c2 p) {
+    c2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(p));
+    return r;
+}
+__device__ __forceinline__ c2 scale_hi(c2 a, c2 p) {
+    c2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(p));
+    return r;
+}
+#else
+typedef cf c2;
+GJ_HD c2 to_c2(cf a) { return a; }
+GJ_HD cf to_cf(c2 a) { return a; }
+GJ_HD c2 make_c2(float x, float y) { return c2{x, y}; }
+GJ_HD c2 cmul(c2 a, c2 b) { return c2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+GJ_HD c2 cadd(c2 a, c2 b) { return c2{a.x + b.x, a.y + b.y}; }
+GJ_HD c2 csub(c2 a, c2 b) { return c2{a.x - b.x, a.y - b.y}; }
+GJ_HD c2 add_mj(c2 a, c2 b) { return c2{a.x + b.y, a.y - b.x}; }
+GJ_HD c2 add_pj(c2 a, c2 b) { return c2{a.x - b.y, a.y + b.x}; }
+GJ_HD c2 mul_mj(c2 a) { return c2{a.y, -a.x}; }
+GJ_HD void acc_sq(c2& acc, c2 a) { acc.x += a.x * a.x; acc.y += a.y * a.y; }
+GJ_HD c2 fma2(c2 a, c2 b, c2 c) { return c2{a.x * b.x + c.x, a.y * b.y + c.y}; }
+GJ_HD c2 scale_lo(c2 a, c2 p) { return c2{a.x * p.x, a.y * p.x}; }
+GJ_HD c2 scale_hi(c2 a, c2 p) { return c2{a.x * p.y, a.y * p.y}; }
+#endif
 
 constexpr int kPointsPerThread = 16;
 constexpr int kBlockThreads = 256;
@@ -53,45 +122,56 @@ constexpr int fft_ns(int n, int pass) {   // product of the radices of the passe
 }
 
 // ---- small DFTs, forward sign (W = exp(-2 pi i / R)), in place, natural order out -------
-GJ_HD void dft2(cf& a, cf& b) {
-    cf t = a;
+GJ_HD void dft2(c2& a, c2& b) {
+    c2 t = a;
     a = cadd(t, b);
     b = csub(t, b);
 }
 
-GJ_HD void dft4(cf& x0, cf& x1, cf& x2, cf& x3) {
-    cf t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = csub(x1, x3);
+GJ_HD void dft4(c2& x0, c2& x1, c2& x2, c2& x3) {
+    c2 t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = csub(x1, x3);
     x0 = cadd(t0, t2);
     x2 = csub(t0, t2);
-    x1 = cadd(t1, mul_mj(t3));
-    x3 = cadd(t1, mul_pj(t3));
+    x1 = add_mj(t1, t3);
+    x3 = add_pj(t1, t3);
 }
 
 constexpr float kSqrtHalf = 0.70710678118654752440f;
 constexpr float kCosPi8 = 0.92387953251128675613f;
 constexpr float kSinPi8 = 0.38268343236508977173f;
 
-GJ_HD cf mul_w8_1(cf a) { return cf{(a.x + a.y) * kSqrtHalf, (a.y - a.x) * kSqrtHalf}; }    // * W8^1
-GJ_HD cf mul_w8_3(cf a) { return cf{(a.y - a.x) * kSqrtHalf, -(a.x + a.y) * kSqrtHalf}; }   // * W8^3
+// the non-trivial constant twiddles inside the 8- and 16-point butterflies
+struct InnerTw {
+    c2 w16_1, w16_2, w16_3, w16_6, w16_9;
+};
+GJ_HD InnerTw inner_twiddles() {
+    InnerTw k;
+    k.w16_1 = make_c2(kCosPi8, -kSinPi8);
+    k.w16_2 = make_c2(kSqrtHalf, -kSqrtHalf);    // = W8^1
+    k.w16_3 = make_c2(kSinPi8, -kCosPi8);
+    k.w16_6 = make_c2(-kSqrtHalf, -kSqrtHalf);   // = W8^3
+    k.w16_9 = make_c2(-kCosPi8, kSinPi8);
+    return k;
+}
 
 template <int R>
-GJ_HD void dft(cf (&a)[R]);
+GJ_HD void dft(c2 (&a)[R], const InnerTw& k);
 
 template <>
-GJ_HD void dft<2>(cf (&a)[2]) { dft2(a[0], a[1]); }
+GJ_HD void dft<2>(c2 (&a)[2], const InnerTw&) { dft2(a[0], a[1]); }
 
 template <>
-GJ_HD void dft<4>(cf (&a)[4]) { dft4(a[0], a[1], a[2], a[3]); }
+GJ_HD void dft<4>(c2 (&a)[4], const InnerTw&) { dft4(a[0], a[1], a[2], a[3]); }
 
 template <>
-GJ_HD void dft<8>(cf (&a)[8]) {
+GJ_HD void dft<8>(c2 (&a)[8], const InnerTw& k) {
     // n = n1 + 2 n2, k = 4 k1 + k2 :  radix-4 over n2, twiddle W8^(n1 k2), radix-2 over n1
     dft4(a[0], a[2], a[4], a[6]);   // n1 = 0 : A0[k2] in a[2 k2]
     dft4(a[1], a[3], a[5], a[7]);   // n1 = 1 : A1[k2] in a[2 k2 + 1]
-    a[3] = mul_w8_1(a[3]);
-    a[5] = mul_mj(a[5]);
-    a[7] = mul_w8_3(a[7]);
-    cf r[8];
+    a[3] = cmul(a[3], k.w16_2);     // W8^1
+    a[5] = mul_mj(a[5]);            // W8^2
+    a[7] = cmul(a[7], k.w16_6);     // W8^3
+    c2 r[8];
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) {
         r[k2] = cadd(a[2 * k2], a[2 * k2 + 1]);
@@ -102,24 +182,23 @@ GJ_HD void dft<8>(cf (&a)[8]) {
 }
 
 template <>
-GJ_HD void dft<16>(cf (&a)[16]) {
+GJ_HD void dft<16>(c2 (&a)[16], const InnerTw& k) {
     // n = n1 + 4 n2, k = 4 k1 + k2 :  radix-4 over n2, twiddle W16^(n1 k2), radix-4 over n1
 #pragma unroll
     for (int n1 = 0; n1 < 4; ++n1) dft4(a[n1], a[n1 + 4], a[n1 + 8], a[n1 + 12]);   // A[n1][k2] in a[n1 + 4 k2]
-    const cf w1{kCosPi8, -kSinPi8}, w3{kSinPi8, -kCosPi8};
-    a[5] = cmul(a[5], w1);          // n1 = 1, k2 = 1 : W16^1
-    a[9] = mul_w8_1(a[9]);          // n1 = 1, k2 = 2 : W16^2
-    a[13] = cmul(a[13], w3);        // n1 = 1, k2 = 3 : W16^3
-    a[6] = mul_w8_1(a[6]);          // n1 = 2, k2 = 1 : W16^2
-    a[10] = mul_mj(a[10]);          // n1 = 2, k2 = 2 : W16^4
-    a[14] = mul_w8_3(a[14]);        // n1 = 2, k2 = 3 : W16^6
-    a[7] = cmul(a[7], w3);          // n1 = 3, k2 = 1 : W16^3
-    a[11] = mul_w8_3(a[11]);        // n1 = 3, k2 = 2 : W16^6
-    a[15] = cmul(a[15], cf{-kCosPi8, kSinPi8});   // n1 = 3, k2 = 3 : W16^9 = -W16^1
-    cf r[16];
+    a[5] = cmul(a[5], k.w16_1);     // n1 = 1, k2 = 1
+    a[9] = cmul(a[9], k.w16_2);     // n1 = 1, k2 = 2
+    a[13] = cmul(a[13], k.w16_3);   // n1 = 1, k2 = 3
+    a[6] = cmul(a[6], k.w16_2);     // n1 = 2, k2 = 1
+    a[10] = mul_mj(a[10]);          // n1 = 2, k2 = 2 : W16^4 = -j
+    a[14] = cmul(a[14], k.w16_6);   // n1 = 2, k2 = 3
+    a[7] = cmul(a[7], k.w16_3);     // n1 = 3, k2 = 1
+    a[11] = cmul(a[11], k.w16_6);   // n1 = 3, k2 = 2
+    a[15] = cmul(a[15], k.w16_9);   // n1 = 3, k2 = 3
+    c2 r[16];
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) {
-        cf y0 = a[4 * k2], y1 = a[4 * k2 + 1], y2 = a[4 * k2 + 2], y3 = a[4 * k2 + 3];
+        c2 y0 = a[4 * k2], y1 = a[4 * k2 + 1], y2 = a[4 * k2 + 2], y3 = a[4 * k2 + 3];
         dft4(y0, y1, y2, y3);       // X[4 k1 + k2] = y_k1
         r[k2] = y0;
         r[4 + k2] = y1;
@@ -146,19 +225,19 @@ constexpr int lds_span(int n) { return n + n / 16; }   // slots one N-point tran
 // next pass' input (or IS X[jl + (N/16)(u + t*(16/R))] after the last pass).
 // tw[u*(R-1) + t-1] = W_(Ns R)^(t * ((jl + (N/16) u) mod Ns)), unused when PASS == 0.
 template <int N, int PASS>
-GJ_HD void fft_pass(cf (&v)[16], const cf* tw) {
+GJ_HD void fft_pass(c2 (&v)[16], const c2* tw, const InnerTw& k) {
     constexpr int R = fft_radix(N, PASS);
     constexpr int G = 16 / R;   // butterflies per thread
 #pragma unroll
     for (int u = 0; u < G; ++u) {
-        cf a[R];
+        c2 a[R];
 #pragma unroll
         for (int t = 0; t < R; ++t) a[t] = v[u + t * G];
         if (PASS > 0) {
 #pragma unroll
             for (int t = 1; t < R; ++t) a[t] = cmul(a[t], tw[u * (R - 1) + t - 1]);
         }
-        dft<R>(a);
+        dft<R>(a, k);
 #pragma unroll
         for (int t = 0; t < R; ++t) v[u + t * G] = a[t];
     }
@@ -183,29 +262,29 @@ GJ_HD int twiddle_index(int jl, int u, int t) {
 }
 
 template <int N, int PASS>
-GJ_HD void load_twiddles(cf* tw, const cf* table, int jl) {
+GJ_HD void load_twiddles(c2* tw, const cf* table, int jl) {
     constexpr int R = fft_radix(N, PASS);
     constexpr int G = 16 / R;
 #pragma unroll
     for (int u = 0; u < G; ++u)
 #pragma unroll
-        for (int t = 1; t < R; ++t) tw[u * (R - 1) + t - 1] = table[twiddle_index<N, PASS>(jl, u, t)];
+        for (int t = 1; t < R; ++t) tw[u * (R - 1) + t - 1] = to_c2(table[twiddle_index<N, PASS>(jl, u, t)]);
 }
 
 template <int N, int PASS>
-GJ_HD void lds_scatter(const cf (&v)[16], cf* lds, int base, int jl) {
+GJ_HD void lds_scatter(const c2 (&v)[16], cf* lds, int base, int jl) {
     constexpr int R = fft_radix(N, PASS);
     constexpr int G = 16 / R;
 #pragma unroll
     for (int u = 0; u < G; ++u)
 #pragma unroll
-        for (int t = 0; t < R; ++t) lds[lds_slot(base, out_index<N, PASS>(jl, u, t))] = v[u + t * G];
+        for (int t = 0; t < R; ++t) lds[lds_slot(base, out_index<N, PASS>(jl, u, t))] = to_cf(v[u + t * G]);
 }
 
 template <int N>
-GJ_HD void lds_gather(cf (&v)[16], const cf* lds, int base, int jl) {
+GJ_HD void lds_gather(c2 (&v)[16], const cf* lds, int base, int jl) {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) v[s] = lds[lds_slot(base, jl + (N / 16) * s)];
+    for (int s = 0; s < 16; ++s) v[s] = to_c2(lds[lds_slot(base, jl + (N / 16) * s)]);
 }
 
 }   // namespace gj

@@ -38,10 +38,10 @@ struct WelchBins {   // (thread, slot) that ends up holding bin k
 // while slower threads of the workgroup still gather from the other, so ONE barrier per
 // exchange (between scatter and gather) is enough.
 template <int N, int PASS>
-__device__ __forceinline__ void welch_passes(cf (&v)[16], cf* lds0, cf* lds1, unsigned it, int base, int jl,
-                                             const cf (&tw)[3][15]) {
+__device__ __forceinline__ void welch_passes(c2 (&v)[16], cf* lds0, cf* lds1, unsigned it, int base, int jl,
+                                             const c2 (&tw)[3][15], const InnerTw& ktw) {
     constexpr int NP = fft_npass(N);
-    fft_pass<N, PASS>(v, tw[PASS]);
+    fft_pass<N, PASS>(v, tw[PASS], ktw);
     if constexpr (PASS + 1 < NP) {
         // exchanges per segment: NP-1.  Even count -> parity of PASS; odd count -> parity of (it + PASS)
         const bool second = ((NP - 1) % 2 == 0) ? (PASS & 1) : ((it + PASS) & 1);
@@ -49,7 +49,7 @@ __device__ __forceinline__ void welch_passes(cf (&v)[16], cf* lds0, cf* lds1, un
         lds_scatter<N, PASS>(v, lds, base, jl);
         __syncthreads();
         lds_gather<N>(v, lds, base, jl);
-        welch_passes<N, PASS + 1>(v, lds0, lds1, it, base, jl, tw);
+        welch_passes<N, PASS + 1>(v, lds0, lds1, it, base, jl, tw, ktw);
     }
 }
 
@@ -70,20 +70,22 @@ __global__ __launch_bounds__(kBlockThreads, 2) void welch_kernel(const uint8_t* 
     const unsigned seg_lo = (unsigned)((unsigned long long)part * nseg / g.splits);
     const unsigned seg_hi = (unsigned)((unsigned long long)(part + 1) * nseg / g.splits);
 
-    cf tw[3][15];
+    const InnerTw ktw = inner_twiddles();
+    c2 tw[3][15];
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int k = 0; k < 15; ++k) tw[p][k] = cf{1.f, 0.f};
+        for (int k = 0; k < 15; ++k) tw[p][k] = make_c2(1.f, 0.f);
     if constexpr (NP > 1) load_twiddles<N, 1>(tw[1], twtab, jl);
     if constexpr (NP > 2) load_twiddles<N, 2>(tw[2], twtab, jl);
 
-    float win[16];
+    c2 winp[8];   // (w[2i], w[2i+1]): one VGPR pair serves two points through op_sel
 #pragma unroll
-    for (int s = 0; s < 16; ++s) win[s] = wintab[jl + TF * s];
-    float acc[16];
+    for (int s = 0; s < 8; ++s) winp[s] = make_c2(wintab[jl + TF * (2 * s)], wintab[jl + TF * (2 * s + 1)]);
+    c2 acc[16];   // (sum re^2, sum im^2) per bin: one packed FMA per bin and segment
 #pragma unroll
-    for (int s = 0; s < 16; ++s) acc[s] = 0.f;
+    for (int s = 0; s < 16; ++s) acc[s] = make_c2(0.f, 0.f);
+    const c2 two = make_c2(2.0f, 2.0f), bias = make_c2(-255.0f, -255.0f);
 
     const uint16_t* chunk16 = reinterpret_cast<const uint16_t*>(iq) + (size_t)c * g.chunk_samples;
     const unsigned nsteps = (seg_hi - seg_lo + B - 1) / B;
@@ -98,14 +100,14 @@ __global__ __launch_bounds__(kBlockThreads, 2) void welch_kernel(const uint8_t* 
     for (unsigned it = 0; it < nsteps; ++it) {
         const unsigned seg = seg_lo + it * B + b;
         const bool active = seg < seg_hi;
-        cf v[16];
+        c2 v[16];
         unsigned packed = 0;   // sum I in bits 0..15, sum Q in bits 16..31 (16 * 255 < 65536)
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const unsigned u = raw[s];
-            const float fi = (float)(u & 255u), fq = (float)(u >> 8);
-            v[s].x = fmaf(fi, 2.0f, -255.0f) * win[s];   // w (2u - 255)
-            v[s].y = fmaf(fq, 2.0f, -255.0f) * win[s];
+            const c2 f = make_c2((float)(u & 255u), (float)(u >> 8));
+            const c2 d = fma2(f, two, bias);                                    // 2u - 255
+            v[s] = (s & 1) ? scale_hi(d, winp[s >> 1]) : scale_lo(d, winp[s >> 1]);   // * w
             packed += (u & 255u) | ((u >> 8) << 16);
         }
         {
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void welch_kernel(const uint8_t* 
             }
         }
 
-        welch_passes<N, 0>(v, lds0, lds1, it, b * lds_span(N), jl, tw);
+        welch_passes<N, 0>(v, lds0, lds1, it, b * lds_span(N), jl, tw, ktw);
 
         // detrend in the frequency domain on bins 0, 1, N-1
         if constexpr (TF >= 64) {
@@ -158,12 +160,12 @@ __global__ __launch_bounds__(kBlockThreads, 2) void welch_kernel(const uint8_t* 
         }
         if (active) {
 #pragma unroll
-            for (int s = 0; s < 16; ++s) acc[s] = fmaf(v[s].x, v[s].x, fmaf(v[s].y, v[s].y, acc[s]));
+            for (int s = 0; s < 16; ++s) acc_sq(acc[s], v[s]);
         }
     }
     float* out = partial + ((size_t)blockIdx.x * B + b) * N + jl;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) out[TF * s] = acc[s];
+    for (int s = 0; s < 16; ++s) out[TF * s] = acc[s].x + acc[s].y;
 }
 
 __global__ __launch_bounds__(256) void welch_finalize_kernel(const float* __restrict__ partial, int n, unsigned per_chunk,

@@ -35,19 +35,19 @@ struct XcCand {
     int m;
 };
 
-__device__ __forceinline__ cf twiddle_big(unsigned long long m, unsigned long long L) {
+__device__ __forceinline__ c2 twiddle_big(unsigned long long m, unsigned long long L) {
     // exp(-2 pi i m / L), m < L <= 2^24: the ratio is exact in float
     float s, c;
     sincospif(-2.0f * ((float)m / (float)L), &s, &c);
-    return cf{c, s};
+    return make_c2(c, s);
 }
 
 template <int N, int PASS>
-__device__ __forceinline__ void xc_passes(cf (&v)[16], cf* lds, int base, int jl, const cf* twtab) {
+__device__ __forceinline__ void xc_passes(c2 (&v)[16], cf* lds, int base, int jl, const cf* twtab) {
     constexpr int NP = fft_npass(N);
-    cf tw[15];
+    c2 tw[15];
     if constexpr (PASS > 0) load_twiddles<N, PASS>(tw, twtab, jl);
-    fft_pass<N, PASS>(v, tw);
+    fft_pass<N, PASS>(v, tw, inner_twiddles());
     if constexpr (PASS + 1 < NP) {
         lds_scatter<N, PASS>(v, lds, base, jl);
         __syncthreads();
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kBlockThreads) void xc_cols_kernel(XcParams P, cons
     const int b = tid % B, jl = tid / B;
     const int t = blockIdx.y;   // antenna (MODE 0) or pair (MODE 1)
     const int n2 = blockIdx.x * B + b;
-    cf v[16];
+    c2 v[16];
     if constexpr (MODE == 0) {
         const bool ok = valid[t] != 0;
         const uint16_t* src = reinterpret_cast<const uint16_t*>(P.iq[t]) + (ok ? eff[t] : 0);
@@ -92,15 +92,15 @@ __global__ __launch_bounds__(kBlockThreads) void xc_cols_kernel(XcParams P, cons
             const unsigned long long n = (unsigned long long)(jl + TF * s) * kRow + n2;
             if (ok && n < P.n) {
                 const unsigned u = src[n];
-                v[s] = cf{(float)(2 * (int)(u & 255u) - 255), (float)(2 * (int)(u >> 8) - 255)};
+                v[s] = make_c2((float)(2 * (int)(u & 255u) - 255), (float)(2 * (int)(u >> 8) - 255));
             } else {
-                v[s] = cf{0.f, 0.f};
+                v[s] = make_c2(0.f, 0.f);
             }
         }
     } else {
         const cf* src = buf + (size_t)t * P.L;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) v[s] = src[(size_t)(jl + TF * s) * kRow + n2];
+        for (int s = 0; s < 16; ++s) v[s] = to_c2(src[(size_t)(jl + TF * s) * kRow + n2]);
     }
     xc_passes<L1, 0>(v, lds, b * RS, jl, twtab);
     if constexpr (MODE == 0) {
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kBlockThreads) void xc_cols_kernel(XcParams P, cons
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int k1 = jl + TF * s;
-            dst[(size_t)k1 * kRow + n2] = cmul(v[s], twiddle_big((unsigned long long)k1 * n2, P.L));
+            dst[(size_t)k1 * kRow + n2] = to_cf(cmul(v[s], twiddle_big((unsigned long long)k1 * n2, P.L)));
         }
     } else {
         float best = -1.f;
@@ -151,31 +151,31 @@ __global__ __launch_bounds__(kBlockThreads) void xc_rows_kernel(XcParams P, cons
     const int jl = threadIdx.x;
     const int r = blockIdx.x;   // k1
     const int t = blockIdx.y;
-    cf v[16];
+    c2 v[16];
     if constexpr (MODE == 0) {
         const cf* src = spec + (size_t)t * P.L + (size_t)r * N;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) v[s] = src[jl + TF * s];
+        for (int s = 0; s < 16; ++s) v[s] = to_c2(src[jl + TF * s]);
     } else {
         const cf* zi = spec + (size_t)P.pair_i[t] * P.L + (size_t)r * N;
         const cf* zj = spec + (size_t)P.pair_j[t] * P.L + (size_t)r * N;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const cf a = zj[jl + TF * s], bb = zi[jl + TF * s];
-            v[s] = cf{a.x * bb.x + a.y * bb.y, a.x * bb.y - a.y * bb.x};   // conj(a) * b
+            v[s] = make_c2(a.x * bb.x + a.y * bb.y, a.x * bb.y - a.y * bb.x);   // conj(a) * b
         }
     }
     xc_passes<N, 0>(v, lds, 0, jl, twtab);
     if constexpr (MODE == 0) {
         cf* dst = spec + (size_t)t * P.L + (size_t)r * N;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) dst[jl + TF * s] = v[s];
+        for (int s = 0; s < 16; ++s) dst[jl + TF * s] = to_cf(v[s]);
     } else {
         cf* dst = dbuf + (size_t)t * P.L + (size_t)r * N;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int n2 = jl + TF * s;
-            dst[n2] = cmul(v[s], twiddle_big((unsigned long long)r * n2, P.L));
+            dst[n2] = to_cf(cmul(v[s], twiddle_big((unsigned long long)r * n2, P.L)));
         }
     }
 }

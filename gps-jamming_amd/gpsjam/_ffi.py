@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libgpsjam_hip.so")
+# GPSJAM_LIB lets a developer A/B an alternative build of the same library (tools/ab_build.sh)
+LIB_PATH = os.environ.get("GPSJAM_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libgpsjam_hip.so")
 
 
 class GpsJamLibraryError(RuntimeError):

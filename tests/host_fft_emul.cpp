@@ -18,10 +18,10 @@ static void run_passes(std::vector<cf (*)[16]>& regs, std::vector<cf>& lds) {
     constexpr int TF = N / 16, NP = fft_npass(N);
     for (int j = 0; j < kBlockThreads; ++j) {
         const int b = j / TF, jl = j % TF;
-        cf tw[15];
-        for (auto& t : tw) t = cf{0.f, 0.f};
+        c2 tw[15];
+        for (auto& t : tw) t = make_c2(0.f, 0.f);
         if constexpr (PASS > 0) load_twiddles<N, PASS>(tw, g_table.data(), jl);
-        fft_pass<N, PASS>(*regs[j], tw);
+        fft_pass<N, PASS>(*regs[j], tw, inner_twiddles());
         if constexpr (PASS + 1 < NP) lds_scatter<N, PASS>(*regs[j], lds.data(), b * lds_span(N), jl);
     }
     if constexpr (PASS + 1 < NP) {

@@ -315,7 +315,7 @@ def test_full_size_1gib_properties(dev):
         lin, _ = orc.widmo_chunk_psd_db(piece, nperseg=4096)
         assert rel_err(psd[c], lin) < 1e-4
         alone, _ = dev.welch(piece, nperseg=4096, want_db=False)
-        np.testing.assert_array_equal(alone[0], psd[c])
+        np.testing.assert_allclose(alone[0], psd[c], rtol=1e-5)   # other split, other summation order
     amp = np.frombuffer(d_amp.download(np.uint8).tobytes(), dtype=[("i", "<i8"), ("c", "<u8"), ("s", "<f8"),
                                                                    ("m", "<f4"), ("r", "<f4")])[0]
     assert amp["i"] == 0 and amp["c"] == ns
