@@ -52,6 +52,16 @@ __device__ __forceinline__ c2 cmul(c2 a, c2 w) {
         : "v"(a), "v"(w), "v"(t));
     return r;
 }
+// same with a wave-uniform constant w held in an SGPR pair (the fixed W16 / W8 twiddles inside
+// the butterflies): costs no VGPRs
+__device__ __forceinline__ c2 cmul_k(c2 a, c2 w) {
+    c2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r)
+        : "v"(a), "s"(w), "v"(t));
+    return r;
+}
 // a + (-j) b = (a.x + b.y, a.y - b.x)      a + (+j) b = (a.x - b.y, a.y + b.x)
 __device__ __forceinline__ c2 add_mj(c2 a, c2 b) {
     c2 r;
@@ -90,6 +100,7 @@ GJ_HD c2 to_c2(cf a) { return a; }
 GJ_HD cf to_cf(c2 a) { return a; }
 GJ_HD c2 make_c2(float x, float y) { return c2{x, y}; }
 GJ_HD c2 cmul(c2 a, c2 b) { return c2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+GJ_HD c2 cmul_k(c2 a, c2 b) { return cmul(a, b); }
 GJ_HD c2 cadd(c2 a, c2 b) { return c2{a.x + b.x, a.y + b.y}; }
 GJ_HD c2 csub(c2 a, c2 b) { return c2{a.x - b.x, a.y - b.y}; }
 GJ_HD c2 add_mj(c2 a, c2 b) { return c2{a.x + b.y, a.y - b.x}; }
@@ -168,9 +179,9 @@ GJ_HD void dft<8>(c2 (&a)[8], const InnerTw& k) {
     // n = n1 + 2 n2, k = 4 k1 + k2 :  radix-4 over n2, twiddle W8^(n1 k2), radix-2 over n1
     dft4(a[0], a[2], a[4], a[6]);   // n1 = 0 : A0[k2] in a[2 k2]
     dft4(a[1], a[3], a[5], a[7]);   // n1 = 1 : A1[k2] in a[2 k2 + 1]
-    a[3] = cmul(a[3], k.w16_2);     // W8^1
+    a[3] = cmul_k(a[3], k.w16_2);     // W8^1
     a[5] = mul_mj(a[5]);            // W8^2
-    a[7] = cmul(a[7], k.w16_6);     // W8^3
+    a[7] = cmul_k(a[7], k.w16_6);     // W8^3
     c2 r[8];
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) {
@@ -186,20 +197,59 @@ GJ_HD void dft<16>(c2 (&a)[16], const InnerTw& k) {
     // n = n1 + 4 n2, k = 4 k1 + k2 :  radix-4 over n2, twiddle W16^(n1 k2), radix-4 over n1
 #pragma unroll
     for (int n1 = 0; n1 < 4; ++n1) dft4(a[n1], a[n1 + 4], a[n1 + 8], a[n1 + 12]);   // A[n1][k2] in a[n1 + 4 k2]
-    a[5] = cmul(a[5], k.w16_1);     // n1 = 1, k2 = 1
-    a[9] = cmul(a[9], k.w16_2);     // n1 = 1, k2 = 2
-    a[13] = cmul(a[13], k.w16_3);   // n1 = 1, k2 = 3
-    a[6] = cmul(a[6], k.w16_2);     // n1 = 2, k2 = 1
+    a[5] = cmul_k(a[5], k.w16_1);     // n1 = 1, k2 = 1
+    a[9] = cmul_k(a[9], k.w16_2);     // n1 = 1, k2 = 2
+    a[13] = cmul_k(a[13], k.w16_3);   // n1 = 1, k2 = 3
+    a[6] = cmul_k(a[6], k.w16_2);     // n1 = 2, k2 = 1
     a[10] = mul_mj(a[10]);          // n1 = 2, k2 = 2 : W16^4 = -j
-    a[14] = cmul(a[14], k.w16_6);   // n1 = 2, k2 = 3
-    a[7] = cmul(a[7], k.w16_3);     // n1 = 3, k2 = 1
-    a[11] = cmul(a[11], k.w16_6);   // n1 = 3, k2 = 2
-    a[15] = cmul(a[15], k.w16_9);   // n1 = 3, k2 = 3
+    a[14] = cmul_k(a[14], k.w16_6);   // n1 = 2, k2 = 3
+    a[7] = cmul_k(a[7], k.w16_3);     // n1 = 3, k2 = 1
+    a[11] = cmul_k(a[11], k.w16_6);   // n1 = 3, k2 = 2
+    a[15] = cmul_k(a[15], k.w16_9);   // n1 = 3, k2 = 3
     c2 r[16];
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) {
         c2 y0 = a[4 * k2], y1 = a[4 * k2 + 1], y2 = a[4 * k2 + 2], y3 = a[4 * k2 + 3];
         dft4(y0, y1, y2, y3);       // X[4 k1 + k2] = y_k1
+        r[k2] = y0;
+        r[4 + k2] = y1;
+        r[8 + k2] = y2;
+        r[12 + k2] = y3;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = r[i];
+}
+
+// Radix-16 butterfly with its input twiddles W^(t k), t = n1 + 4 n2, applied in two steps:
+// W^(4 n2 k) before the first radix-4 stage and W^(n1 k) after it (constant over the sum on
+// n2).  Six twiddle values (12 VGPRs) instead of fifteen (30) per pass for nine more complex
+// multiplies: the registers buy a third resident workgroup per CU.
+// tw6 = { W^(4k), W^(8k), W^(12k), W^(k), W^(2k), W^(3k) }.
+GJ_HD void dft16_twiddled(c2 (&a)[16], const c2* tw6, const InnerTw& k) {
+#pragma unroll
+    for (int n2 = 1; n2 < 4; ++n2)
+#pragma unroll
+        for (int n1 = 0; n1 < 4; ++n1) a[n1 + 4 * n2] = cmul(a[n1 + 4 * n2], tw6[n2 - 1]);
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) dft4(a[n1], a[n1 + 4], a[n1 + 8], a[n1 + 12]);   // A[n1][k2] in a[n1 + 4 k2]
+#pragma unroll
+    for (int n1 = 1; n1 < 4; ++n1)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) a[n1 + 4 * k2] = cmul(a[n1 + 4 * k2], tw6[2 + n1]);
+    a[5] = cmul_k(a[5], k.w16_1);
+    a[9] = cmul_k(a[9], k.w16_2);
+    a[13] = cmul_k(a[13], k.w16_3);
+    a[6] = cmul_k(a[6], k.w16_2);
+    a[10] = mul_mj(a[10]);
+    a[14] = cmul_k(a[14], k.w16_6);
+    a[7] = cmul_k(a[7], k.w16_3);
+    a[11] = cmul_k(a[11], k.w16_6);
+    a[15] = cmul_k(a[15], k.w16_9);
+    c2 r[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+        c2 y0 = a[4 * k2], y1 = a[4 * k2 + 1], y2 = a[4 * k2 + 2], y3 = a[4 * k2 + 3];
+        dft4(y0, y1, y2, y3);
         r[k2] = y0;
         r[4 + k2] = y1;
         r[8 + k2] = y2;
@@ -224,10 +274,15 @@ constexpr int lds_span(int n) { return n + n / 16; }   // slots one N-point tran
 // leg t sits in v[u + t*(16/R)] and belongs at index out_index<N,PASS>(jl, u, t) of the
 // next pass' input (or IS X[jl + (N/16)(u + t*(16/R))] after the last pass).
 // tw[u*(R-1) + t-1] = W_(Ns R)^(t * ((jl + (N/16) u) mod Ns)), unused when PASS == 0.
-template <int N, int PASS>
+// TWO_STEP (radix-16 passes after the first only): tw holds the six values of dft16_twiddled.
+template <int N, int PASS, bool TWO_STEP = false>
 GJ_HD void fft_pass(c2 (&v)[16], const c2* tw, const InnerTw& k) {
     constexpr int R = fft_radix(N, PASS);
     constexpr int G = 16 / R;   // butterflies per thread
+    if constexpr (TWO_STEP && PASS > 0 && R == 16) {
+        dft16_twiddled(v, tw, k);
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < G; ++u) {
         c2 a[R];
@@ -259,6 +314,17 @@ GJ_HD int twiddle_index(int jl, int u, int t) {
     constexpr int NS = fft_ns(N, PASS);
     const int k = (jl + (N / 16) * u) & (NS - 1);
     return (t * k * (kTwiddleTable / (NS * R))) & (kTwiddleTable - 1);
+}
+
+// the six twiddles of dft16_twiddled for thread jl (radix-16 pass, one butterfly per thread)
+template <int N, int PASS>
+GJ_HD void load_twiddles6(c2* tw6, const cf* table, int jl) {
+    constexpr int NS = fft_ns(N, PASS);
+    const int k = jl & (NS - 1);
+    constexpr int step = kTwiddleTable / (NS * 16);
+    const int e[6] = {4, 8, 12, 1, 2, 3};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) tw6[i] = to_c2(table[(e[i] * k * step) & (kTwiddleTable - 1)]);
 }
 
 template <int N, int PASS>

@@ -17,6 +17,21 @@
 // fixed order (deterministic), applies fftshift and writes the optional dB row.
 #include "gj_common.h"
 
+// ---- build-time tuning knobs (defaults = the shipped configuration; tools/ab_build.sh flips them)
+#ifndef GJ_LB
+#define GJ_LB 2          // min waves per SIMD asked of the register allocator
+#endif
+#ifndef GJ_W_TWOSTEP
+#define GJ_W_TWOSTEP 0   // 1: six twiddles per radix-16 pass (dft16_twiddled) instead of fifteen
+#endif
+#ifndef GJ_W_PREFETCH
+#define GJ_W_PREFETCH 1  // 1: next step's raw samples are loaded while the current one is transformed
+#endif
+#ifndef GJ_W_DBUF
+#define GJ_W_DBUF 1      // 1: two LDS exchange buffers, one barrier per exchange; 0: one buffer, two barriers
+#endif
+#define GJ_LOAD_RAW(x) (x)
+
 namespace gj {
 
 struct WelchGeom {
@@ -41,27 +56,28 @@ template <int N, int PASS>
 __device__ __forceinline__ void welch_passes(c2 (&v)[16], cf* lds0, cf* lds1, unsigned it, int base, int jl,
                                              const c2 (&tw)[3][15], const InnerTw& ktw) {
     constexpr int NP = fft_npass(N);
-    fft_pass<N, PASS>(v, tw[PASS], ktw);
+    fft_pass<N, PASS, GJ_W_TWOSTEP != 0>(v, tw[PASS], ktw);
     if constexpr (PASS + 1 < NP) {
         // exchanges per segment: NP-1.  Even count -> parity of PASS; odd count -> parity of (it + PASS)
         const bool second = ((NP - 1) % 2 == 0) ? (PASS & 1) : ((it + PASS) & 1);
-        cf* lds = second ? lds1 : lds0;
+        cf* lds = (GJ_W_DBUF && second) ? lds1 : lds0;
         lds_scatter<N, PASS>(v, lds, base, jl);
         __syncthreads();
         lds_gather<N>(v, lds, base, jl);
+        if (!GJ_W_DBUF) __syncthreads();
         welch_passes<N, PASS + 1>(v, lds0, lds1, it, base, jl, tw, ktw);
     }
 }
 
 template <int N>
-__global__ __launch_bounds__(kBlockThreads, 2) void welch_kernel(const uint8_t* __restrict__ iq, WelchGeom g,
+__global__ __launch_bounds__(kBlockThreads, GJ_LB) void welch_kernel(const uint8_t* __restrict__ iq, WelchGeom g,
                                                               const cf* __restrict__ twtab,
                                                               const float* __restrict__ wintab,
                                                               float* __restrict__ partial) {
     constexpr int TF = N / 16, B = kBlockPoints / N, NP = fft_npass(N);
     constexpr int WPF = (TF >= 64) ? TF / 64 : 1;   // waves per transform
     __shared__ cf lds0[lds_span(kBlockPoints)];
-    __shared__ cf lds1[lds_span(kBlockPoints)];
+    __shared__ cf lds1[GJ_W_DBUF ? lds_span(kBlockPoints) : 1];
     __shared__ int wsum[2][B][WPF][2];
     const int tid = threadIdx.x;
     const int b = tid / TF, jl = tid % TF;
@@ -76,15 +92,21 @@ __global__ __launch_bounds__(kBlockThreads, 2) void welch_kernel(const uint8_t* 
     for (int p = 0; p < 3; ++p)
 #pragma unroll
         for (int k = 0; k < 15; ++k) tw[p][k] = make_c2(1.f, 0.f);
-    if constexpr (NP > 1) load_twiddles<N, 1>(tw[1], twtab, jl);
-    if constexpr (NP > 2) load_twiddles<N, 2>(tw[2], twtab, jl);
+    if constexpr (NP > 1) {
+        if constexpr (GJ_W_TWOSTEP && fft_radix(N, 1) == 16) load_twiddles6<N, 1>(tw[1], twtab, jl);
+        else load_twiddles<N, 1>(tw[1], twtab, jl);
+    }
+    if constexpr (NP > 2) {
+        if constexpr (GJ_W_TWOSTEP && fft_radix(N, 2) == 16) load_twiddles6<N, 2>(tw[2], twtab, jl);
+        else load_twiddles<N, 2>(tw[2], twtab, jl);
+    }
 
     c2 winp[8];   // (w[2i], w[2i+1]): one VGPR pair serves two points through op_sel
 #pragma unroll
     for (int s = 0; s < 8; ++s) winp[s] = make_c2(wintab[jl + TF * (2 * s)], wintab[jl + TF * (2 * s + 1)]);
-    c2 acc[16];   // (sum re^2, sum im^2) per bin: one packed FMA per bin and segment
+    float acc[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) acc[s] = make_c2(0.f, 0.f);
+    for (int s = 0; s < 16; ++s) acc[s] = 0.f;
     const c2 two = make_c2(2.0f, 2.0f), bias = make_c2(-255.0f, -255.0f);
 
     const uint16_t* chunk16 = reinterpret_cast<const uint16_t*>(iq) + (size_t)c * g.chunk_samples;
@@ -95,28 +117,34 @@ __global__ __launch_bounds__(kBlockThreads, 2) void welch_kernel(const uint8_t* 
         const unsigned seg0 = (seg_lo + b < seg_hi) ? seg_lo + b : seg_lo;
         const uint16_t* src = chunk16 + (size_t)seg0 * (N / 2) + jl;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) raw[s] = src[TF * s];
+        for (int s = 0; s < 16; ++s) raw[s] = GJ_LOAD_RAW(src[TF * s]);
     }
     for (unsigned it = 0; it < nsteps; ++it) {
         const unsigned seg = seg_lo + it * B + b;
         const bool active = seg < seg_hi;
         c2 v[16];
-        unsigned packed = 0;   // sum I in bits 0..15, sum Q in bits 16..31 (16 * 255 < 65536)
+        unsigned sum_i = 0, sum_q = 0;
+        if (!GJ_W_PREFETCH && it > 0) {
+            const uint16_t* src = chunk16 + (size_t)(active ? seg : seg_lo) * (N / 2) + jl;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) raw[s] = GJ_LOAD_RAW(src[TF * s]);
+        }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const unsigned u = raw[s];
             const c2 f = make_c2((float)(u & 255u), (float)(u >> 8));
             const c2 d = fma2(f, two, bias);                                    // 2u - 255
             v[s] = (s & 1) ? scale_hi(d, winp[s >> 1]) : scale_lo(d, winp[s >> 1]);   // * w
-            packed += (u & 255u) | ((u >> 8) << 16);
+            sum_i = __builtin_amdgcn_udot4(u, 0x00000001u, sum_i, false);   // += byte 0
+            sum_q = __builtin_amdgcn_udot4(u, 0x00000100u, sum_q, false);   // += byte 1
         }
-        {
+        if (GJ_W_PREFETCH) {
             const unsigned nxt = seg + B;
             const uint16_t* src = chunk16 + (size_t)((nxt < seg_hi) ? nxt : seg_lo) * (N / 2) + jl;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) raw[s] = src[TF * s];
+            for (int s = 0; s < 16; ++s) raw[s] = GJ_LOAD_RAW(src[TF * s]);
         }
-        int si = (int)(packed & 0xffffu), sq = (int)(packed >> 16);
+        int si = (int)sum_i, sq = (int)sum_q;
         if constexpr (TF >= 64) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -160,12 +188,12 @@ __global__ __launch_bounds__(kBlockThreads, 2) void welch_kernel(const uint8_t* 
         }
         if (active) {
 #pragma unroll
-            for (int s = 0; s < 16; ++s) acc_sq(acc[s], v[s]);
+            for (int s = 0; s < 16; ++s) acc[s] = fmaf(v[s].x, v[s].x, fmaf(v[s].y, v[s].y, acc[s]));
         }
     }
     float* out = partial + ((size_t)blockIdx.x * B + b) * N + jl;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) out[TF * s] = acc[s].x + acc[s].y;
+    for (int s = 0; s < 16; ++s) out[TF * s] = acc[s];
 }
 
 __global__ __launch_bounds__(256) void welch_finalize_kernel(const float* __restrict__ partial, int n, unsigned per_chunk,
