@@ -25,7 +25,29 @@ from ._ffi import (AmpStats, GpsJamError, GpsJamLibraryError, Onset, SynthParams
                    GJ_LAG_INVALID, GJ_MAX_ANTENNAS)
 
 __all__ = ["Device", "DevBuf", "GpsJamError", "GpsJamLibraryError", "device_count",
-           "library_path", "as_u8"]
+           "library_path", "as_u8", "default_device", "read_capture"]
+
+_default = None
+_default_lock = __import__("threading").Lock()
+
+
+def default_device() -> "Device":
+    """Process-wide context used by the drop-in modules (GPU index from GPSJAM_DEVICE,
+    default 0).  Raises if the HIP library or the GPU is missing -- there is no CPU path."""
+    global _default
+    with _default_lock:
+        if _default is None or _default._ctx is None:
+            _default = Device(int(__import__("os").environ.get("GPSJAM_DEVICE", "0")))
+        return _default
+
+
+def read_capture(path) -> np.ndarray:
+    """uint8 view of a capture file without copying it through Python (memory-mapped;
+    empty files give an empty array)."""
+    import os
+    if os.path.getsize(path) == 0:
+        return np.zeros(0, np.uint8)
+    return np.memmap(path, dtype=np.uint8, mode="r")
 
 
 def library_path() -> str:

@@ -1,0 +1,168 @@
+"""Drop-in for skrypty/triangulateTDOA.py of mfkiwl/GPS-JAMMING, MI355X-backed.
+
+Two-antenna TDOA bearing: software synchronisation on the power onset of each capture, FFT
+cross-correlation of onset-aligned slices, lag -> path difference -> angle of arrival
+(reference: skrypty/triangulateTDOA.py:51-127).  Same constants, same function names, same
+console report when run as a script.
+
+On the GPU (libgpsjam_hip.so): ``find_interference_start`` (K4, reference :37-49) and the
+slice correlation + arg-max (K5, reference :80-89).  Both work on the raw uint8 captures; the
+complex64 expansion of the whole file that the reference performs (:33-34) never happens.
+``load_iq_data`` therefore returns a light handle that keeps the bytes; code that indexes it
+like an array still gets the reference's un-normalised complex64 values.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # .../gps-jamming_amd
+if _PKG_ROOT not in sys.path:
+    sys.path.append(_PKG_ROOT)
+
+import gpsjam   # noqa: E402
+
+# --- configuration (reference :9-29) --------------------------------------------------------
+FILE_ANT0 = '17_10/capture1710_0_15m.bin'
+FILE_ANT1 = '17_10/capture1710_1.bin'
+SAMPLE_RATE = 2048000
+CENTER_FREQ = 1575420000
+ANT0_POS = np.array([0, 0])
+ANT1_POS = np.array([0.5, 0])
+NOISE_SAMPLE_SIZE = 200000
+DETECTION_WINDOW_SIZE = 1000
+DETECTION_THRESHOLD_FACTOR = 50.0
+CORRELATION_SLICE_SIZE = 50000
+SPEED_OF_LIGHT = 299792458
+
+
+class IQCapture:
+    """uint8 capture with the array surface the reference script uses on its complex
+    arrays: ``len()``, slicing (-> IQCapture) and ``np.asarray`` (-> complex64 of
+    (I-127.5) + j(Q-127.5), reference :34)."""
+
+    def __init__(self, raw):
+        raw = gpsjam.as_u8(raw)
+        self.raw = raw[:raw.size - (raw.size & 1)]
+
+    def __len__(self):
+        return self.raw.size // 2
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            start, stop, step = key.indices(len(self))
+            if step != 1:
+                raise IndexError("IQCapture supports contiguous slices only")
+            return IQCapture(self.raw[2 * start:2 * max(stop, start)])
+        return np.asarray(self)[key]
+
+    def __array__(self, dtype=None, copy=None):
+        z = (self.raw[0::2].astype(np.float32) - 127.5) + 1j * (self.raw[1::2].astype(np.float32) - 127.5)
+        return z if dtype is None else z.astype(dtype)
+
+
+def load_iq_data(filename):
+    """Capture handle (reference :31-35 returned the expanded complex64 array)."""
+    return IQCapture(gpsjam.read_capture(filename))
+
+
+def _raw_of(iq_data):
+    return iq_data.raw if isinstance(iq_data, IQCapture) else None
+
+
+def find_interference_start(iq_data, noise_samples, window_size, threshold_factor):
+    """Sample index where the moving-average power first exceeds threshold_factor x the
+    noise power, + window_size // 2; -1 if none (reference :37-49)."""
+    raw = _raw_of(iq_data)
+    if raw is None:
+        raise TypeError("find_interference_start expects the capture returned by load_iq_data")
+    if len(iq_data) < noise_samples + window_size:
+        return -1
+    res = gpsjam.default_device().onset(raw, int(noise_samples), int(window_size), float(threshold_factor))
+    return int(res.start_index)
+
+
+def correlation_lag(signal1_slice, signal0_slice):
+    """argmax |correlate(signal1, signal0, 'full')| - (len(signal0) - 1) (reference :86-89),
+    positive when antenna 1 receives the signal later.  Returns (lag, peak)."""
+    r1, r0 = _raw_of(signal1_slice), _raw_of(signal0_slice)
+    if r1 is None or r0 is None or r1.size != r0.size:
+        raise TypeError("correlation_lag expects two equal-length slices of load_iq_data captures")
+    lags, peaks = gpsjam.default_device().xcorr_lags([r0, r1], [(0, 1)])
+    return int(lags[0]), float(peaks[0])
+
+
+def bearing_from_lag(lag_samples, ant0_pos=ANT0_POS, ant1_pos=ANT1_POS, sample_rate=SAMPLE_RATE):
+    """Scalar geometry of reference :92-119 (including its baseline-angle expression, :114).
+    Returns a dict, or a dict with 'error' when the geometry is impossible."""
+    tdoa = lag_samples / sample_rate
+    path_difference = tdoa * SPEED_OF_LIGHT
+    antenna_distance = np.linalg.norm(np.asarray(ant1_pos) - np.asarray(ant0_pos))
+    out = {'tdoa': tdoa, 'path_difference': path_difference, 'antenna_distance': antenna_distance}
+    if antenna_distance == 0:
+        out['error'] = 'zero_baseline'
+        return out
+    cos_theta = path_difference / antenna_distance
+    if abs(cos_theta) > 1:
+        out['error'] = 'path_longer_than_baseline'
+        return out
+    theta = math.acos(cos_theta)
+    baseline = math.atan2(ant1_pos[1] - ant0_pos[1], ant0_pos[0] - ant0_pos[0])
+    out.update(theta_deg=math.degrees(theta),
+               azimuth1_deg=math.degrees(baseline + theta) % 360,
+               azimuth2_deg=math.degrees(baseline - theta) % 360)
+    return out
+
+
+def main(file0=FILE_ANT0, file1=FILE_ANT1):
+    print("Wczytywanie danych I/Q...")
+    try:
+        signal0_full = load_iq_data(file0)
+        signal1_full = load_iq_data(file1)
+    except FileNotFoundError as e:
+        print(f"Błąd: Nie znaleziono pliku! {e}")
+        return 1
+
+    print("\nRozpoczynanie synchronizacji programowej...")
+    start0 = find_interference_start(signal0_full, NOISE_SAMPLE_SIZE, DETECTION_WINDOW_SIZE, DETECTION_THRESHOLD_FACTOR)
+    start1 = find_interference_start(signal1_full, NOISE_SAMPLE_SIZE, DETECTION_WINDOW_SIZE, DETECTION_THRESHOLD_FACTOR)
+    if start0 == -1 or start1 == -1:
+        print("BŁĄD KRYTYCZNY: Nie udało się wykryć początku interferencji.")
+        return 1
+    print(f"Wykryto początek interferencji w pliku 0 na próbce: {start0}")
+    print(f"Wykryto początek interferencji w pliku 1 na próbce: {start1}")
+
+    if len(signal0_full) < start0 + CORRELATION_SLICE_SIZE or len(signal1_full) < start1 + CORRELATION_SLICE_SIZE:
+        print("BŁĄD: Niewystarczająca ilość danych po wykryciu interferencji do analizy.")
+        return 1
+    signal0_slice = signal0_full[start0:start0 + CORRELATION_SLICE_SIZE]
+    signal1_slice = signal1_full[start1:start1 + CORRELATION_SLICE_SIZE]
+    print(f"\nSygnały wyrównane. Przetwarzanie wycinka {CORRELATION_SLICE_SIZE} próbek.")
+
+    print("Obliczanie korelacji wzajemnej na wycinkach sygnału...")
+    lag_samples, _ = correlation_lag(signal1_slice, signal0_slice)
+    print(f"Znaleziono maksymalną korelację przy przesunięciu {lag_samples} próbek.")
+
+    geo = bearing_from_lag(lag_samples)
+    print(f"Różnica czasu dotarcia (TDOA): {geo['tdoa'] * 1e9:.2f} ns")
+    print(f"Różnica w odległości do anten: {geo['path_difference']:.4f} m")
+    if geo.get('error') == 'zero_baseline':
+        print("Błąd: Odległość między antenami wynosi 0.")
+        return 1
+    if geo.get('error'):
+        print("\nOSTRZEŻENIE: Obliczona różnica ścieżek jest większa niż odległość między antenami.")
+        print("Możliwe przyczyny: błąd w konfiguracji odległości anten lub bardzo silne odbicia (multipath).")
+        return 1
+
+    print("\n--- WYNIKI ---")
+    print(f"Odległość między antenami: {geo['antenna_distance']:.2f} m")
+    print(f"Kąt nadejścia fali interferencyjnej (względem osi anten): {geo['theta_deg']:.2f} stopni")
+    print("Potencjalne kierunki do źródła interferencji (azymuty):")
+    print(f"  Kierunek 1: {geo['azimuth1_deg']:.2f} stopni")
+    print(f"  Kierunek 2: {geo['azimuth2_deg']:.2f} stopni")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(*sys.argv[1:3]))

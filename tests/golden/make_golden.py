@@ -224,6 +224,52 @@ def main():
     g4["peaks"] = peaks
     meta["g4"] = g4
 
+    # ------------------------------------------------------------------ G5
+    # detector state machine replay: gnssdec telemetry recorded by the reference's authors
+    # (GpsJammerApp/backend/helpers/wyniki/static/capture1.txt, reduced to the fields the
+    # worker reads) followed by a synthetic stretch that exercises the C/N0-drop and
+    # altitude branches; fed to the REFERENCE GPSAnalysisThread.process_incoming_data.
+    from golden_inputs import g5_records, g5_scenario
+    cap = os.path.join(REF, "GpsJammerApp", "backend", "helpers", "wyniki", "static", "capture1.txt")
+    txt = open(cap, encoding="utf-8").read()
+    logged = [json.loads(b[b.index("{"):]) for b in txt.split("=" * 80) if "{" in b]
+    keep_pos = ("nsat", "lat", "lon", "hgt", "gdop", "clk_bias", "buffcnt")
+    reduced = [{"elapsed_time": r.get("elapsed_time", 0.0),
+                "position": {k: r["position"][k] for k in keep_pos if k in r.get("position", {})},
+                "observations": [{k: o[k] for k in ("snr", "residual") if k in o}
+                                 for o in r.get("observations", [])]} for r in logged]
+    with open(os.path.join(HERE, "g5_capture1_reduced.json"), "w") as f:
+        json.dump(reduced, f, separators=(",", ":"))
+    records = g5_records(reduced)
+    with redirect_stdout(io.StringIO()):
+        th = ref_worker.GPSAnalysisThread([])
+    sc = g5_scenario()
+    th.power_map = sc["power_map"]
+    th.global_baseline_power = sc["baseline"]
+    th.jamming_byte_ranges = sc["ranges"]
+    th.power_map_ready = True
+    th.total_file_bytes = sc["total_file_bytes"]
+    th.total_samples = th.estimated_total_samples = sc["total_file_bytes"] // 2
+    with redirect_stdout(io.StringIO()):
+        for r in records:
+            th.process_incoming_data(r)
+    g5 = {
+        "n_records": len(records),
+        "new_analysis_text": [a[0] for a in th.new_analysis_text.emitted],
+        "new_position_data": [list(map(float, a)) for a in th.new_position_data.emitted],
+        "jamming_detected_realtime": [[bool(a[0]), json.loads(json.dumps(a[1], default=float))]
+                                      for a in th.jamming_detected_realtime.emitted],
+        "progress_update": [[int(a[0]), a[1]] for a in th.progress_update.emitted],
+        "jamming_events": json.loads(json.dumps(th.jamming_events, default=float)),
+        "last_position_before_jamming": json.loads(json.dumps(th.last_position_before_jamming, default=float)),
+        "final": {"jamming_detected": bool(th.jamming_detected), "median_cn0": float(th.median_cn0),
+                  "current_iq_power": float(th.current_iq_power), "cn0_history_len": len(th.cn0_history)},
+    }
+    with open(os.path.join(HERE, "g5_replay_expected.json"), "w") as f:
+        json.dump(g5, f, separators=(",", ":"), ensure_ascii=False)
+    meta["g5"] = {"n_logged": len(logged), "n_records": len(records),
+                  "n_events": len(th.jamming_events)}
+
     with open(os.path.join(HERE, "golden_meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True, ensure_ascii=False)
     print("golden vectors written to", HERE)
