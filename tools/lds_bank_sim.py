@@ -4,6 +4,17 @@
 ds_write_b64: 4 groups of 16 contiguous lanes, bank = (addr/4) % 32 (each lane covers 2 banks)
 ds_read_b64 : 2 groups of 32 lanes,            bank = (addr/4) % 64
 cost of a group = max over banks of the number of DISTINCT 8-byte addresses on that bank.
+Why no additive layout is conflict-free on both sides: with slot(256 s + 16 m + t) =
+s P + B[m] + C[t] (the form that keeps every address "thread base + immediate"), store groups
+of pass 0 need B[m] distinct mod 16 over 16 consecutive m, store groups of pass 1 need C[t]
+distinct mod 16, and a 32-lane load group reads {B[2h] + C[t]} u {B[2h+1] + C[t]}, which must
+cover all 32 residues mod 32.  C hits every class mod 16 once, so the second set must be the
+first one shifted by 16 (mod 32), i.e. the set C is invariant under the shift
+B[2h+1] - B[2h] - 16; any non-zero shift generates a subgroup of Z_32 that contains 16, which
+would put c and c + 16 (same class mod 16) both in C.  Hence B[2h+1] = B[2h] + 16 (mod 32),
+contradicting "B distinct mod 16".  The shipped layout (one pad slot per 16) keeps the stores
+conflict free and pays a 2-way conflict on the cheaper loads.
+
 Prints, per FFT size / thread mapping / padding scheme, the average cycles per
 wave-instruction relative to the conflict-free count (1.0 = conflict free).
 """
