@@ -83,6 +83,17 @@ __device__ __forceinline__ c2 mul_mj(c2 a) {
 __device__ __forceinline__ void acc_sq(c2& acc, c2 a) { asm("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(acc) : "v"(a)); }
 // elementwise a*b + c
 __device__ __forceinline__ c2 fma2(c2 a, c2 b, c2 c) { return __builtin_elementwise_fma(a, b, c); }
+// a * p.x + q.x  /  a * p.y + q.y  (real scale and offset taken from one half of packed pairs)
+__device__ __forceinline__ c2 fma_lo(c2 a, c2 p, c2 q) {
+    c2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(p), "v"(q));
+    return r;
+}
+__device__ __forceinline__ c2 fma_hi(c2 a, c2 p, c2 q) {
+    c2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(p), "v"(q));
+    return r;
+}
 // a * p.x / a * p.y (real scale taken from one half of a packed pair of scalars)
 __device__ __forceinline__ c2 scale_lo(c2 a, c2 p) {
     c2 r;
@@ -108,6 +119,8 @@ GJ_HD c2 add_pj(c2 a, c2 b) { return c2{a.x - b.y, a.y + b.x}; }
 GJ_HD c2 mul_mj(c2 a) { return c2{a.y, -a.x}; }
 GJ_HD void acc_sq(c2& acc, c2 a) { acc.x += a.x * a.x; acc.y += a.y * a.y; }
 GJ_HD c2 fma2(c2 a, c2 b, c2 c) { return c2{a.x * b.x + c.x, a.y * b.y + c.y}; }
+GJ_HD c2 fma_lo(c2 a, c2 p, c2 q) { return c2{a.x * p.x + q.x, a.y * p.x + q.x}; }
+GJ_HD c2 fma_hi(c2 a, c2 p, c2 q) { return c2{a.x * p.y + q.y, a.y * p.y + q.y}; }
 GJ_HD c2 scale_lo(c2 a, c2 p) { return c2{a.x * p.x, a.y * p.x}; }
 GJ_HD c2 scale_hi(c2 a, c2 p) { return c2{a.x * p.y, a.y * p.y}; }
 #endif

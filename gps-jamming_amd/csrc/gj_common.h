@@ -85,6 +85,41 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
+// Sum of `v` over each aligned group of G lanes (G = 1..64, power of two), result in every
+// lane of the group -- DPP row operations for the in-row steps (quad_perm swaps, row_half_mirror,
+// row_mirror: plain VALU, no LDS round trip per step like __shfl_xor's ds_bpermute chain), then
+// v_readlane of the four row totals for the 64-lane case (the result is then wave-uniform).
+template <int G>
+__device__ __forceinline__ int group_sum_dpp(int v) {
+    if constexpr (G >= 2) v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+    if constexpr (G >= 4) v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+    if constexpr (G >= 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);   // row_half_mirror
+    if constexpr (G >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
+    if constexpr (G == 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (G == 64)
+        v = __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+            __builtin_amdgcn_readlane(v, 48);
+    return v;
+}
+
+// the same for exactly-representable float sums
+template <int G>
+__device__ __forceinline__ float group_sum_dpp_f(float v) {
+#define GJ_DPP_F(x, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xf, 0xf, false))
+    if constexpr (G >= 2) v += GJ_DPP_F(v, 0xB1);
+    if constexpr (G >= 4) v += GJ_DPP_F(v, 0x4E);
+    if constexpr (G >= 8) v += GJ_DPP_F(v, 0x141);
+    if constexpr (G >= 16) v += GJ_DPP_F(v, 0x140);
+#undef GJ_DPP_F
+    if constexpr (G == 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (G == 64) {
+        const int b = __float_as_int(v);
+        v = (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
+            (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
+    }
+    return v;
+}
+
 }   // namespace gj
 
 // entry points implemented per translation unit (called from api.hip)

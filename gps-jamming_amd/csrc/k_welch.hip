@@ -27,12 +27,32 @@
 #ifndef GJ_W_PREFETCH
 #define GJ_W_PREFETCH 1  // 1: next step's raw samples are loaded while the current one is transformed
 #endif
+#ifndef GJ_W_PKACC
+#define GJ_W_PKACC 1     // 1: |X|^2 accumulated as (re^2, im^2) pairs with one v_pk_fma_f32 per bin
+#endif
 #ifndef GJ_W_DBUF
 #define GJ_W_DBUF 1      // 1: two LDS exchange buffers, one barrier per exchange; 0: one buffer, two barriers
 #endif
 #define GJ_LOAD_RAW(x) (x)
+// GJ_STAMPS (diagnostic builds only, tools/ab_build.sh): s_memtime stamps around the phases of
+// a step, summed per wave and added to g_welch_stamps; read with gj_debug_welch_stamps().
+#ifdef GJ_STAMPS
+#define GJ_STAMP(var)                                                                        \
+    unsigned long long var;                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");              \
+    __builtin_amdgcn_sched_barrier(0)
+#define GJ_STAMP_ADD(slot, a, b) stamps[slot] += (b) - (a)
+#else
+#define GJ_STAMP(var)
+#define GJ_STAMP_ADD(slot, a, b)
+#endif
 
 namespace gj {
+
+#ifdef GJ_STAMPS
+__device__ unsigned long long g_welch_stamps[8];
+#endif
 
 struct WelchGeom {
     unsigned long long chunk_samples;
@@ -54,18 +74,28 @@ struct WelchBins {   // (thread, slot) that ends up holding bin k
 // exchange (between scatter and gather) is enough.
 template <int N, int PASS>
 __device__ __forceinline__ void welch_passes(c2 (&v)[16], cf* lds0, cf* lds1, unsigned it, int base, int jl,
-                                             const c2 (&tw)[3][15], const InnerTw& ktw) {
+                                             const c2 (&tw)[3][15], const InnerTw& ktw,
+                                             unsigned long long (&stamps)[8]) {
     constexpr int NP = fft_npass(N);
+    GJ_STAMP(t0);
     fft_pass<N, PASS, GJ_W_TWOSTEP != 0>(v, tw[PASS], ktw);
+    GJ_STAMP(t1);
+    GJ_STAMP_ADD(0, t0, t1);   // butterflies
     if constexpr (PASS + 1 < NP) {
         // exchanges per segment: NP-1.  Even count -> parity of PASS; odd count -> parity of (it + PASS)
         const bool second = ((NP - 1) % 2 == 0) ? (PASS & 1) : ((it + PASS) & 1);
         cf* lds = (GJ_W_DBUF && second) ? lds1 : lds0;
         lds_scatter<N, PASS>(v, lds, base, jl);
+        GJ_STAMP(t2);
+        GJ_STAMP_ADD(1, t1, t2);   // scatter issued and landed (the stamp waits lgkmcnt(0))
         __syncthreads();
+        GJ_STAMP(t3);
+        GJ_STAMP_ADD(2, t2, t3);   // barrier wait
         lds_gather<N>(v, lds, base, jl);
+        GJ_STAMP(t4);
+        GJ_STAMP_ADD(3, t3, t4);   // gather
         if (!GJ_W_DBUF) __syncthreads();
-        welch_passes<N, PASS + 1>(v, lds0, lds1, it, base, jl, tw, ktw);
+        welch_passes<N, PASS + 1>(v, lds0, lds1, it, base, jl, tw, ktw, stamps);
     }
 }
 
@@ -78,7 +108,7 @@ __global__ __launch_bounds__(kBlockThreads, GJ_LB) void welch_kernel(const uint8
     constexpr int WPF = (TF >= 64) ? TF / 64 : 1;   // waves per transform
     __shared__ cf lds0[lds_span(kBlockPoints)];
     __shared__ cf lds1[GJ_W_DBUF ? lds_span(kBlockPoints) : 1];
-    __shared__ int wsum[2][B][WPF][2];
+    __shared__ float wsum[2][B][WPF][2];
     const int tid = threadIdx.x;
     const int b = tid / TF, jl = tid % TF;
     const unsigned c = blockIdx.x / g.splits, part = blockIdx.x % g.splits;
@@ -101,79 +131,82 @@ __global__ __launch_bounds__(kBlockThreads, GJ_LB) void welch_kernel(const uint8
         else load_twiddles<N, 2>(tw[2], twtab, jl);
     }
 
-    c2 winp[8];   // (w[2i], w[2i+1]): one VGPR pair serves two points through op_sel
+    // window folded into the unpack: w (2u - 255) = u (2w) + (-255 w); (w[2i], w[2i+1]) share a
+    // VGPR pair and op_sel picks the half, so 16 points cost 16 register pairs
+    c2 w2p[8], wcp[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) winp[s] = make_c2(wintab[jl + TF * (2 * s)], wintab[jl + TF * (2 * s + 1)]);
+    for (int s = 0; s < 8; ++s) {
+        const float wa = wintab[jl + TF * (2 * s)], wb = wintab[jl + TF * (2 * s + 1)];
+        w2p[s] = make_c2(2.0f * wa, 2.0f * wb);
+        wcp[s] = make_c2(-255.0f * wa, -255.0f * wb);
+    }
+#if GJ_W_PKACC
+    c2 acc[16];   // (sum re^2, sum im^2): one packed FMA per bin and step
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = make_c2(0.f, 0.f);
+#else
     float acc[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc[s] = 0.f;
-    const c2 two = make_c2(2.0f, 2.0f), bias = make_c2(-255.0f, -255.0f);
+#endif
 
-    const uint16_t* chunk16 = reinterpret_cast<const uint16_t*>(iq) + (size_t)c * g.chunk_samples;
+    // wave-uniform chunk base + 32-bit per-lane byte offsets: the loads keep their addresses in
+    // one SGPR pair + one VGPR + immediates
+    const uint8_t* chunk8 = iq + (size_t)c * g.chunk_samples * 2;
+    auto load_step = [&](unsigned (&dst)[16], unsigned seg_idx) {
+        const unsigned byte0 = (seg_idx * (unsigned)(N / 2) + (unsigned)jl) * 2u;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            dst[s] = GJ_LOAD_RAW(*reinterpret_cast<const uint16_t*>(chunk8 + (byte0 + 2u * TF * s)));
+    };
     const unsigned nsteps = (seg_hi - seg_lo + B - 1) / B;
     // raw samples of the NEXT step are fetched while the current one is transformed
     unsigned raw[16];
-    {
-        const unsigned seg0 = (seg_lo + b < seg_hi) ? seg_lo + b : seg_lo;
-        const uint16_t* src = chunk16 + (size_t)seg0 * (N / 2) + jl;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) raw[s] = GJ_LOAD_RAW(src[TF * s]);
-    }
+    load_step(raw, (seg_lo + b < seg_hi) ? seg_lo + b : seg_lo);
+    unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    GJ_STAMP(t_begin);
     for (unsigned it = 0; it < nsteps; ++it) {
+        GJ_STAMP(t_it0);
         const unsigned seg = seg_lo + it * B + b;
         const bool active = seg < seg_hi;
         c2 v[16];
-        unsigned sum_i = 0, sum_q = 0;
-        if (!GJ_W_PREFETCH && it > 0) {
-            const uint16_t* src = chunk16 + (size_t)(active ? seg : seg_lo) * (N / 2) + jl;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) raw[s] = GJ_LOAD_RAW(src[TF * s]);
-        }
+        if (!GJ_W_PREFETCH && it > 0) load_step(raw, active ? seg : seg_lo);
+        c2 fsum = make_c2(0.f, 0.f);   // (sum I, sum Q) of the raw bytes: integers < 2^24, exact in f32
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const unsigned u = raw[s];
-            const c2 f = make_c2((float)(u & 255u), (float)(u >> 8));
-            const c2 d = fma2(f, two, bias);                                    // 2u - 255
-            v[s] = (s & 1) ? scale_hi(d, winp[s >> 1]) : scale_lo(d, winp[s >> 1]);   // * w
-            sum_i = __builtin_amdgcn_udot4(u, 0x00000001u, sum_i, false);   // += byte 0
-            sum_q = __builtin_amdgcn_udot4(u, 0x00000100u, sum_q, false);   // += byte 1
+            const c2 f = make_c2((float)(u & 255u), (float)((u >> 8) & 255u));
+            v[s] = (s & 1) ? fma_hi(f, w2p[s >> 1], wcp[s >> 1]) : fma_lo(f, w2p[s >> 1], wcp[s >> 1]);
+            fsum = cadd(fsum, f);
         }
-        if (GJ_W_PREFETCH) {
-            const unsigned nxt = seg + B;
-            const uint16_t* src = chunk16 + (size_t)((nxt < seg_hi) ? nxt : seg_lo) * (N / 2) + jl;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) raw[s] = GJ_LOAD_RAW(src[TF * s]);
-        }
-        int si = (int)sum_i, sq = (int)sum_q;
+        if (GJ_W_PREFETCH) load_step(raw, (seg + B < seg_hi) ? seg + B : seg_lo);
+        float si, sq;
         if constexpr (TF >= 64) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                si += __shfl_xor(si, off, 64);
-                sq += __shfl_xor(sq, off, 64);
-            }
+            si = group_sum_dpp_f<64>(fsum.x);   // wave-uniform
+            sq = group_sum_dpp_f<64>(fsum.y);
             if ((tid & 63) == 0) {
                 wsum[it & 1][b][(tid >> 6) % WPF][0] = si;
                 wsum[it & 1][b][(tid >> 6) % WPF][1] = sq;
             }
         } else {
-#pragma unroll
-            for (int off = TF / 2; off > 0; off >>= 1) {
-                si += __shfl_xor(si, off, 64);
-                sq += __shfl_xor(sq, off, 64);
-            }
+            si = group_sum_dpp_f<TF>(fsum.x);
+            sq = group_sum_dpp_f<TF>(fsum.y);
         }
 
-        welch_passes<N, 0>(v, lds0, lds1, it, b * lds_span(N), jl, tw, ktw);
+        GJ_STAMP(t_it1);
+        GJ_STAMP_ADD(4, t_it0, t_it1);   // unpack + window + sums (+ waiting for the prefetched loads)
+        welch_passes<N, 0>(v, lds0, lds1, it, b * lds_span(N), jl, tw, ktw, stamps);
+        GJ_STAMP(t_it2);
 
         // detrend in the frequency domain on bins 0, 1, N-1
         if constexpr (TF >= 64) {
             if (jl <= 1 || jl == TF - 1) {
-                si = 0; sq = 0;
+                si = 0.f; sq = 0.f;
 #pragma unroll
                 for (int k = 0; k < WPF; ++k) { si += wsum[it & 1][b][k][0]; sq += wsum[it & 1][b][k][1]; }
             }
         }
-        const float Sx = (float)(2 * si - 255 * N), Sy = (float)(2 * sq - 255 * N);
+        const float Sx = fmaf(2.0f, si, -255.0f * N), Sy = fmaf(2.0f, sq, -255.0f * N);   // sum of (2u - 255)
         if (jl == WelchBins<N>::jl(0)) {
             v[WelchBins<N>::slot(0)].x -= 0.5f * Sx;
             v[WelchBins<N>::slot(0)].y -= 0.5f * Sy;
@@ -188,12 +221,31 @@ __global__ __launch_bounds__(kBlockThreads, GJ_LB) void welch_kernel(const uint8
         }
         if (active) {
 #pragma unroll
+#if GJ_W_PKACC
+            for (int s = 0; s < 16; ++s) acc_sq(acc[s], v[s]);
+#else
             for (int s = 0; s < 16; ++s) acc[s] = fmaf(v[s].x, v[s].x, fmaf(v[s].y, v[s].y, acc[s]));
+#endif
         }
+        GJ_STAMP(t_it3);
+        GJ_STAMP_ADD(5, t_it2, t_it3);   // detrend fix + |X|^2
     }
+#ifdef GJ_STAMPS
+    {
+        GJ_STAMP(t_end);
+        stamps[6] = t_end - t_begin;
+        stamps[7] = nsteps;
+        if ((tid & 63) == 0)
+            for (int k = 0; k < 8; ++k) atomicAdd(&g_welch_stamps[k], stamps[k]);
+    }
+#endif
     float* out = partial + ((size_t)blockIdx.x * B + b) * N + jl;
 #pragma unroll
+#if GJ_W_PKACC
+    for (int s = 0; s < 16; ++s) out[TF * s] = acc[s].x + acc[s].y;
+#else
     for (int s = 0; s < 16; ++s) out[TF * s] = acc[s];
+#endif
 }
 
 __global__ __launch_bounds__(256) void welch_finalize_kernel(const float* __restrict__ partial, int n, unsigned per_chunk,
@@ -249,6 +301,17 @@ static bool welch_plan(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int npe
     pl.scale_last = 1.0 / (fs * sw2 * 65025.0 * (double)pl.g.nseg_last);
     return true;
 }
+
+#ifdef GJ_STAMPS
+extern "C" int gj_debug_welch_stamps(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_welch_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_welch_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 size_t welch_workspace(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int nperseg) {
     WelchPlan pl;
