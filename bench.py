@@ -7,8 +7,9 @@
 
 One "step" = one pass of the hot path over one synthetic antenna capture per GPU
 (BASELINE.json configs[1], one stream per rank = configs[4] for N > 1):
-  K1 per-chunk power + 5th-percentile/+6 dB threshold, K2 fused unpack + 4096-pt Welch PSD
-  (1-s chunks), K3 amplitude statistics, K4 onset, K5 2^20-pt FFT cross-correlation of the
+  one fused HBM pass for K1 per-chunk power (+ 5th-percentile/+6 dB threshold), K3 amplitude
+  statistics and K4 onset; K2 fused unpack + 4096-pt Welch PSD (1-s chunks); K5 2^20-pt FFT
+  cross-correlation of the
   rank's onset-aligned 2^19-sample slice against the reference antenna's slice (rank 0,
   broadcast over RCCL), then an RCCL gather of the per-stream result vector to rank 0.
 Captures are generated in HBM before the timed region (2^30 bytes = 536 870 912 I/Q samples
@@ -99,13 +100,10 @@ def main():
     gathered = None
     for k in range(args.steps):
         # the step, with HIP events on the launch stream around the dominant kernel
-        dev.chunk_power_dev(stream.cap, stream.nbytes, stream.chunk_bytes, stream.power)
-        dev.power_threshold_dev(stream.power, stream.n_chunks, stream.stats, stream.mask)
+        stream.stream_scan()            # K1 + K3 + K4 in one HBM pass, + noise-floor threshold
         ev[k][0].record()
-        dev.welch_dev(stream.cap, stream.nbytes, stream.chunk_samples, stream.nperseg, stream.fs, stream.psd)
+        stream.welch()                  # K2
         ev[k][1].record()
-        dev.amp_stats_dev(stream.cap, stream.nbytes, stream.rssi_threshold, stream.amp)
-        dev.onset_dev(stream.cap, stream.nbytes, stream.noise_samples, stream.window, stream.factor, stream.onset)
         stream.tdoa()
         from gpsjam.sharded import gather_results
         gathered = gather_results(stream.pack(), rank, world, 0)

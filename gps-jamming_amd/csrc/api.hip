@@ -287,6 +287,16 @@ int gj_onset_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, int noise_samp
     return launch_onset(ctx, d_iq, nbytes, noise_samples, window, factor, d_out);
 }
 
+int gj_stream_scan_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
+                       float* d_power, float rssi_threshold, gj_amp_stats* d_amp, int noise_samples, int window,
+                       float factor, gj_onset* d_onset) {
+    GJ_ENTER(ctx);
+    if (!d_power || !d_amp || !d_onset || (nbytes && !d_iq)) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    if (chunk_bytes == 0) return fail(ctx, GJ_ERR_INVALID, "chunk_bytes must be > 0");
+    return launch_stream_scan(ctx, d_iq, nbytes, chunk_bytes, eps, flags, d_power, rssi_threshold, d_amp,
+                              noise_samples, window, factor, d_onset);
+}
+
 int gj_xcorr_lags_dev(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, int n_ant, const int64_t* d_starts,
                       size_t n_samples, const int32_t* pairs, int n_pairs, int32_t* d_lags, float* d_peaks) {
     GJ_ENTER(ctx);

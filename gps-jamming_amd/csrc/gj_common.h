@@ -128,6 +128,8 @@ int launch_chunk_power(gj_ctx*, const uint8_t*, size_t, size_t, float, int, floa
 int launch_power_threshold(gj_ctx*, const float*, size_t, float, float, float*, uint8_t*);
 int launch_amp_stats(gj_ctx*, const uint8_t*, size_t, float, gj_amp_stats*);
 int launch_onset(gj_ctx*, const uint8_t*, size_t, int, int, float, gj_onset*);
+int launch_stream_scan(gj_ctx*, const uint8_t*, size_t, size_t, float, int, float*, float, gj_amp_stats*, int, int,
+                       float, gj_onset*);
 int launch_histogram(gj_ctx*, const uint8_t*, size_t, size_t, int, int, unsigned long long*);
 int launch_welch(gj_ctx*, const uint8_t*, size_t, size_t, int, double, int, float*, float*);
 size_t welch_workspace(gj_ctx*, size_t, size_t, int);

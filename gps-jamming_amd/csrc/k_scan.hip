@@ -402,44 +402,52 @@ __global__ __launch_bounds__(kScanThreads) void onset_noise_kernel(const uint8_t
 
 __device__ __forceinline__ int onset_pad(int k) { return k + (k >> 5); }   // spreads stride-`per` accesses over banks
 
-// Screening pass (HBM-bound): per 16-byte load one exact sum c8 of 4|z|^2 over 8 samples
-// (v_dot4_u32_u8), then U[j] = sum of the CB = (window+6)/8 + 1 blocks starting at block j.
-// Every window that STARTS inside block j lies inside those blocks and 4|z|^2 >= 0, so
-// U[j] <= threshold proves that no start index in block j crosses the threshold.  Only the
-// first block that fails the proof is handed to the exact scan below.
-constexpr int kCoarseBlocks = 4096;   // 8-sample blocks per workgroup = 64 KiB of capture
+// Screening pass: exact block sums c[j] of 4|z|^2 over BS samples, then U[j] = sum of the
+// CB = (window + BS - 2)/BS + 1 blocks starting at block j.  Every window that STARTS inside
+// block j lies inside those blocks and 4|z|^2 >= 0, so U[j] <= threshold proves that no start
+// index in block j crosses the threshold; only the first block that fails the proof is handed
+// to the exact scan below (sc->cand = its first sample).
+//   BS = 8  : c8 straight from the capture, one 16-byte load per block (v_dot4_u32_u8) -- HBM-bound
+//   BS = 128: c128 precomputed by the fused stream scan (16 MB per GiB of capture)
+constexpr int kCoarseBlocks = 4096;   // blocks per workgroup
 constexpr int kCoarseHalo = (kOnsetMaxWin + 6) / 8 + 1;
 
-__global__ __launch_bounds__(kScanThreads) void onset_coarse_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
+template <int BS>
+__global__ __launch_bounds__(kScanThreads) void onset_coarse_kernel(const uint8_t* __restrict__ iq,
+                                                                    const unsigned* __restrict__ cblk, size_t nsamples,
                                                                     int window, OnsetScratch* __restrict__ sc) {
     __shared__ unsigned pre[kCoarseBlocks + kCoarseHalo + (kCoarseBlocks + kCoarseHalo) / 32 + 8];
     __shared__ unsigned thread_tot[kScanThreads];
     const size_t nout = nsamples - (size_t)window + 1;
     const size_t j0 = (size_t)blockIdx.x * kCoarseBlocks;   // first block of this tile
-    if (8 * j0 >= nout) return;
-    if (__hip_atomic_load(&sc->cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < j0) return;
-    const int cb = (window + 6) / 8 + 1;
+    if (BS * j0 >= nout) return;
+    if (__hip_atomic_load(&sc->cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < BS * j0) return;
+    const int cb = (window + BS - 2) / BS + 1;
     const int tid = threadIdx.x;
-    const size_t nblk_total = (nsamples + 7) / 8;
+    const size_t nblk_total = (nsamples + BS - 1) / BS;
     size_t jend = j0 + kCoarseBlocks;
-    if (8 * jend > nout) jend = (nout + 7) / 8;   // blocks holding a valid start index
+    if (BS * jend > nout) jend = (nout + BS - 1) / BS;   // blocks holding a valid start index
     const int nloc = (int)(jend - j0);
-    const int need = nloc + cb - 1;               // blocks [j0, j0 + need)
+    const int need = nloc + cb - 1;                      // blocks [j0, j0 + need)
     const uint4* v = reinterpret_cast<const uint4*>(iq);
     for (int k = tid; k < need; k += kScanThreads) {
         const size_t j = j0 + k;
-        unsigned c8 = 0;
+        unsigned c = 0;
         if (j < nblk_total) {
-            if (8 * j + 8 <= nsamples) {
-                const uint4 q = v[j];
-                unsigned s2 = 0, s1 = 0;
-                acc_moments(q, s2, s1);
-                c8 = 4u * s2 - 1020u * s1 + 16u * 65025u;
+            if constexpr (BS == 8) {
+                if (8 * j + 8 <= nsamples) {
+                    const uint4 q = v[j];
+                    unsigned s2 = 0, s1 = 0;
+                    acc_moments(q, s2, s1);
+                    c = 4u * s2 - 1020u * s1 + 16u * 65025u;
+                } else {
+                    for (size_t n = 8 * j; n < nsamples; ++n) c += m_of(iq[2 * n], iq[2 * n + 1]);
+                }
             } else {
-                for (size_t n = 8 * j; n < nsamples; ++n) c8 += m_of(iq[2 * n], iq[2 * n + 1]);
+                c = cblk[j];
             }
         }
-        pre[onset_pad(k + 1)] = c8;
+        pre[onset_pad(k + 1)] = c;
     }
     if (tid == 0) pre[0] = 0;
     __syncthreads();
@@ -477,7 +485,7 @@ __global__ __launch_bounds__(kScanThreads) void onset_coarse_kernel(const uint8_
     unsigned long long best = ~0ull;
     for (int k = tid; k < nloc; k += kScanThreads) {
         const unsigned U = pre[onset_pad(k + cb)] - pre[onset_pad(k)];
-        if ((double)U * scale > thr) { best = j0 + k; break; }
+        if ((double)U * scale > thr) { best = (unsigned long long)(j0 + k) * BS; break; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -487,7 +495,10 @@ __global__ __launch_bounds__(kScanThreads) void onset_coarse_kernel(const uint8_
     if ((tid & 63) == 0 && best != ~0ull) atomicMin(&sc->cand, best);
 }
 
-
+// Exact scan from the candidate on: prefix sums of 4|z|^2 in LDS, window sums by difference.
+// Persistent: workgroup g takes tiles g, g + grid, ... after the candidate and stops as soon
+// as an earlier tile has reported a hit (or the stream ends), so the common case -- onset in the
+// first tile after the candidate -- costs one tile per workgroup.
 __global__ __launch_bounds__(kScanThreads) void onset_scan_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
                                                                   int window, OnsetScratch* __restrict__ sc) {
     __shared__ unsigned pre[kOnsetLds + kOnsetLds / 32 + 2];
@@ -495,67 +506,71 @@ __global__ __launch_bounds__(kScanThreads) void onset_scan_kernel(const uint8_t*
     const size_t nout = nsamples - (size_t)window + 1;   // valid positions
     const unsigned long long cand = sc->cand;            // written by the screening kernel before this launch
     if (cand == ~0ull) return;                           // proven: nothing crosses the threshold
-    const size_t o0 = (size_t)cand * 8 + (size_t)blockIdx.x * kOnsetOut;
-    if (o0 >= nout) return;
-    // everything before this tile already decided?
-    if (__hip_atomic_load(&sc->first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < o0) return;
-    const size_t o1 = (o0 + kOnsetOut < nout) ? o0 + kOnsetOut : nout;
-    const int need = (int)(o1 - o0) + window - 1;   // samples [o0, o0+need)
     const int tid = threadIdx.x;
-    // (A) coalesced load: pre[1 + k] = 4|z_k|^2
-    const uint16_t* iq16 = reinterpret_cast<const uint16_t*>(iq) + o0;
-    for (int k = tid; k < need; k += kScanThreads) {
-        const unsigned w = iq16[k];
-        pre[onset_pad(k + 1)] = m_of(w & 255u, w >> 8);
-    }
-    if (tid == 0) pre[0] = 0;
-    __syncthreads();
-    // (B) inclusive prefix inside each thread's contiguous span
-    const int per = (need + kScanThreads - 1) / kScanThreads;
-    const int lo = tid * per;
-    const int hi = (lo + per < need) ? lo + per : need;
-    unsigned run = 0;
-    for (int k = lo; k < hi; ++k) {
-        run += pre[onset_pad(k + 1)];
-        pre[onset_pad(k + 1)] = run;
-    }
-    thread_tot[tid] = run;
-    __syncthreads();
-    // (C) exclusive scan of the 256 span totals
-    if (tid < 64) {
-        unsigned t0 = thread_tot[4 * tid], t1 = thread_tot[4 * tid + 1], t2 = thread_tot[4 * tid + 2],
-                 t3 = thread_tot[4 * tid + 3];
-        unsigned tot = t0 + t1 + t2 + t3, inc = tot;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned o = __shfl_up(inc, off, 64);
-            if (tid >= off) inc += o;
+    const uint16_t* iq16_all = reinterpret_cast<const uint16_t*>(iq);
+    for (size_t tile = blockIdx.x;; tile += gridDim.x) {
+        const size_t o0 = (size_t)cand + tile * kOnsetOut;
+        if (o0 >= nout) return;
+        // everything before this tile already decided?
+        if (__hip_atomic_load(&sc->first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < o0) return;
+        const size_t o1 = (o0 + kOnsetOut < nout) ? o0 + kOnsetOut : nout;
+        const int need = (int)(o1 - o0) + window - 1;   // samples [o0, o0+need)
+        // (A) coalesced load: pre[1 + k] = 4|z_k|^2
+        const uint16_t* iq16 = iq16_all + o0;
+        for (int k = tid; k < need; k += kScanThreads) {
+            const unsigned w = iq16[k];
+            pre[onset_pad(k + 1)] = m_of(w & 255u, w >> 8);
         }
-        const unsigned ex = inc - tot;
-        thread_tot[4 * tid] = ex;
-        thread_tot[4 * tid + 1] = ex + t0;
-        thread_tot[4 * tid + 2] = ex + t0 + t1;
-        thread_tot[4 * tid + 3] = ex + t0 + t1 + t2;
-    }
-    __syncthreads();
-    // (D) fold the span offsets in
-    const unsigned add = thread_tot[tid];
-    for (int k = lo; k < hi; ++k) pre[onset_pad(k + 1)] += add;
-    __syncthreads();
-    const double thr = (double)sc->thr;
-    const double scale = 0.25 / (double)window;
-    unsigned long long best = ~0ull;
-    const int nloc = (int)(o1 - o0);
-    for (int k = tid; k < nloc; k += kScanThreads) {
-        const unsigned S = pre[onset_pad(k + window)] - pre[onset_pad(k)];
-        if ((double)S * scale > thr) { best = o0 + k; break; }
-    }
+        if (tid == 0) pre[0] = 0;
+        __syncthreads();
+        // (B) inclusive prefix inside each thread's contiguous span
+        const int per = (need + kScanThreads - 1) / kScanThreads;
+        const int lo = tid * per;
+        const int hi = (lo + per < need) ? lo + per : need;
+        unsigned run = 0;
+        for (int k = lo; k < hi; ++k) {
+            run += pre[onset_pad(k + 1)];
+            pre[onset_pad(k + 1)] = run;
+        }
+        thread_tot[tid] = run;
+        __syncthreads();
+        // (C) exclusive scan of the 256 span totals
+        if (tid < 64) {
+            unsigned t0 = thread_tot[4 * tid], t1 = thread_tot[4 * tid + 1], t2 = thread_tot[4 * tid + 2],
+                     t3 = thread_tot[4 * tid + 3];
+            unsigned tot = t0 + t1 + t2 + t3, inc = tot;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(best, off, 64);
-        best = o < best ? o : best;
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = __shfl_up(inc, off, 64);
+                if (tid >= off) inc += o;
+            }
+            const unsigned ex = inc - tot;
+            thread_tot[4 * tid] = ex;
+            thread_tot[4 * tid + 1] = ex + t0;
+            thread_tot[4 * tid + 2] = ex + t0 + t1;
+            thread_tot[4 * tid + 3] = ex + t0 + t1 + t2;
+        }
+        __syncthreads();
+        // (D) fold the span offsets in
+        const unsigned add = thread_tot[tid];
+        for (int k = lo; k < hi; ++k) pre[onset_pad(k + 1)] += add;
+        __syncthreads();
+        const double thr = (double)sc->thr;
+        const double scale = 0.25 / (double)window;
+        unsigned long long best = ~0ull;
+        const int nloc = (int)(o1 - o0);
+        for (int k = tid; k < nloc; k += kScanThreads) {
+            const unsigned S = pre[onset_pad(k + window)] - pre[onset_pad(k)];
+            if ((double)S * scale > thr) { best = o0 + k; break; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(best, off, 64);
+            best = o < best ? o : best;
+        }
+        if ((tid & 63) == 0 && best != ~0ull) atomicMin(&sc->first, best);
+        __syncthreads();   // LDS is reused by the next tile
     }
-    if ((tid & 63) == 0 && best != ~0ull) atomicMin(&sc->first, best);
 }
 
 __global__ void onset_set_cand_kernel(OnsetScratch* __restrict__ sc) { sc->cand = 0; }
@@ -588,17 +603,219 @@ int launch_onset(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, int noise_samp
         if (ntiles > 0x7fffffffull) return fail(ctx, GJ_ERR_UNSUPPORTED, "capture too long");
         if ((reinterpret_cast<uintptr_t>(d_iq) & 15) == 0) {
             const size_t nct = ((nout + 7) / 8 + kCoarseBlocks - 1) / kCoarseBlocks;
-            hipLaunchKernelGGL(onset_coarse_kernel, dim3((unsigned)nct), dim3(kScanThreads), 0, ctx->stream, d_iq,
-                               nsamples, window, sc);
+            hipLaunchKernelGGL(onset_coarse_kernel<8>, dim3((unsigned)nct), dim3(kScanThreads), 0, ctx->stream, d_iq,
+                               (const unsigned*)nullptr, nsamples, window, sc);
         } else {
             hipLaunchKernelGGL(onset_set_cand_kernel, dim3(1), dim3(1), 0, ctx->stream, sc);   // scan everything
         }
         GJ_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(onset_scan_kernel, dim3((unsigned)ntiles), dim3(kScanThreads), 0, ctx->stream, d_iq, nsamples,
-                           window, sc);
+        hipLaunchKernelGGL(onset_scan_kernel, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(kScanThreads), 0,
+                           ctx->stream, d_iq, nsamples, window, sc);
         GJ_LAUNCH_CHECK(ctx);
     }
     hipLaunchKernelGGL(onset_finalize_kernel, dim3(1), dim3(1), 0, ctx->stream, sc, window, valid, d_out);
+    GJ_LAUNCH_CHECK(ctx);
+    return GJ_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused stream scan: ONE pass over the capture feeds K1 (chunk power), K3 (amplitude
+// statistics) and the K4 screening (128-sample block sums), instead of three passes.
+// One workgroup per 64 KiB tile; per 16-byte load (8 samples) a lane computes the byte moments
+// (v_dot4_u32_u8) that give both the chunk sums and the block sum of 4|z|^2, and the eight
+// amplitudes (v_dot2 on the packed (2I-255, 2Q-255) pair, v_sqrt_f32).
+// ---------------------------------------------------------------------------------------
+typedef short gj_short2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float amp_of_pair(unsigned iq16) {   // iq16 = I | Q << 8
+    // (2I-255, 2Q-255) as packed int16 -> dot with itself = 4|z|^2
+    const unsigned spread = (iq16 & 0xffu) | ((iq16 & 0xff00u) << 8);          // I in bits 0-7, Q in bits 16-23
+    const gj_short2 u = __builtin_bit_cast(gj_short2, spread);
+    const gj_short2 h = u * (short)2 - (short)255;                             // packed 16-bit: no borrow across halves
+    const int m = __builtin_amdgcn_sdot2(h, h, 0, false);
+    return __fsqrt_rn((float)m) * (1.0f / 255.0f);
+}
+
+template <bool TRACK_FIRST>
+__global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
+                                                                   size_t nbytes, size_t chunk_bytes,
+                                                                   unsigned tiles_per_chunk, float eps, int flags,
+                                                                   float* __restrict__ power,
+                                                                   unsigned long long* __restrict__ acc, float thr,
+                                                                   AmpTile* __restrict__ tiles,
+                                                                   unsigned* __restrict__ c128) {
+    __shared__ unsigned long long red_m[2][kScanThreads / 64];
+    __shared__ double red_s[kScanThreads / 64];
+    __shared__ long long red_f[kScanThreads / 64];
+    const int tid = threadIdx.x;
+    const size_t t = blockIdx.x;
+    const size_t b0 = t * kScanTile;                               // first byte of the tile
+    const size_t use_end = 2 * nsamples;                           // a trailing odd byte is never used
+    const size_t b1 = (b0 + kScanTile < use_end) ? b0 + kScanTile : use_end;
+    const size_t nvec = (b1 - b0) >> 4;                            // full 16-byte vectors
+    const uint4* v = reinterpret_cast<const uint4*>(iq + b0);
+    unsigned s2 = 0, s1 = 0;
+    double sum = 0.0;
+    long long first = 0x7fffffffffffffffll;
+    for (size_t i = tid; i < nvec; i += kScanThreads) {
+        const uint4 q = v[i];
+        unsigned v2 = 0, v1 = 0;
+        acc_moments(q, v2, v1);
+        s2 += v2;
+        s1 += v1;
+        // block sum of 4|z|^2 over the 16 lanes that hold one 128-sample block
+        int c8 = (int)(4u * v2 - 1020u * v1 + 16u * 65025u);
+        c8 = group_sum_dpp<16>(c8);
+        if ((tid & 15) == 0) c128[(b0 >> 8) + (i >> 4)] = (unsigned)c8;
+        const unsigned ws[4] = {q.x, q.y, q.z, q.w};
+        float part = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a0 = amp_of_pair(ws[k] & 0xffffu), a1 = amp_of_pair(ws[k] >> 16);
+            part += a0;
+            part += a1;
+            if constexpr (TRACK_FIRST) {
+                const long long base = (long long)((b0 >> 1) + i * 8 + 2 * k);
+                if (a0 > thr && base < first) first = base;
+                if (a1 > thr && base + 1 < first) first = base + 1;
+            }
+        }
+        sum += (double)part;
+    }
+    // ragged end of the stream (< 8 samples): one lane, scalar
+    if (tid == 0 && (b0 + (nvec << 4)) < b1) {
+        unsigned c = 0;
+        for (size_t n = (b0 >> 1) + nvec * 8; 2 * n < b1; ++n) {
+            const unsigned ui = iq[2 * n], uq = iq[2 * n + 1];
+            s2 += ui * ui + uq * uq;
+            s1 += ui + uq;
+            c += m_of(ui, uq);
+            const float a = amp_of_pair(ui | (uq << 8));
+            sum += (double)a;
+            if (TRACK_FIRST && a > thr && (long long)n < first) first = (long long)n;
+        }
+        (void)c;
+    }
+    // a stream that ends inside a 128-sample block: the lanes above wrote the sum of its full
+    // vectors only; one lane recomputes the whole block after the workgroup's stores have landed
+    if (b1 == use_end && (b1 & 255) != 0) {
+        __syncthreads();
+        if (tid == 0) {
+            const size_t jb = (b1 - 1) >> 8;
+            unsigned c = 0;
+            for (size_t n = jb * 128; n < nsamples; ++n) c += m_of(iq[2 * n], iq[2 * n + 1]);
+            c128[jb] = c;
+        }
+    }
+    if constexpr (!TRACK_FIRST) {
+        if (tid == 0 && b1 > b0) first = (long long)(b0 >> 1);   // threshold below the smallest amplitude
+    }
+    const unsigned long long m2 = wave_sum_u64(s2), m1 = wave_sum_u64(s1);
+    sum = wave_sum_f64(sum);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const long long o = __shfl_xor(first, off, 64);
+        first = o < first ? o : first;
+    }
+    if ((tid & 63) == 0) { red_m[0][tid >> 6] = m2; red_m[1][tid >> 6] = m1; red_s[tid >> 6] = sum; red_f[tid >> 6] = first; }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long t2 = red_m[0][0] + red_m[0][1] + red_m[0][2] + red_m[0][3];
+        const unsigned long long t1 = red_m[1][0] + red_m[1][1] + red_m[1][2] + red_m[1][3];
+        AmpTile at;
+        at.sum = (red_s[0] + red_s[1]) + (red_s[2] + red_s[3]);
+        long long f = red_f[0];
+        for (int k = 1; k < 4; ++k) f = red_f[k] < f ? red_f[k] : f;
+        at.first = f;
+        tiles[t] = at;
+        const size_t c = t / tiles_per_chunk;
+        const size_t off = c * chunk_bytes;
+        const size_t len = (nbytes - off < chunk_bytes) ? nbytes - off : chunk_bytes;
+        const bool zero_rule = (flags & GJ_CP_ODD_CHUNK_ZERO) && ((len & 1) || len == 0);
+        if (tiles_per_chunk == 1) {
+            power[c] = zero_rule ? 0.0f : ((len >> 1) ? power_from_moments(t2, t1, len >> 1, eps) : __builtin_nanf(""));
+        } else {
+            atomicAdd(&acc[2 * c], t2);
+            atomicAdd(&acc[2 * c + 1], t1);
+        }
+    }
+}
+
+__global__ void chunk_power_edge_kernel(size_t nchunks, size_t nbytes, size_t chunk_bytes, int flags,
+                                        float* __restrict__ power) {
+    // chunks the tile kernel never touches (a last chunk of 1 byte) or that follow the zero rule
+    const size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    const size_t off = c * chunk_bytes;
+    const size_t len = (nbytes - off < chunk_bytes) ? nbytes - off : chunk_bytes;
+    if ((flags & GJ_CP_ODD_CHUNK_ZERO) && ((len & 1) || len == 0)) power[c] = 0.0f;
+    else if ((len >> 1) == 0) power[c] = __builtin_nanf("");
+}
+
+int launch_stream_scan(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
+                       float* d_power, float rssi_threshold, gj_amp_stats* d_amp, int noise_samples, int window,
+                       float factor, gj_onset* d_onset) {
+    const bool fusable = chunk_bytes >= kScanTile && chunk_bytes % kScanTile == 0 &&
+                         (reinterpret_cast<uintptr_t>(d_iq) & 15) == 0 && nbytes >= 2;
+    if (!fusable) {   // odd chunk sizes / unaligned captures: the three separate passes
+        int rc = launch_chunk_power(ctx, d_iq, nbytes, chunk_bytes, eps, flags, d_power);
+        if (!rc) rc = launch_amp_stats(ctx, d_iq, nbytes, rssi_threshold, d_amp);
+        if (!rc) rc = launch_onset(ctx, d_iq, nbytes, noise_samples, window, factor, d_onset);
+        return rc;
+    }
+    if (noise_samples <= 0 || window <= 0) return fail(ctx, GJ_ERR_INVALID, "noise_samples and window must be > 0");
+    if (window > kOnsetMaxWin) return fail(ctx, GJ_ERR_UNSUPPORTED, "window > %d", kOnsetMaxWin);
+    const size_t nsamples = nbytes / 2;
+    const size_t ntiles = (2 * nsamples + kScanTile - 1) / kScanTile;
+    const size_t nchunks = gj_chunk_count(nbytes, chunk_bytes);
+    const size_t tpc = chunk_bytes / kScanTile;
+    const size_t n128 = (nsamples + 127) / 128;
+    if (ntiles > 0x7fffffffull) return fail(ctx, GJ_ERR_UNSUPPORTED, "capture too long");
+    // workspace: [OnsetScratch][AmpTile x ntiles][acc u64 x 2 x nchunks][c128 u32 x n128]
+    const size_t off_tiles = 256;
+    const size_t off_acc = off_tiles + align_up((ntiles + 1) * sizeof(AmpTile), 256);
+    const size_t off_c128 = off_acc + align_up(nchunks * 16, 256);
+    int rc = ensure_workspace(ctx, off_c128 + (n128 + 16) * sizeof(unsigned));
+    if (rc) return rc;
+    OnsetScratch* sc = reinterpret_cast<OnsetScratch*>(ctx->ws);
+    AmpTile* tiles = reinterpret_cast<AmpTile*>(ctx->ws + off_tiles);
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(ctx->ws + off_acc);
+    unsigned* c128 = reinterpret_cast<unsigned*>(ctx->ws + off_c128);
+    if (tpc > 1) GJ_HIP(ctx, hipMemsetAsync(acc, 0, nchunks * 16, ctx->stream));
+    // amplitudes are >= sqrt(2)/255 > 0.0055: a threshold below that makes every sample a hit
+    const bool track = !(rssi_threshold < 0.005f);
+    if (track)
+        hipLaunchKernelGGL(stream_scan_kernel<true>, dim3((unsigned)ntiles), dim3(kScanThreads), 0, ctx->stream, d_iq,
+                           nsamples, nbytes, chunk_bytes, (unsigned)tpc, eps, flags, d_power, acc, rssi_threshold, tiles, c128);
+    else
+        hipLaunchKernelGGL(stream_scan_kernel<false>, dim3((unsigned)ntiles), dim3(kScanThreads), 0, ctx->stream, d_iq,
+                           nsamples, nbytes, chunk_bytes, (unsigned)tpc, eps, flags, d_power, acc, rssi_threshold, tiles, c128);
+    GJ_LAUNCH_CHECK(ctx);
+    if (tpc > 1) {
+        hipLaunchKernelGGL(chunk_power_finalize_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0,
+                           ctx->stream, acc, nchunks, nbytes, chunk_bytes, eps, flags, d_power);
+        GJ_LAUNCH_CHECK(ctx);
+    }
+    hipLaunchKernelGGL(chunk_power_edge_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, ctx->stream,
+                       nchunks, nbytes, chunk_bytes, flags, d_power);
+    GJ_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(amp_finalize_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_iq, nsamples, tiles, ntiles, d_amp);
+    GJ_LAUNCH_CHECK(ctx);
+    const int valid = nsamples >= (size_t)noise_samples + (size_t)window;
+    if (valid) {
+        hipLaunchKernelGGL(onset_noise_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_iq, noise_samples, factor, sc);
+        GJ_LAUNCH_CHECK(ctx);
+        const size_t nout = nsamples - window + 1;
+        const size_t nct = ((nout + 127) / 128 + kCoarseBlocks - 1) / kCoarseBlocks;
+        hipLaunchKernelGGL(onset_coarse_kernel<128>, dim3((unsigned)nct), dim3(kScanThreads), 0, ctx->stream, d_iq,
+                           (const unsigned*)c128, nsamples, window, sc);
+        GJ_LAUNCH_CHECK(ctx);
+        const size_t nt = (nout + kOnsetOut - 1) / kOnsetOut;
+        hipLaunchKernelGGL(onset_scan_kernel, dim3((unsigned)(nt < 512 ? nt : 512)), dim3(kScanThreads), 0, ctx->stream,
+                           d_iq, nsamples, window, sc);
+        GJ_LAUNCH_CHECK(ctx);
+    }
+    hipLaunchKernelGGL(onset_finalize_kernel, dim3(1), dim3(1), 0, ctx->stream, sc, window, valid, d_onset);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
 }

@@ -285,6 +285,13 @@ class Device:
         self._check(self._lib.gj_onset_dev(self._ctx, _ptr(d_iq), nbytes, noise_samples, window,
                                            factor, _ptr(d_out)))
 
+    def stream_scan_dev(self, d_iq, nbytes, chunk_bytes, d_power, rssi_threshold, d_amp, noise_samples, window,
+                        factor, d_onset, eps=1e-10, flags=0):
+        """K1 + K3 + K4 in one pass over the capture (gj_stream_scan_dev)."""
+        self._check(self._lib.gj_stream_scan_dev(self._ctx, _ptr(d_iq), nbytes, chunk_bytes, eps, flags,
+                                                 _ptr(d_power), rssi_threshold, _ptr(d_amp), noise_samples,
+                                                 window, factor, _ptr(d_onset)))
+
     def xcorr_lags_dev(self, d_iqs, nbytes_list, d_starts, n_samples, pairs, d_lags, d_peaks):
         n_ant = len(d_iqs)
         ptrs = (C.c_void_p * n_ant)(*[_ptr(p) for p in d_iqs])

@@ -78,6 +78,7 @@ SIGNATURES = {
     "gj_amp_stats_u8": (_i, [_vp, _vp, _sz, _f, C.POINTER(AmpStats), _pf]),
     "gj_onset_dev": (_i, [_vp, _vp, _sz, _i, _i, _f, _vp]),
     "gj_onset_u8": (_i, [_vp, _vp, _sz, _i, _i, _f, C.POINTER(Onset), _pf]),
+    "gj_stream_scan_dev": (_i, [_vp, _vp, _sz, _sz, _f, _i, _vp, _f, _vp, _i, _i, _f, _vp]),
     "gj_xcorr_lags_dev": (_i, [_vp, C.POINTER(_vp), _psz, _i, _vp, _sz, C.POINTER(C.c_int32), _i,
                                _vp, _vp]),
     "gj_xcorr_lags_u8": (_i, [_vp, C.POINTER(_vp), _i, _sz, C.POINTER(C.c_int32), _i,

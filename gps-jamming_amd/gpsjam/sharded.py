@@ -148,17 +148,22 @@ class AntennaStream:
         self._ar = torch.arange(slice_samples, dtype=torch.int64, device=d)
         self.cap16 = capture.view(torch.int16)
         ws = max(dev.welch_workspace(self.nbytes, chunk_samples, nperseg),
-                 dev.xcorr_workspace(2, slice_samples, 1), 1 << 20)
+                 dev.xcorr_workspace(2, slice_samples, 1), self.nbytes // 48 + (1 << 20))
         dev.reserve(ws)
 
+    def stream_scan(self):
+        """K1 + K3 + K4 in one pass over the capture, then the noise-floor threshold."""
+        self.dev.stream_scan_dev(self.cap, self.nbytes, self.chunk_bytes, self.power, self.rssi_threshold,
+                                 self.amp, self.noise_samples, self.window, self.factor, self.onset)
+        self.dev.power_threshold_dev(self.power, self.n_chunks, self.stats, self.mask)
+
+    def welch(self):
+        self.dev.welch_dev(self.cap, self.nbytes, self.chunk_samples, self.nperseg, self.fs, self.psd)
+
     def scan(self):
-        """K1 + threshold, K2, K3, K4 on this rank's capture (no host synchronisation)."""
-        dev = self.dev
-        dev.chunk_power_dev(self.cap, self.nbytes, self.chunk_bytes, self.power)
-        dev.power_threshold_dev(self.power, self.n_chunks, self.stats, self.mask)
-        dev.welch_dev(self.cap, self.nbytes, self.chunk_samples, self.nperseg, self.fs, self.psd)
-        dev.amp_stats_dev(self.cap, self.nbytes, self.rssi_threshold, self.amp)
-        dev.onset_dev(self.cap, self.nbytes, self.noise_samples, self.window, self.factor, self.onset)
+        """Everything that only needs this rank's capture (no host synchronisation)."""
+        self.stream_scan()
+        self.welch()
 
     def tdoa(self):
         """Reference slice from rank 0 (broadcast), lag of this capture against it."""

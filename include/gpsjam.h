@@ -152,6 +152,16 @@ int gj_onset_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, int noise_samp
 int gj_onset_u8(gj_ctx* ctx, const uint8_t* iq, size_t nbytes, int noise_samples, int window,
                 float factor, gj_onset* out, float* kernel_ms);
 
+/* ------------------------------------------------- fused stream scan ---------------- */
+/* K1 + K3 + K4 in ONE pass over the capture (the three are pure streaming reductions over
+ * the same bytes): identical results to gj_chunk_power_dev, gj_amp_stats_dev and gj_onset_dev
+ * called one after the other.  The single pass is used when chunk_bytes is a multiple of
+ * 65536 and the capture is 16-byte aligned; otherwise the three passes run back to back. */
+int gj_stream_scan_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes,
+                       size_t chunk_bytes, float eps, int flags, float* d_power,
+                       float rssi_threshold, gj_amp_stats* d_amp,
+                       int noise_samples, int window, float factor, gj_onset* d_onset);
+
 /* ------------------------------------------------- K5: TDOA cross-correlation ------- */
 /* Replaces signal.correlate(sig1, sig0, 'full') + argmax|.| - (N-1)
  * (skrypty/triangulateTDOA.py:80-89) for every requested antenna pair.

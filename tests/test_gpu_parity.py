@@ -323,3 +323,41 @@ def test_full_size_1gib_properties(dev):
     ref_part = np.sqrt(v[0::2] ** 2 + v[1::2] ** 2).sum() / 255.0
     st = dev.amp_stats(raw[:1 << 26], 0.0)
     np.testing.assert_allclose(st.sum, ref_part, rtol=1e-7)
+
+
+# ----------------------------------------------------------------------------- fused stream scan
+@pytest.mark.parametrize("nbytes,chunk,thr", [(20 * 65536 + 24691, 65536, 0.0), (20 * 65536 + 24691, 131072, 0.45),
+                                              (65536 * 7, 65536, 0.1), (65536 * 3 + 254, 65536, 0.0),
+                                              (65536 * 3 + 258, 65536, 0.2), (600001, 65536, 0.0),
+                                              (400000, 1000, 0.0), (2, 65536, 0.0), (3, 65536, 0.0)])
+def test_stream_scan_equals_separate_kernels(dev, nbytes, chunk, thr):
+    """gj_stream_scan_dev (one pass) against K1, K3, K4 called one after the other."""
+    n = (nbytes + 1) // 2
+    raw = generate(StreamSpec(seed=nbytes & 0xffff, jam_start=220000, jam_end=1 << 40, jam_sigma=60.0), n)[:nbytes]
+    buf = dev.alloc(max(nbytes, 16)).upload(raw)
+    nch = dev.chunk_count(nbytes, chunk)
+    out = {}
+    for mode in ("fused", "separate"):
+        d_pow, d_amp, d_on = dev.alloc(4 * max(nch, 1)), dev.alloc(32), dev.alloc(16)
+        if mode == "fused":
+            dev.stream_scan_dev(buf, nbytes, chunk, d_pow, thr, d_amp, 200000, 1000, 50.0, d_on)
+        else:
+            dev.chunk_power_dev(buf, nbytes, chunk, d_pow)
+            dev.amp_stats_dev(buf, nbytes, thr, d_amp)
+            dev.onset_dev(buf, nbytes, 200000, 1000, 50.0, d_on)
+        dev.synchronize()
+        amp = np.frombuffer(d_amp.download(np.uint8).tobytes(), dtype=[("i", "<i8"), ("c", "<u8"), ("s", "<f8"),
+                                                                       ("m", "<f4"), ("r", "<f4")])[0]
+        out[mode] = (d_pow.download(np.float32, nch), amp, int(d_on.download(np.int64, 1)[0]))
+    np.testing.assert_array_equal(out["fused"][0], out["separate"][0])
+    np.testing.assert_array_equal(out["fused"][0], exact_chunk_power(raw, chunk))
+    assert out["fused"][1]["i"] == out["separate"][1]["i"] and out["fused"][1]["c"] == out["separate"][1]["c"]
+    np.testing.assert_allclose(out["fused"][1]["s"], out["separate"][1]["s"], rtol=1e-7)   # f32 partial sums group differently
+    assert out["fused"][2] == out["separate"][2]
+    even = raw[:2 * (nbytes // 2)]          # the reference itself cannot unpack an odd-length file
+    k, avg = orc.rssi_amp_stats(even, thr)
+    if k is not None:
+        assert out["fused"][1]["i"] == k
+        np.testing.assert_allclose(out["fused"][1]["m"], avg, rtol=1e-6)
+    z = orc.tdoa_unpack(even)
+    assert out["fused"][2] == orc.tdoa_onset(z)

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(REPO, "gps-jamming_amd"))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["welch", "scan", "xcorr", "k1", "k3", "k4"])
+    ap.add_argument("what", choices=["welch", "scan", "fscan", "thr", "xcorr", "k1", "k3", "k4"])
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--nperseg", type=int, default=4096)
     ap.add_argument("--bytes", type=int, default=1 << 30)
@@ -48,6 +48,10 @@ def main():
             dev.amp_stats_dev(cap, nbytes, 0.0, d_amp)
         elif args.what == "k4":
             dev.onset_dev(cap, nbytes, 200000, 1000, 50.0, d_on)
+        elif args.what == "fscan":
+            dev.stream_scan_dev(cap, nbytes, 65536, d_pow, 0.0, d_amp, 200000, 1000, 50.0, d_on)
+        elif args.what == "thr":
+            dev.power_threshold_dev(d_pow, nch, d_stats, d_mask)
         elif args.what == "scan":
             dev.chunk_power_dev(cap, nbytes, 65536, d_pow)
             dev.power_threshold_dev(d_pow, nch, d_stats, d_mask)
