@@ -149,33 +149,63 @@ __device__ __forceinline__ float key_float(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-// value of rank `rank` (0-based, ascending, NaNs last) -- whole block must call
-__device__ unsigned block_select(const float* __restrict__ a, size_t n, size_t rank, unsigned* hist /* [256] */,
-                                 unsigned* bc /* [2] */) {
+// Radix select over monotone uint keys of the power map, keys cached in LDS (one read of the
+// map from HBM), 256-bin histograms by LDS atomics, digit search by a parallel prefix scan.
+constexpr int kThrCache = 32768;   // keys held in LDS (128 KiB); longer maps re-read global memory
+
+struct ThrShared {
+    unsigned hist[256];
+    unsigned wave_tot[4];
+    unsigned digit, rest;
+    unsigned nan_flag;
+    unsigned count_le;
+    unsigned next_key;
+    unsigned long long above;
+    float thr;
+};
+
+__device__ __forceinline__ unsigned thr_key(const unsigned* __restrict__ keys, const float* __restrict__ power, bool cached,
+                                            size_t i) {
+    return cached ? keys[i] : float_key(power[i]);
+}
+
+// key of rank `rank` (0-based, ascending, NaNs last) -- whole block must call
+__device__ unsigned block_select(const unsigned* __restrict__ keys, const float* __restrict__ power, bool cached, size_t n,
+                                 size_t rank, ThrShared& sh) {
     unsigned prefix = 0, mask = 0;
-    size_t want = rank;
+    unsigned want = (unsigned)rank;
+    const int tid = threadIdx.x;
     for (int shift = 24; shift >= 0; shift -= 8) {
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        if (tid < 256) sh.hist[tid] = 0;
         __syncthreads();
-        for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
-            unsigned k = float_key(a[i]);
-            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        for (size_t i = tid; i < n; i += blockDim.x) {
+            const unsigned k = thr_key(keys, power, cached, i);
+            if ((k & mask) == prefix) atomicAdd(&sh.hist[(k >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            size_t cum = 0;
-            unsigned d = 0;
-            for (; d < 256; ++d) {
-                if (cum + hist[d] > want) break;
-                cum += hist[d];
+        // digit d with excl(d) <= want < excl(d) + hist[d]
+        unsigned h = 0, inc = 0;
+        if (tid < 256) {
+            h = sh.hist[tid];
+            inc = h;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = __shfl_up(inc, off, 64);
+                if ((tid & 63) >= off) inc += o;
             }
-            bc[0] = d;
-            bc[1] = (unsigned)(want - cum);
+            if ((tid & 63) == 63) sh.wave_tot[tid >> 6] = inc;
         }
         __syncthreads();
-        prefix |= bc[0] << shift;
+        if (tid < 256) {
+            unsigned base = 0;
+            for (int w = 0; w < (tid >> 6); ++w) base += sh.wave_tot[w];
+            const unsigned excl = base + inc - h;
+            if (h && excl <= want && want < excl + h) { sh.digit = tid; sh.rest = want - excl; }
+        }
+        __syncthreads();
+        prefix |= sh.digit << shift;
         mask |= 255u << shift;
-        want = bc[1];
+        want = sh.rest;
         __syncthreads();
     }
     return prefix;
@@ -184,16 +214,19 @@ __device__ unsigned block_select(const float* __restrict__ a, size_t n, size_t r
 __global__ __launch_bounds__(1024) void power_threshold_kernel(const float* __restrict__ power, size_t n, float pct,
                                                                float ratio, float* __restrict__ stats,
                                                                uint8_t* __restrict__ mask) {
-    __shared__ unsigned hist[256];
-    __shared__ unsigned bc[2];
-    __shared__ unsigned nan_flag;
-    __shared__ unsigned long long above;
-    __shared__ float thr_s;
-    if (threadIdx.x == 0) { nan_flag = 0; above = 0; }
+    __shared__ unsigned keys[kThrCache];
+    __shared__ ThrShared sh;
+    const int tid = threadIdx.x;
+    const bool cached = n <= (size_t)kThrCache;
+    if (tid == 0) { sh.nan_flag = 0; sh.above = 0; sh.count_le = 0; sh.next_key = 0xffffffffu; }
     __syncthreads();
     unsigned has_nan = 0;
-    for (size_t i = threadIdx.x; i < n; i += blockDim.x) has_nan |= (power[i] != power[i]);
-    if (has_nan) atomicOr(&nan_flag, 1u);
+    for (size_t i = tid; i < n; i += blockDim.x) {
+        const float p = power[i];
+        has_nan |= (p != p);
+        if (cached) keys[i] = float_key(p);
+    }
+    if (has_nan) atomicOr(&sh.nan_flag, 1u);
     // numpy 2.x: q = float32(pct)/float32(100); virtual index = float32(n-1) * q  (all float32)
     const float q = pct / 100.0f;
     const float vidx = (float)(n - 1) * q;
@@ -201,30 +234,49 @@ __global__ __launch_bounds__(1024) void power_threshold_kernel(const float* __re
     if (lo > n - 1) lo = n - 1;
     const size_t hi = (lo + 1 < n) ? lo + 1 : n - 1;
     const float g = vidx - (float)lo;
-    const float a = key_float(block_select(power, n, lo, hist, bc));
-    const float b = key_float(block_select(power, n, hi, hist, bc));
-    if (threadIdx.x == 0) {
+    const unsigned ka = block_select(keys, power, cached, n, lo, sh);
+    // rank lo+1: ka again when it occurs often enough, else the smallest key above it
+    unsigned kb = ka;
+    if (hi != lo) {
+        unsigned cnt = 0, nxt = 0xffffffffu;
+        for (size_t i = tid; i < n; i += blockDim.x) {
+            const unsigned k = thr_key(keys, power, cached, i);
+            cnt += (k <= ka);
+            if (k > ka && k < nxt) nxt = k;
+        }
+        cnt = wave_sum_u32(cnt);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned o = __shfl_xor(nxt, off, 64);
+            nxt = o < nxt ? o : nxt;
+        }
+        if ((tid & 63) == 0) { atomicAdd(&sh.count_le, cnt); atomicMin(&sh.next_key, nxt); }
+        __syncthreads();
+        kb = (sh.count_le >= lo + 2) ? ka : sh.next_key;
+    }
+    if (tid == 0) {
+        const float a = key_float(ka), b = key_float(kb);
         const float d = b - a;
         float base = (g >= 0.5f) ? (b - d * (1.0f - g)) : (a + d * g);
-        if (nan_flag) base = __builtin_nanf("");
+        if (sh.nan_flag) base = __builtin_nanf("");
         if (base <= 0.0f) base = 1.0f;
         const float thr = base * ratio;
         stats[0] = base;
         stats[1] = thr;
-        thr_s = thr;
+        sh.thr = thr;
     }
     __syncthreads();
-    const float thr = thr_s;
+    const float thr = sh.thr;
     unsigned cnt = 0;
-    for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+    for (size_t i = tid; i < n; i += blockDim.x) {
         const bool hot = power[i] > thr;
         cnt += hot;
         if (mask) mask[i] = hot;
     }
     cnt = wave_sum_u32(cnt);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&above, (unsigned long long)cnt);
+    if ((tid & 63) == 0) atomicAdd(&sh.above, (unsigned long long)cnt);
     __syncthreads();
-    if (threadIdx.x == 0) stats[2] = (float)above;
+    if (tid == 0) stats[2] = (float)sh.above;
 }
 
 int launch_power_threshold(gj_ctx* ctx, const float* d_power, size_t n, float pct, float rise_db, float* d_stats,
@@ -316,7 +368,16 @@ __device__ double block_sum_f64(double v, double* sh /* [blockDim/64] */) {
 
 __global__ __launch_bounds__(1024) void amp_finalize_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
                                                             const AmpTile* __restrict__ tiles, size_t ntiles,
-                                                            gj_amp_stats* __restrict__ out) {
+                                                            gj_amp_stats* __restrict__ out,
+                                                            float* __restrict__ power = nullptr, size_t nchunks = 0,
+                                                            size_t nbytes = 0, size_t chunk_bytes = 1, int flags = 0) {
+    // (fused scan only) the last chunk when no tile wrote it or the odd-chunk rule applies
+    if (power && nchunks && threadIdx.x == 0) {
+        const size_t off = (nchunks - 1) * chunk_bytes;
+        const size_t len = nbytes - off;
+        if ((flags & GJ_CP_ODD_CHUNK_ZERO) && (len & 1)) power[nchunks - 1] = 0.0f;
+        else if ((len >> 1) == 0) power[nchunks - 1] = __builtin_nanf("");
+    }
     __shared__ double sh[16];
     __shared__ long long first_s;
     if (threadIdx.x == 0) first_s = 0x7fffffffffffffffll;
@@ -335,9 +396,14 @@ __global__ __launch_bounds__(1024) void amp_finalize_kernel(const uint8_t* __res
     const size_t t0 = (size_t)first / kAmpTileSamples;
     double acc = 0.0;
     for (size_t t = t0 + 1 + threadIdx.x; t < ntiles; t += blockDim.x) acc += tiles[t].sum;
-    // remainder of the tile that holds the first hit
-    const size_t e0 = ((t0 + 1) * kAmpTileSamples < nsamples) ? (t0 + 1) * kAmpTileSamples : nsamples;
-    for (size_t s = (size_t)first + threadIdx.x; s < e0; s += blockDim.x) acc += (double)amp_of(iq[2 * s], iq[2 * s + 1]);
+    if ((size_t)first == t0 * kAmpTileSamples) {
+        if (threadIdx.x == 0) acc += tiles[t0].sum;   // hit on the tile's first sample: its sum is the remainder
+    } else {
+        // remainder of the tile that holds the first hit
+        const size_t e0 = ((t0 + 1) * kAmpTileSamples < nsamples) ? (t0 + 1) * kAmpTileSamples : nsamples;
+        for (size_t s = (size_t)first + threadIdx.x; s < e0; s += blockDim.x)
+            acc += (double)amp_of(iq[2 * s], iq[2 * s + 1]);
+    }
     const double total = block_sum_f64(acc, sh);
     if (threadIdx.x == 0) {
         const unsigned long long cnt = nsamples - (size_t)first;
@@ -369,16 +435,28 @@ int launch_amp_stats(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, float thre
 // ---------------------------------------------------------------------------------------
 // K4 onset: moving average of |z|^2 against factor x noise, exact integer window sums
 // ---------------------------------------------------------------------------------------
-constexpr int kOnsetOut = 8192;    // moving-average positions per workgroup
+constexpr int kOnsetOut = 2048;    // moving-average positions per workgroup tile of the exact scan
 constexpr int kOnsetMaxWin = 8192;
 constexpr int kOnsetLds = kOnsetOut + kOnsetMaxWin;   // u32 words (64 KiB)
 
+// All-zero = initial state (one hipMemsetAsync): the two minima are kept INVERTED (atomicMax of
+// ~index, 0 = none) so that zero means "nothing found yet".
 struct OnsetScratch {
-    unsigned long long first;   // min index of the moving average above threshold
-    unsigned long long cand;    // first 8-sample block whose coarse upper bound exceeds the threshold
+    unsigned long long first_inv;   // ~(min index whose moving average is above the threshold)
+    unsigned long long cand_inv;    // ~(first sample of the first block that fails the screening proof)
+    unsigned long long noise_m2;    // sum u^2 / sum u over the bytes of the first noise_samples samples
+    unsigned long long noise_m1;
     float noise;
     float thr;
 };
+
+__device__ __forceinline__ float onset_threshold(const OnsetScratch* sc, int noise_samples, float factor, float* noise_out) {
+    const long long S = 4ll * (long long)sc->noise_m2 - 1020ll * (long long)sc->noise_m1 + 65025ll * (2ll * noise_samples);
+    float noise = (float)((double)S / (4.0 * (double)noise_samples));
+    if (noise == 0.f) noise = 1e-9f;          // triangulateTDOA.py:42
+    if (noise_out) *noise_out = noise;
+    return noise * factor;
+}
 
 __device__ __forceinline__ unsigned m_of(unsigned i8, unsigned q8) {
     const int vi = 2 * (int)i8 - 255, vq = 2 * (int)q8 - 255;
@@ -386,18 +464,10 @@ __device__ __forceinline__ unsigned m_of(unsigned i8, unsigned q8) {
 }
 
 __global__ __launch_bounds__(kScanThreads) void onset_noise_kernel(const uint8_t* __restrict__ iq, int noise_samples,
-                                                                   float factor, OnsetScratch* __restrict__ sc) {
+                                                                   OnsetScratch* __restrict__ sc) {
     unsigned long long s2 = 0, s1 = 0;
     block_byte_moments(iq, 0, (size_t)2 * noise_samples, s2, s1);
-    if (threadIdx.x == 0) {
-        const long long S = 4ll * (long long)s2 - 1020ll * (long long)s1 + 65025ll * (2ll * noise_samples);
-        float noise = (float)((double)S / (4.0 * (double)noise_samples));
-        if (noise == 0.f) noise = 1e-9f;
-        sc->noise = noise;
-        sc->thr = noise * factor;
-        sc->first = ~0ull;
-        sc->cand = ~0ull;
-    }
+    if (threadIdx.x == 0) { sc->noise_m2 = s2; sc->noise_m1 = s1; }
 }
 
 __device__ __forceinline__ int onset_pad(int k) { return k + (k >> 5); }   // spreads stride-`per` accesses over banks
@@ -408,22 +478,26 @@ __device__ __forceinline__ int onset_pad(int k) { return k + (k >> 5); }   // sp
 // index in block j crosses the threshold; only the first block that fails the proof is handed
 // to the exact scan below (sc->cand = its first sample).
 //   BS = 8  : c8 straight from the capture, one 16-byte load per block (v_dot4_u32_u8) -- HBM-bound
-//   BS = 128: c128 precomputed by the fused stream scan (16 MB per GiB of capture)
+//   BS = 512: c512 precomputed by the fused stream scan (4 MB per GiB of capture)
 constexpr int kCoarseBlocks = 4096;   // blocks per workgroup
 constexpr int kCoarseHalo = (kOnsetMaxWin + 6) / 8 + 1;
 
 template <int BS>
 __global__ __launch_bounds__(kScanThreads) void onset_coarse_kernel(const uint8_t* __restrict__ iq,
                                                                     const unsigned* __restrict__ cblk, size_t nsamples,
-                                                                    int window, OnsetScratch* __restrict__ sc) {
+                                                                    int window, int noise_samples, float factor,
+                                                                    OnsetScratch* __restrict__ sc) {
     __shared__ unsigned pre[kCoarseBlocks + kCoarseHalo + (kCoarseBlocks + kCoarseHalo) / 32 + 8];
     __shared__ unsigned thread_tot[kScanThreads];
     const size_t nout = nsamples - (size_t)window + 1;
     const size_t j0 = (size_t)blockIdx.x * kCoarseBlocks;   // first block of this tile
-    if (BS * j0 >= nout) return;
-    if (__hip_atomic_load(&sc->cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < BS * j0) return;
-    const int cb = (window + BS - 2) / BS + 1;
     const int tid = threadIdx.x;
+    float noise;
+    const double thr = (double)onset_threshold(sc, noise_samples, factor, &noise);
+    if (blockIdx.x == 0 && tid == 0) { sc->noise = noise; sc->thr = (float)thr; }   // for the exact scan + report
+    if (BS * j0 >= nout) return;
+    if (~__hip_atomic_load(&sc->cand_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < BS * j0) return;
+    const int cb = (window + BS - 2) / BS + 1;
     const size_t nblk_total = (nsamples + BS - 1) / BS;
     size_t jend = j0 + kCoarseBlocks;
     if (BS * jend > nout) jend = (nout + BS - 1) / BS;   // blocks holding a valid start index
@@ -480,7 +554,6 @@ __global__ __launch_bounds__(kScanThreads) void onset_coarse_kernel(const uint8_
     const unsigned add = thread_tot[tid];
     for (int k = lo; k < hi; ++k) pre[onset_pad(k + 1)] += add;
     __syncthreads();
-    const double thr = (double)sc->thr;
     const double scale = 0.25 / (double)window;
     unsigned long long best = ~0ull;
     for (int k = tid; k < nloc; k += kScanThreads) {
@@ -492,7 +565,7 @@ __global__ __launch_bounds__(kScanThreads) void onset_coarse_kernel(const uint8_
         const unsigned long long o = __shfl_xor(best, off, 64);
         best = o < best ? o : best;
     }
-    if ((tid & 63) == 0 && best != ~0ull) atomicMin(&sc->cand, best);
+    if ((tid & 63) == 0 && best != ~0ull) atomicMax(&sc->cand_inv, ~best);
 }
 
 // Exact scan from the candidate on: prefix sums of 4|z|^2 in LDS, window sums by difference.
@@ -504,7 +577,7 @@ __global__ __launch_bounds__(kScanThreads) void onset_scan_kernel(const uint8_t*
     __shared__ unsigned pre[kOnsetLds + kOnsetLds / 32 + 2];
     __shared__ unsigned thread_tot[kScanThreads];
     const size_t nout = nsamples - (size_t)window + 1;   // valid positions
-    const unsigned long long cand = sc->cand;            // written by the screening kernel before this launch
+    const unsigned long long cand = ~sc->cand_inv;       // written by the screening kernel before this launch
     if (cand == ~0ull) return;                           // proven: nothing crosses the threshold
     const int tid = threadIdx.x;
     const uint16_t* iq16_all = reinterpret_cast<const uint16_t*>(iq);
@@ -512,7 +585,7 @@ __global__ __launch_bounds__(kScanThreads) void onset_scan_kernel(const uint8_t*
         const size_t o0 = (size_t)cand + tile * kOnsetOut;
         if (o0 >= nout) return;
         // everything before this tile already decided?
-        if (__hip_atomic_load(&sc->first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < o0) return;
+        if (~__hip_atomic_load(&sc->first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < o0) return;
         const size_t o1 = (o0 + kOnsetOut < nout) ? o0 + kOnsetOut : nout;
         const int need = (int)(o1 - o0) + window - 1;   // samples [o0, o0+need)
         // (A) coalesced load: pre[1 + k] = 4|z_k|^2
@@ -568,19 +641,25 @@ __global__ __launch_bounds__(kScanThreads) void onset_scan_kernel(const uint8_t*
             const unsigned long long o = __shfl_xor(best, off, 64);
             best = o < best ? o : best;
         }
-        if ((tid & 63) == 0 && best != ~0ull) atomicMin(&sc->first, best);
+        if ((tid & 63) == 0 && best != ~0ull) atomicMax(&sc->first_inv, ~best);
         __syncthreads();   // LDS is reused by the next tile
     }
 }
 
-__global__ void onset_set_cand_kernel(OnsetScratch* __restrict__ sc) { sc->cand = 0; }
+__global__ void onset_set_cand_kernel(OnsetScratch* __restrict__ sc, int noise_samples, float factor) {
+    // unaligned capture: no screening, scan from sample 0
+    sc->cand_inv = ~0ull;
+    float noise;
+    sc->thr = onset_threshold(sc, noise_samples, factor, &noise);
+    sc->noise = noise;
+}
 
 __global__ void onset_finalize_kernel(const OnsetScratch* __restrict__ sc, int window, int valid, gj_onset* __restrict__ out) {
     if (!valid) {
         out->start_index = -1; out->noise_power = 0.f; out->threshold = 0.f;
         return;
     }
-    out->start_index = (sc->first == ~0ull) ? -1 : (long long)sc->first + window / 2;
+    out->start_index = (sc->first_inv == 0ull) ? -1 : (long long)(~sc->first_inv) + window / 2;
     out->noise_power = sc->noise;
     out->threshold = sc->thr;
 }
@@ -594,9 +673,10 @@ int launch_onset(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, int noise_samp
     int rc = ensure_workspace(ctx, sizeof(OnsetScratch));
     if (rc) return rc;
     OnsetScratch* sc = reinterpret_cast<OnsetScratch*>(ctx->ws);
+    GJ_HIP(ctx, hipMemsetAsync(sc, 0, sizeof(OnsetScratch), ctx->stream));
     const int valid = nsamples >= (size_t)noise_samples + (size_t)window;   // triangulateTDOA.py:39
     if (valid) {
-        hipLaunchKernelGGL(onset_noise_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_iq, noise_samples, factor, sc);
+        hipLaunchKernelGGL(onset_noise_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_iq, noise_samples, sc);
         GJ_LAUNCH_CHECK(ctx);
         const size_t nout = nsamples - window + 1;
         const size_t ntiles = (nout + kOnsetOut - 1) / kOnsetOut;
@@ -604,12 +684,12 @@ int launch_onset(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, int noise_samp
         if ((reinterpret_cast<uintptr_t>(d_iq) & 15) == 0) {
             const size_t nct = ((nout + 7) / 8 + kCoarseBlocks - 1) / kCoarseBlocks;
             hipLaunchKernelGGL(onset_coarse_kernel<8>, dim3((unsigned)nct), dim3(kScanThreads), 0, ctx->stream, d_iq,
-                               (const unsigned*)nullptr, nsamples, window, sc);
+                               (const unsigned*)nullptr, nsamples, window, noise_samples, factor, sc);
         } else {
-            hipLaunchKernelGGL(onset_set_cand_kernel, dim3(1), dim3(1), 0, ctx->stream, sc);   // scan everything
+            hipLaunchKernelGGL(onset_set_cand_kernel, dim3(1), dim3(1), 0, ctx->stream, sc, noise_samples, factor);
         }
         GJ_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(onset_scan_kernel, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(kScanThreads), 0,
+        hipLaunchKernelGGL(onset_scan_kernel, dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(kScanThreads), 0,
                            ctx->stream, d_iq, nsamples, window, sc);
         GJ_LAUNCH_CHECK(ctx);
     }
@@ -620,7 +700,8 @@ int launch_onset(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, int noise_samp
 
 // ---------------------------------------------------------------------------------------
 // Fused stream scan: ONE pass over the capture feeds K1 (chunk power), K3 (amplitude
-// statistics) and the K4 screening (128-sample block sums), instead of three passes.
+// statistics) and K4 (noise-span moments + 512-sample block sums for the screening), instead of
+// three passes.
 // One workgroup per 64 KiB tile; per 16-byte load (8 samples) a lane computes the byte moments
 // (v_dot4_u32_u8) that give both the chunk sums and the block sum of 4|z|^2, and the eight
 // amplitudes (v_dot2 on the packed (2I-255, 2Q-255) pair, v_sqrt_f32).
@@ -643,7 +724,8 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
                                                                    float* __restrict__ power,
                                                                    unsigned long long* __restrict__ acc, float thr,
                                                                    AmpTile* __restrict__ tiles,
-                                                                   unsigned* __restrict__ c128) {
+                                                                   unsigned* __restrict__ cblk, size_t noise_bytes,
+                                                                   OnsetScratch* __restrict__ sc) {
     __shared__ unsigned long long red_m[2][kScanThreads / 64];
     __shared__ double red_s[kScanThreads / 64];
     __shared__ long long red_f[kScanThreads / 64];
@@ -654,19 +736,20 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
     const size_t b1 = (b0 + kScanTile < use_end) ? b0 + kScanTile : use_end;
     const size_t nvec = (b1 - b0) >> 4;                            // full 16-byte vectors
     const uint4* v = reinterpret_cast<const uint4*>(iq + b0);
-    unsigned s2 = 0, s1 = 0;
+    unsigned s2 = 0, s1 = 0, n2 = 0, n1 = 0;
     double sum = 0.0;
     long long first = 0x7fffffffffffffffll;
+    const bool in_noise = b0 < noise_bytes;                        // tile touches the K4 noise span
     for (size_t i = tid; i < nvec; i += kScanThreads) {
         const uint4 q = v[i];
         unsigned v2 = 0, v1 = 0;
         acc_moments(q, v2, v1);
         s2 += v2;
         s1 += v1;
-        // block sum of 4|z|^2 over the 16 lanes that hold one 128-sample block
-        int c8 = (int)(4u * v2 - 1020u * v1 + 16u * 65025u);
-        c8 = group_sum_dpp<16>(c8);
-        if ((tid & 15) == 0) c128[(b0 >> 8) + (i >> 4)] = (unsigned)c8;
+        if (in_noise && b0 + (i << 4) < noise_bytes) { n2 += v2; n1 += v1; }   // noise_bytes % 16 == 0
+        // block sum of 4|z|^2 over the wave = one 512-sample block (wave-uniform after the reduction)
+        const int c512 = group_sum_dpp<64>((int)(4u * v2 - 1020u * v1 + 16u * 65025u));
+        if ((tid & 63) == 0) cblk[(b0 >> 10) + (i >> 6)] = (unsigned)c512;
         const unsigned ws[4] = {q.x, q.y, q.z, q.w};
         float part = 0.f;
 #pragma unroll
@@ -696,16 +779,22 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
         }
         (void)c;
     }
-    // a stream that ends inside a 128-sample block: the lanes above wrote the sum of its full
-    // vectors only; one lane recomputes the whole block after the workgroup's stores have landed
-    if (b1 == use_end && (b1 & 255) != 0) {
+    // a stream that ends inside a 512-sample block: the waves above wrote the sum of its full
+    // vectors only (inactive lanes add 0); one wave recomputes the whole block after the
+    // workgroup's stores have landed
+    if (b1 == use_end && (b1 & 1023) != 0) {
         __syncthreads();
-        if (tid == 0) {
-            const size_t jb = (b1 - 1) >> 8;
-            unsigned c = 0;
-            for (size_t n = jb * 128; n < nsamples; ++n) c += m_of(iq[2 * n], iq[2 * n + 1]);
-            c128[jb] = c;
+        if (tid < 64) {
+            const size_t jb = (b1 - 1) >> 10;
+            int c = 0;
+            for (size_t n = jb * 512 + tid; n < nsamples; n += 64) c += (int)m_of(iq[2 * n], iq[2 * n + 1]);
+            c = group_sum_dpp<64>(c);
+            if (tid == 0) cblk[jb] = (unsigned)c;
         }
+    }
+    if (in_noise) {
+        const unsigned long long w2 = wave_sum_u64(n2), w1 = wave_sum_u64(n1);
+        if ((tid & 63) == 0) { atomicAdd(&sc->noise_m2, w2); atomicAdd(&sc->noise_m1, w1); }
     }
     if constexpr (!TRACK_FIRST) {
         if (tid == 0 && b1 > b0) first = (long long)(b0 >> 1);   // threshold below the smallest amplitude
@@ -741,17 +830,6 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
     }
 }
 
-__global__ void chunk_power_edge_kernel(size_t nchunks, size_t nbytes, size_t chunk_bytes, int flags,
-                                        float* __restrict__ power) {
-    // chunks the tile kernel never touches (a last chunk of 1 byte) or that follow the zero rule
-    const size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (c >= nchunks) return;
-    const size_t off = c * chunk_bytes;
-    const size_t len = (nbytes - off < chunk_bytes) ? nbytes - off : chunk_bytes;
-    if ((flags & GJ_CP_ODD_CHUNK_ZERO) && ((len & 1) || len == 0)) power[c] = 0.0f;
-    else if ((len >> 1) == 0) power[c] = __builtin_nanf("");
-}
-
 int launch_stream_scan(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
                        float* d_power, float rssi_threshold, gj_amp_stats* d_amp, int noise_samples, int window,
                        float factor, gj_onset* d_onset) {
@@ -769,49 +847,56 @@ int launch_stream_scan(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t c
     const size_t ntiles = (2 * nsamples + kScanTile - 1) / kScanTile;
     const size_t nchunks = gj_chunk_count(nbytes, chunk_bytes);
     const size_t tpc = chunk_bytes / kScanTile;
-    const size_t n128 = (nsamples + 127) / 128;
+    const size_t nblk = (nsamples + 511) / 512;
     if (ntiles > 0x7fffffffull) return fail(ctx, GJ_ERR_UNSUPPORTED, "capture too long");
-    // workspace: [OnsetScratch][AmpTile x ntiles][acc u64 x 2 x nchunks][c128 u32 x n128]
+    // workspace: [OnsetScratch][AmpTile x ntiles][acc u64 x 2 x nchunks][c512 u32 x nblk]
     const size_t off_tiles = 256;
     const size_t off_acc = off_tiles + align_up((ntiles + 1) * sizeof(AmpTile), 256);
-    const size_t off_c128 = off_acc + align_up(nchunks * 16, 256);
-    int rc = ensure_workspace(ctx, off_c128 + (n128 + 16) * sizeof(unsigned));
+    const size_t off_blk = off_acc + align_up(nchunks * 16, 256);
+    int rc = ensure_workspace(ctx, off_blk + (nblk + 16) * sizeof(unsigned));
     if (rc) return rc;
     OnsetScratch* sc = reinterpret_cast<OnsetScratch*>(ctx->ws);
     AmpTile* tiles = reinterpret_cast<AmpTile*>(ctx->ws + off_tiles);
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(ctx->ws + off_acc);
-    unsigned* c128 = reinterpret_cast<unsigned*>(ctx->ws + off_c128);
+    unsigned* cblk = reinterpret_cast<unsigned*>(ctx->ws + off_blk);
+    GJ_HIP(ctx, hipMemsetAsync(sc, 0, sizeof(OnsetScratch), ctx->stream));
     if (tpc > 1) GJ_HIP(ctx, hipMemsetAsync(acc, 0, nchunks * 16, ctx->stream));
+    const int valid = nsamples >= (size_t)noise_samples + (size_t)window;
+    // the K4 noise span rides along in the same pass when it ends on a 16-byte boundary
+    const size_t noise_bytes = (size_t)2 * noise_samples;
+    const bool noise_fused = valid && (noise_bytes % 16 == 0);
     // amplitudes are >= sqrt(2)/255 > 0.0055: a threshold below that makes every sample a hit
     const bool track = !(rssi_threshold < 0.005f);
     if (track)
         hipLaunchKernelGGL(stream_scan_kernel<true>, dim3((unsigned)ntiles), dim3(kScanThreads), 0, ctx->stream, d_iq,
-                           nsamples, nbytes, chunk_bytes, (unsigned)tpc, eps, flags, d_power, acc, rssi_threshold, tiles, c128);
+                           nsamples, nbytes, chunk_bytes, (unsigned)tpc, eps, flags, d_power, acc, rssi_threshold, tiles,
+                           cblk, noise_fused ? noise_bytes : (size_t)0, sc);
     else
         hipLaunchKernelGGL(stream_scan_kernel<false>, dim3((unsigned)ntiles), dim3(kScanThreads), 0, ctx->stream, d_iq,
-                           nsamples, nbytes, chunk_bytes, (unsigned)tpc, eps, flags, d_power, acc, rssi_threshold, tiles, c128);
+                           nsamples, nbytes, chunk_bytes, (unsigned)tpc, eps, flags, d_power, acc, rssi_threshold, tiles,
+                           cblk, noise_fused ? noise_bytes : (size_t)0, sc);
     GJ_LAUNCH_CHECK(ctx);
     if (tpc > 1) {
         hipLaunchKernelGGL(chunk_power_finalize_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0,
                            ctx->stream, acc, nchunks, nbytes, chunk_bytes, eps, flags, d_power);
         GJ_LAUNCH_CHECK(ctx);
     }
-    hipLaunchKernelGGL(chunk_power_edge_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, ctx->stream,
-                       nchunks, nbytes, chunk_bytes, flags, d_power);
+    // amplitude totals + the chunk-power edge cases (last chunk odd / without a complete pair)
+    hipLaunchKernelGGL(amp_finalize_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_iq, nsamples, tiles, ntiles, d_amp,
+                       d_power, nchunks, nbytes, chunk_bytes, flags);
     GJ_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(amp_finalize_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_iq, nsamples, tiles, ntiles, d_amp);
-    GJ_LAUNCH_CHECK(ctx);
-    const int valid = nsamples >= (size_t)noise_samples + (size_t)window;
     if (valid) {
-        hipLaunchKernelGGL(onset_noise_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_iq, noise_samples, factor, sc);
-        GJ_LAUNCH_CHECK(ctx);
+        if (!noise_fused) {
+            hipLaunchKernelGGL(onset_noise_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_iq, noise_samples, sc);
+            GJ_LAUNCH_CHECK(ctx);
+        }
         const size_t nout = nsamples - window + 1;
-        const size_t nct = ((nout + 127) / 128 + kCoarseBlocks - 1) / kCoarseBlocks;
-        hipLaunchKernelGGL(onset_coarse_kernel<128>, dim3((unsigned)nct), dim3(kScanThreads), 0, ctx->stream, d_iq,
-                           (const unsigned*)c128, nsamples, window, sc);
+        const size_t nct = ((nout + 511) / 512 + kCoarseBlocks - 1) / kCoarseBlocks;
+        hipLaunchKernelGGL(onset_coarse_kernel<512>, dim3((unsigned)nct), dim3(kScanThreads), 0, ctx->stream, d_iq,
+                           (const unsigned*)cblk, nsamples, window, noise_samples, factor, sc);
         GJ_LAUNCH_CHECK(ctx);
         const size_t nt = (nout + kOnsetOut - 1) / kOnsetOut;
-        hipLaunchKernelGGL(onset_scan_kernel, dim3((unsigned)(nt < 512 ? nt : 512)), dim3(kScanThreads), 0, ctx->stream,
+        hipLaunchKernelGGL(onset_scan_kernel, dim3((unsigned)(nt < 256 ? nt : 256)), dim3(kScanThreads), 0, ctx->stream,
                            d_iq, nsamples, window, sc);
         GJ_LAUNCH_CHECK(ctx);
     }
