@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--capture-bytes", type=int, default=CAPTURE_BYTES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (with --backend gloo) on a one-GPU box")
     ap.add_argument("--cpu-sample-chunks", type=int, default=24,
                     help="1-s chunks of the capture given to the CPU oracle (bounded sample)")
     args = ap.parse_args()
@@ -64,10 +67,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     dev = gpsjam.Device(local_rank)
     # one explicit HIP stream for everything in the step: the gpsjam kernels, torch's small

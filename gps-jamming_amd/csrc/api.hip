@@ -304,6 +304,16 @@ int gj_xcorr_lags_dev(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nby
     return launch_xcorr(ctx, d_iq, nbytes, n_ant, d_starts, n_samples, pairs, n_pairs, d_lags, d_peaks);
 }
 
+int gj_pack_result_dev(gj_ctx* ctx, size_t n_chunks, const float* d_power, const float* d_stats, const gj_amp_stats* d_amp,
+                       const gj_onset* d_onset, const int32_t* d_lag, const float* d_peak, const float* d_psd,
+                       size_t rows, int nperseg, int rank, double* d_out) {
+    GJ_ENTER(ctx);
+    if (!d_power || !d_stats || !d_amp || !d_onset || !d_lag || !d_peak || !d_out || (rows && !d_psd))
+        return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    return launch_pack_result(ctx, n_chunks, d_power, d_stats, d_amp, d_onset, d_lag, d_peak, d_psd, rows, nperseg, rank,
+                              d_out);
+}
+
 int gj_synth_u8_dev(gj_ctx* ctx, const gj_synth_params* params, int64_t first_sample, size_t n_samples, uint8_t* d_out) {
     GJ_ENTER(ctx);
     if (!params || (n_samples && !d_out)) return fail(ctx, GJ_ERR_INVALID, "null buffer");

@@ -137,4 +137,6 @@ int launch_xcorr(gj_ctx*, const uint8_t* const*, const size_t*, int, const int64
                  const int32_t*, int, int32_t*, float*);
 size_t xcorr_workspace(gj_ctx*, int, size_t, int);
 int launch_synth(gj_ctx*, const gj_synth_params&, int64_t, size_t, uint8_t*);
+int launch_pack_result(gj_ctx*, size_t, const float*, const float*, const gj_amp_stats*, const gj_onset*, const int32_t*,
+                       const float*, const float*, size_t, int, int, double*);
 }   // namespace gj

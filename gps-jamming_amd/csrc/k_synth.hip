@@ -62,6 +62,60 @@ __global__ __launch_bounds__(256) void synth_kernel(gj_synth_params p, long long
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// result vector of one stream (see gj_pack_result_dev in gpsjam.h)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_result_kernel(size_t n_chunks, const float* __restrict__ power,
+                                                          const float* __restrict__ stats,
+                                                          const gj_amp_stats* __restrict__ amp,
+                                                          const gj_onset* __restrict__ onset, const int* __restrict__ lag,
+                                                          const float* __restrict__ peak, const float* __restrict__ psd,
+                                                          size_t rows, int nperseg, int rank, double* __restrict__ out) {
+    const size_t total = GJ_RESULT_HEADER + n_chunks + (size_t)nperseg;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        double v = 0.0;
+        if (i < GJ_RESULT_HEADER) {
+            switch (i) {
+                case 0: v = (double)n_chunks; break;
+                case 1: v = stats[0]; break;
+                case 2: v = stats[1]; break;
+                case 3: v = stats[2]; break;
+                case 4: v = (double)amp->first_index; break;
+                case 5: v = (double)amp->count; break;
+                case 6: v = amp->mean; break;
+                case 7: v = (double)onset->start_index; break;
+                case 8: v = (double)lag[0]; break;
+                case 9: v = peak[0]; break;
+                case 10: v = onset->noise_power; break;
+                case 11: v = (double)rows; break;
+                case 12: v = (double)nperseg; break;
+                case 13: v = (double)rank; break;
+                default: v = 0.0;
+            }
+        } else if (i < GJ_RESULT_HEADER + n_chunks) {
+            v = power[i - GJ_RESULT_HEADER];
+        } else {
+            const size_t k = i - GJ_RESULT_HEADER - n_chunks;
+            float s = 0.f;
+            for (size_t r = 0; r < rows; ++r) s += psd[r * (size_t)nperseg + k];   // coalesced over k
+            v = rows ? s / (float)rows : 0.f;
+        }
+        out[i] = v;
+    }
+}
+
+int launch_pack_result(gj_ctx* ctx, size_t n_chunks, const float* d_power, const float* d_stats, const gj_amp_stats* d_amp,
+                       const gj_onset* d_onset, const int32_t* d_lag, const float* d_peak, const float* d_psd,
+                       size_t rows, int nperseg, int rank, double* d_out) {
+    const size_t total = GJ_RESULT_HEADER + n_chunks + (size_t)nperseg;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(pack_result_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n_chunks, d_power, d_stats,
+                       d_amp, d_onset, d_lag, d_peak, d_psd, rows, nperseg, rank, d_out);
+    GJ_LAUNCH_CHECK(ctx);
+    return GJ_OK;
+}
+
 int launch_synth(gj_ctx* ctx, const gj_synth_params& p, int64_t first_sample, size_t n_samples, uint8_t* d_out) {
     if (n_samples == 0) return GJ_OK;
     size_t blocks = ((n_samples + 7) / 8 + 255) / 256;

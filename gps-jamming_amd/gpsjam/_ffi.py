@@ -84,6 +84,7 @@ SIGNATURES = {
     "gj_xcorr_lags_u8": (_i, [_vp, C.POINTER(_vp), _i, _sz, C.POINTER(C.c_int32), _i,
                               C.POINTER(C.c_int32), _pf, _pf]),
     "gj_xcorr_workspace": (_sz, [_vp, _i, _sz, _i]),
+    "gj_pack_result_dev": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp]),
     "gj_synth_u8_dev": (_i, [_vp, C.POINTER(SynthParams), C.c_int64, _sz, _vp]),
 }
 

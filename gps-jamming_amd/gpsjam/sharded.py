@@ -146,6 +146,7 @@ class AntennaStream:
         self.peak = torch.zeros(1, dtype=torch.float32, device=d)
         self.ref_slice = torch.zeros(slice_samples, dtype=torch.int16, device=d)
         self._ar = torch.arange(slice_samples, dtype=torch.int64, device=d)
+        self.result = torch.zeros(result_len(self.n_chunks, nperseg), dtype=torch.float64, device=d)
         self.cap16 = capture.view(torch.int16)
         ws = max(dev.welch_workspace(self.nbytes, chunk_samples, nperseg),
                  dev.xcorr_workspace(2, slice_samples, 1), self.nbytes // 48 + (1 << 20))
@@ -176,23 +177,19 @@ class AntennaStream:
             broadcast_reference_slice(self.ref_slice, self.world, 0)
             # rank 0's onset travels in the slice's validity: an un-found onset (-1) on rank 0
             # makes idx start at the clamp and the lag meaningless; rank 0 reports it.
-            self.starts[0] = 0
-            self.starts[1] = self.onset[0]
+            self.starts[1:2].copy_(self.onset[0:1])          # starts[0] stays 0: the slice is already aligned
             self.dev.xcorr_lags_dev([self.ref_slice, self.cap], [2 * n, self.nbytes], self.starts, n,
                                     [(0, 1)], self.lag, self.peak)
         else:
-            self.starts[0] = self.onset[0]
-            self.starts[1] = self.onset[0]
+            self.starts.copy_(self.onset[0:1].expand(2))
             self.dev.xcorr_lags_dev([self.cap, self.cap], [self.nbytes, self.nbytes], self.starts, n,
                                     [(0, 1)], self.lag, self.peak)
 
     def pack(self) -> torch.Tensor:
-        amp_mean = self.amp[3:4].view(torch.float32)[0]
-        noise = self.onset[1:2].view(torch.float32)[0]
-        mean_spec = self.psd[:max(self.rows, 1)].mean(dim=0)
-        return pack_results(self.n_chunks, self.nperseg, self.power, self.stats, self.amp[0], self.amp[1],
-                            amp_mean, self.onset[0], self.lag[0], self.peak[0], noise, mean_spec, self.rows,
-                            self.rank)
+        """Result vector of this stream, built by one kernel (layout = pack_results)."""
+        self.dev.pack_result_dev(self.n_chunks, self.power, self.stats, self.amp, self.onset, self.lag, self.peak,
+                                 self.psd, self.rows, self.nperseg, self.rank, self.result)
+        return self.result
 
     def step(self):
         """One pass of the hot path over this rank's capture + the exchange."""

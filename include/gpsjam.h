@@ -182,6 +182,18 @@ int gj_xcorr_lags_u8(gj_ctx* ctx, const uint8_t* const* slices, int n_ant, size_
                      float* kernel_ms);
 size_t gj_xcorr_workspace(gj_ctx* ctx, int n_ant, size_t n_samples, int n_pairs);
 
+/* ------------------------------------------------- per-stream result vector ---------- */
+/* What one rank sends to rank 0 (gpsjam/sharded.py): double[16 + n_chunks + nperseg] =
+ * { n_chunks, baseline, threshold, n_above, amp.first_index, amp.count, amp.mean,
+ *   onset.start_index, lag, peak, onset.noise_power, rows, nperseg, rank, 0, 0 },
+ * the float32 power map, the mean over the rows of the PSD waterfall -- packed by one
+ * kernel from the device-resident outputs of the calls above (no host synchronisation). */
+#define GJ_RESULT_HEADER 16
+int gj_pack_result_dev(gj_ctx* ctx, size_t n_chunks, const float* d_power, const float* d_stats,
+                       const gj_amp_stats* d_amp, const gj_onset* d_onset, const int32_t* d_lag,
+                       const float* d_peak, const float* d_psd, size_t rows, int nperseg, int rank,
+                       double* d_out);
+
 /* ------------------------------------------------- synthetic captures --------------- */
 /* Bit-identical to gpsjam/synth.py (integer-only counter-based generator that mirrors
  * the value distribution of simulate/frontend/weaken_gps.py + add_jammer_and_mix.py). */

@@ -1,0 +1,51 @@
+"""The per-GPU pipeline object used by bench.py (gpsjam.sharded.AntennaStream) on one GPU:
+device-side result packing against the torch reference packer, and the unpacked results
+against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_antenna_stream_single_gpu():
+    import torch
+    import gpsjam
+    from gpsjam import sharded
+    from gpsjam.synth import StreamSpec, generate
+    from oracle import gpsjam_oracle as orc
+
+    n = 700000
+    spec = StreamSpec(seed=21, antenna=0, delay=0, jam_start=300000, jam_end=1 << 40, jam_sigma=60.0)
+    raw = generate(spec, n)
+    dev = gpsjam.Device(0)
+    stream_handle = torch.cuda.Stream()
+    torch.cuda.set_stream(stream_handle)
+    dev.set_stream(stream_handle.cuda_stream)
+    cap = torch.from_numpy(raw).cuda()
+    st = sharded.AntennaStream(dev, cap, nperseg=1024, chunk_samples=200000, slice_samples=65536)
+    got = st.step()
+    torch.cuda.synchronize()
+    assert len(got) == 1
+    # the kernel-packed vector equals the torch-packed one
+    amp_mean = st.amp[3:4].view(torch.float32)[0]
+    noise = st.onset[1:2].view(torch.float32)[0]
+    ref = sharded.pack_results(st.n_chunks, st.nperseg, st.power, st.stats, st.amp[0], st.amp[1], amp_mean,
+                               st.onset[0], st.lag[0], st.peak[0], noise, st.psd[:st.rows].mean(dim=0), st.rows, 0)
+    np.testing.assert_allclose(got[0].cpu().numpy(), ref.cpu().numpy(), rtol=1e-6)
+    np.testing.assert_array_equal(got[0][:sharded.HEADER + st.n_chunks].cpu().numpy(),
+                                  ref[:sharded.HEADER + st.n_chunks].cpu().numpy())
+    res = sharded.unpack_results(got[0])
+    pm = orc.chunk_power(raw)
+    np.testing.assert_allclose(res.power_map, pm, rtol=1e-6)
+    base, thr, ranges = orc.power_threshold(pm)
+    assert res.baseline == np.float32(base) and res.jamming_byte_ranges() == [(int(a), int(b)) for a, b in ranges]
+    k, avg = orc.rssi_amp_stats(raw, 0.0)
+    assert res.amp_first == k and res.amp_count == n - k
+    np.testing.assert_allclose(res.amp_mean, avg, rtol=1e-6)
+    z = orc.tdoa_unpack(raw)
+    assert res.onset == orc.tdoa_onset(z)
+    assert res.lag == 0                                   # a capture against itself
+    lin, _, _ = orc.widmo_waterfall(raw, nperseg=1024, chunk_samples=200000)
+    np.testing.assert_allclose(res.mean_spectrum, lin.mean(axis=0), rtol=1e-4)
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    dev.close()
