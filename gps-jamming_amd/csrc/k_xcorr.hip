@@ -105,10 +105,14 @@ __global__ __launch_bounds__(kBlockThreads) void xc_cols_kernel(XcParams P, cons
     xc_passes<L1, 0>(v, lds, b * RS, jl, twtab);
     if constexpr (MODE == 0) {
         cf* dst = buf + (size_t)t * P.L;
+        // W_L^(k1 n2), k1 = jl + TF s: two sincospi and a geometric recurrence instead of sixteen
+        c2 w = twiddle_big((unsigned long long)jl * n2, P.L);
+        const c2 step = twiddle_big(((unsigned long long)TF * n2) & (P.L - 1), P.L);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int k1 = jl + TF * s;
-            dst[(size_t)k1 * kRow + n2] = to_cf(cmul(v[s], twiddle_big((unsigned long long)k1 * n2, P.L)));
+            dst[(size_t)k1 * kRow + n2] = to_cf(cmul(v[s], w));
+            w = cmul(w, step);
         }
     } else {
         float best = -1.f;
@@ -172,10 +176,13 @@ __global__ __launch_bounds__(kBlockThreads) void xc_rows_kernel(XcParams P, cons
         for (int s = 0; s < 16; ++s) dst[jl + TF * s] = to_cf(v[s]);
     } else {
         cf* dst = dbuf + (size_t)t * P.L + (size_t)r * N;
+        c2 w = twiddle_big((unsigned long long)r * jl, P.L);
+        const c2 step = twiddle_big(((unsigned long long)r * TF) & (P.L - 1), P.L);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int n2 = jl + TF * s;
-            dst[n2] = to_cf(cmul(v[s], twiddle_big((unsigned long long)r * n2, P.L)));
+            dst[n2] = to_cf(cmul(v[s], w));
+            w = cmul(w, step);
         }
     }
 }
