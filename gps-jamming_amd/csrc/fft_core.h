@@ -62,6 +62,29 @@ __device__ __forceinline__ c2 cmul_k(c2 a, c2 w) {
         : "v"(a), "s"(w), "v"(t));
     return r;
 }
+// c + a * w  (two packed FMAs: the twiddle multiply rides on the butterfly's first addition)
+__device__ __forceinline__ c2 cmul_add(c2 a, c2 w, c2 c) {
+    c2 t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "v"(w), "v"(c));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r)
+        : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+__device__ __forceinline__ c2 cmul_add_k(c2 a, c2 w, c2 c) {   // w wave-uniform, in SGPRs
+    c2 t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "s"(w), "v"(c));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r)
+        : "v"(a), "s"(w), "v"(t));
+    return r;
+}
+// 2 u - t   (the "other" butterfly output when t = u + w x is already known)
+__device__ __forceinline__ c2 twice_minus(c2 u, c2 t) {
+    c2 r;
+    asm("v_pk_fma_f32 %0, %1, 2.0, %2 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(u), "v"(t));
+    return r;
+}
 // a + (-j) b = (a.x + b.y, a.y - b.x)      a + (+j) b = (a.x - b.y, a.y + b.x)
 __device__ __forceinline__ c2 add_mj(c2 a, c2 b) {
     c2 r;
@@ -112,6 +135,9 @@ GJ_HD cf to_cf(c2 a) { return a; }
 GJ_HD c2 make_c2(float x, float y) { return c2{x, y}; }
 GJ_HD c2 cmul(c2 a, c2 b) { return c2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 GJ_HD c2 cmul_k(c2 a, c2 b) { return cmul(a, b); }
+GJ_HD c2 cmul_add(c2 a, c2 w, c2 c) { return c2{c.x + a.x * w.x - a.y * w.y, c.y + a.x * w.y + a.y * w.x}; }
+GJ_HD c2 cmul_add_k(c2 a, c2 w, c2 c) { return cmul_add(a, w, c); }
+GJ_HD c2 twice_minus(c2 u, c2 t) { return c2{2.0f * u.x - t.x, 2.0f * u.y - t.y}; }
 GJ_HD c2 cadd(c2 a, c2 b) { return c2{a.x + b.x, a.y + b.y}; }
 GJ_HD c2 csub(c2 a, c2 b) { return c2{a.x - b.x, a.y - b.y}; }
 GJ_HD c2 add_mj(c2 a, c2 b) { return c2{a.x + b.y, a.y - b.x}; }
@@ -233,6 +259,90 @@ GJ_HD void dft<16>(c2 (&a)[16], const InnerTw& k) {
     for (int i = 0; i < 16; ++i) a[i] = r[i];
 }
 
+// ---- FMA-form radix-4 butterflies: X = DFT4(x0, w1 x1, w2 x2, w3 x3) in 12 packed ops instead
+// of 3 complex multiplies + 8 additions = 14 (t0 = x0 + w2 x2 as two FMAs, t1 = 2 x0 - t0, ...).
+GJ_HD void bfly4_tw(c2& x0, c2& x1, c2& x2, c2& x3, c2 w1, c2 w2, c2 w3) {
+    const c2 t0 = cmul_add(x2, w2, x0);
+    const c2 t1 = twice_minus(x0, t0);
+    const c2 u1 = cmul(x1, w1);
+    const c2 t2 = cmul_add(x3, w3, u1);
+    const c2 t3 = twice_minus(u1, t2);
+    x0 = cadd(t0, t2);
+    x2 = csub(t0, t2);
+    x1 = add_mj(t1, t3);
+    x3 = add_pj(t1, t3);
+}
+GJ_HD void bfly4_tw_k(c2& x0, c2& x1, c2& x2, c2& x3, c2 w1, c2 w2, c2 w3) {   // constant (SGPR) twiddles
+    const c2 t0 = cmul_add_k(x2, w2, x0);
+    const c2 t1 = twice_minus(x0, t0);
+    const c2 u1 = cmul_k(x1, w1);
+    const c2 t2 = cmul_add_k(x3, w3, u1);
+    const c2 t3 = twice_minus(u1, t2);
+    x0 = cadd(t0, t2);
+    x2 = csub(t0, t2);
+    x1 = add_mj(t1, t3);
+    x3 = add_pj(t1, t3);
+}
+// all four inputs twiddled: 14 packed ops instead of 16
+GJ_HD void bfly4_tw4(c2& x0, c2& x1, c2& x2, c2& x3, c2 w0, c2 w1, c2 w2, c2 w3) {
+    const c2 u0 = cmul(x0, w0);
+    const c2 t0 = cmul_add(x2, w2, u0);
+    const c2 t1 = twice_minus(u0, t0);
+    const c2 u1 = cmul(x1, w1);
+    const c2 t2 = cmul_add(x3, w3, u1);
+    const c2 t3 = twice_minus(u1, t2);
+    x0 = cadd(t0, t2);
+    x2 = csub(t0, t2);
+    x1 = add_mj(t1, t3);
+    x3 = add_pj(t1, t3);
+}
+
+// second radix-4 layer of the 16-point butterfly (constant twiddles W16^(n1 k2)), FMA form;
+// input A[n1][k2] in a[n1 + 4 k2], output natural order
+GJ_HD void dft16_layer2(c2 (&a)[16], const InnerTw& k) {
+    dft4(a[0], a[1], a[2], a[3]);                                    // k2 = 0: no twiddles
+    bfly4_tw_k(a[4], a[5], a[6], a[7], k.w16_1, k.w16_2, k.w16_3);   // k2 = 1
+    {                                                                // k2 = 2: W16^2, -j, W16^6
+        c2 &y0 = a[8], &y1 = a[9], &y2 = a[10], &y3 = a[11];
+        const c2 t0 = add_mj(y0, y2), t1 = add_pj(y0, y2);           // y0 -+ j y2
+        const c2 u1 = cmul_k(y1, k.w16_2);
+        const c2 t2 = cmul_add_k(y3, k.w16_6, u1);
+        const c2 t3 = twice_minus(u1, t2);
+        y0 = cadd(t0, t2);
+        y2 = csub(t0, t2);
+        y1 = add_mj(t1, t3);
+        y3 = add_pj(t1, t3);
+    }
+    bfly4_tw_k(a[12], a[13], a[14], a[15], k.w16_3, k.w16_6, k.w16_9);   // k2 = 3
+    c2 r[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+        r[k2] = a[4 * k2];            // X[4 k1 + k2] = k1-th output of group k2
+        r[4 + k2] = a[4 * k2 + 1];
+        r[8 + k2] = a[4 * k2 + 2];
+        r[12 + k2] = a[4 * k2 + 3];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = r[i];
+}
+
+// 16-point butterfly of the first pass (no input twiddles), FMA form
+GJ_HD void dft16_fma(c2 (&a)[16], const InnerTw& k) {
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) dft4(a[n1], a[n1 + 4], a[n1 + 8], a[n1 + 12]);
+    dft16_layer2(a, k);
+}
+
+// 16-point butterfly with input twiddles tw[t-1] = W^(t k), t = 1..15, FMA form:
+// 54 + 47 packed ops instead of 30 + 64 + 17
+GJ_HD void dft16_fma_tw(c2 (&a)[16], const c2* tw, const InnerTw& k) {
+    bfly4_tw(a[0], a[4], a[8], a[12], tw[3], tw[7], tw[11]);
+#pragma unroll
+    for (int n1 = 1; n1 < 4; ++n1)
+        bfly4_tw4(a[n1], a[n1 + 4], a[n1 + 8], a[n1 + 12], tw[n1 - 1], tw[n1 + 3], tw[n1 + 7], tw[n1 + 11]);
+    dft16_layer2(a, k);
+}
+
 // Radix-16 butterfly with its input twiddles W^(t k), t = n1 + 4 n2, applied in two steps:
 // W^(4 n2 k) before the first radix-4 stage and W^(n1 k) after it (constant over the sum on
 // n2).  Six twiddle values (12 VGPRs) instead of fifteen (30) per pass for nine more complex
@@ -288,12 +398,19 @@ constexpr int lds_span(int n) { return n + n / 16; }   // slots one N-point tran
 // next pass' input (or IS X[jl + (N/16)(u + t*(16/R))] after the last pass).
 // tw[u*(R-1) + t-1] = W_(Ns R)^(t * ((jl + (N/16) u) mod Ns)), unused when PASS == 0.
 // TWO_STEP (radix-16 passes after the first only): tw holds the six values of dft16_twiddled.
-template <int N, int PASS, bool TWO_STEP = false>
+// FMA_FORM (radix-16 passes): the FMA-form butterflies above (same twiddle registers as the
+// default form).
+template <int N, int PASS, bool TWO_STEP = false, bool FMA_FORM = false>
 GJ_HD void fft_pass(c2 (&v)[16], const c2* tw, const InnerTw& k) {
     constexpr int R = fft_radix(N, PASS);
     constexpr int G = 16 / R;   // butterflies per thread
     if constexpr (TWO_STEP && PASS > 0 && R == 16) {
         dft16_twiddled(v, tw, k);
+        return;
+    }
+    if constexpr (FMA_FORM && R == 16) {
+        if constexpr (PASS > 0) dft16_fma_tw(v, tw, k);
+        else dft16_fma(v, k);
         return;
     }
 #pragma unroll

@@ -65,14 +65,35 @@ __global__ __launch_bounds__(256) void synth_kernel(gj_synth_params p, long long
 // ---------------------------------------------------------------------------------------
 // result vector of one stream (see gj_pack_result_dev in gpsjam.h)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_result_kernel(size_t n_chunks, const float* __restrict__ power,
-                                                          const float* __restrict__ stats,
-                                                          const gj_amp_stats* __restrict__ amp,
-                                                          const gj_onset* __restrict__ onset, const int* __restrict__ lag,
-                                                          const float* __restrict__ peak, const float* __restrict__ psd,
-                                                          size_t rows, int nperseg, int rank, double* __restrict__ out) {
-    const size_t total = GJ_RESULT_HEADER + n_chunks + (size_t)nperseg;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+// block = 64 bins x 16 row lanes; blocks [0, nperseg/64) reduce the waterfall to its mean
+// spectrum, the following blocks copy the header and the power map
+__global__ __launch_bounds__(1024) void pack_result_kernel(size_t n_chunks, const float* __restrict__ power,
+                                                           const float* __restrict__ stats,
+                                                           const gj_amp_stats* __restrict__ amp,
+                                                           const gj_onset* __restrict__ onset, const int* __restrict__ lag,
+                                                           const float* __restrict__ peak, const float* __restrict__ psd,
+                                                           size_t rows, int nperseg, int rank, double* __restrict__ out) {
+    __shared__ float part[16][64];
+    const unsigned spec_blocks = (unsigned)((nperseg + 63) / 64);
+    if (blockIdx.x < spec_blocks) {
+        const int kx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+        const int k = blockIdx.x * 64 + kx;
+        float s = 0.f;
+        if (k < nperseg)
+            for (size_t r = ry; r < rows; r += 16) s += psd[r * (size_t)nperseg + k];
+        part[ry][kx] = s;
+        __syncthreads();
+        if (ry == 0 && k < nperseg) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t += part[j][kx];
+            out[GJ_RESULT_HEADER + n_chunks + k] = rows ? (double)(t / (float)rows) : 0.0;
+        }
+        return;
+    }
+    const size_t total = GJ_RESULT_HEADER + n_chunks;
+    for (size_t i = (blockIdx.x - spec_blocks) * (size_t)blockDim.x + threadIdx.x; i < total;
+         i += (size_t)(gridDim.x - spec_blocks) * blockDim.x) {
         double v = 0.0;
         if (i < GJ_RESULT_HEADER) {
             switch (i) {
@@ -92,13 +113,8 @@ __global__ __launch_bounds__(256) void pack_result_kernel(size_t n_chunks, const
                 case 13: v = (double)rank; break;
                 default: v = 0.0;
             }
-        } else if (i < GJ_RESULT_HEADER + n_chunks) {
-            v = power[i - GJ_RESULT_HEADER];
         } else {
-            const size_t k = i - GJ_RESULT_HEADER - n_chunks;
-            float s = 0.f;
-            for (size_t r = 0; r < rows; ++r) s += psd[r * (size_t)nperseg + k];   // coalesced over k
-            v = rows ? s / (float)rows : 0.f;
+            v = power[i - GJ_RESULT_HEADER];
         }
         out[i] = v;
     }
@@ -107,11 +123,11 @@ __global__ __launch_bounds__(256) void pack_result_kernel(size_t n_chunks, const
 int launch_pack_result(gj_ctx* ctx, size_t n_chunks, const float* d_power, const float* d_stats, const gj_amp_stats* d_amp,
                        const gj_onset* d_onset, const int32_t* d_lag, const float* d_peak, const float* d_psd,
                        size_t rows, int nperseg, int rank, double* d_out) {
-    const size_t total = GJ_RESULT_HEADER + n_chunks + (size_t)nperseg;
-    size_t blocks = (total + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(pack_result_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, n_chunks, d_power, d_stats,
-                       d_amp, d_onset, d_lag, d_peak, d_psd, rows, nperseg, rank, d_out);
+    const unsigned spec_blocks = (unsigned)((nperseg + 63) / 64);
+    size_t copy_blocks = (GJ_RESULT_HEADER + n_chunks + 1023) / 1024;
+    if (copy_blocks > 256) copy_blocks = 256;
+    hipLaunchKernelGGL(pack_result_kernel, dim3(spec_blocks + (unsigned)copy_blocks), dim3(1024), 0, ctx->stream, n_chunks,
+                       d_power, d_stats, d_amp, d_onset, d_lag, d_peak, d_psd, rows, nperseg, rank, d_out);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
 }

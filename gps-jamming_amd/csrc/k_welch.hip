@@ -27,6 +27,9 @@
 #ifndef GJ_W_PREFETCH
 #define GJ_W_PREFETCH 1  // 1: next step's raw samples are loaded while the current one is transformed
 #endif
+#ifndef GJ_W_FMA
+#define GJ_W_FMA 1       // 1: FMA-form radix-4 butterflies (fft_core.h dft16_fma*): ~9 % fewer packed ops
+#endif
 #ifndef GJ_W_PKACC
 #define GJ_W_PKACC 1     // 1: |X|^2 accumulated as (re^2, im^2) pairs with one v_pk_fma_f32 per bin
 #endif
@@ -78,7 +81,7 @@ __device__ __forceinline__ void welch_passes(c2 (&v)[16], cf* lds0, cf* lds1, un
                                              unsigned long long (&stamps)[8]) {
     constexpr int NP = fft_npass(N);
     GJ_STAMP(t0);
-    fft_pass<N, PASS, GJ_W_TWOSTEP != 0>(v, tw[PASS], ktw);
+    fft_pass<N, PASS, GJ_W_TWOSTEP != 0, GJ_W_FMA != 0>(v, tw[PASS], ktw);
     GJ_STAMP(t1);
     GJ_STAMP_ADD(0, t0, t1);   // butterflies
     if constexpr (PASS + 1 < NP) {
@@ -288,12 +291,22 @@ static bool welch_plan(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int npe
         last_len = rem < chunk_samples ? rem : chunk_samples;
     }
     pl.g.nseg_last = (unsigned)((last_len - nperseg) / step + 1);
-    // enough workgroups to fill 256 CUs several times over, at least ~2 steps each
-    size_t want = pl.rows ? (size_t)(16 * ctx->num_cus + pl.rows - 1) / pl.rows : 1;
-    size_t cap = pl.g.nseg_full / (2 * (size_t)pl.batch);
+    // Workgroups per chunk: 2 workgroups are resident per CU (VGPR-limited), the grid runs in
+    // ceil(workgroups / slots) rounds of about (steps per workgroup + start-up) each, and a
+    // nearly empty last round is pure loss -- pick the split that minimises rounds x length.
+    const size_t slots = (size_t)ctx->num_cus * 2;
+    size_t cap = pl.g.nseg_full / (2 * (size_t)pl.batch);   // at least ~2 steps per workgroup
     if (cap < 1) cap = 1;
-    if (want > cap) want = cap;
-    if (want < 1) want = 1;
+    if (cap > 256) cap = 256;
+    size_t want = 1;
+    double best = 1e300;
+    for (size_t sp = 1; sp <= cap; ++sp) {
+        const size_t wgs = (pl.rows ? pl.rows : 1) * sp;
+        const double rounds = (double)((wgs + slots - 1) / slots);
+        const double steps = (double)pl.g.nseg_full / (double)(sp * pl.batch) + 1.5;   // 1.5: twiddle/window set-up
+        const double cost = rounds * steps;
+        if (cost < best * 0.999) { best = cost; want = sp; }
+    }
     pl.g.splits = (unsigned)want;
     pl.ws_bytes = pl.rows * want * (size_t)kBlockPoints * sizeof(float);
     const double sw2 = 0.375 * nperseg;   // sum of the squared periodic Hann window

@@ -13,7 +13,7 @@ using namespace gj;
 
 static std::vector<cf> g_table;
 
-template <int N, int PASS, bool TWO = false>
+template <int N, int PASS, bool TWO = false, bool FMA = false>
 static void run_passes(std::vector<cf (*)[16]>& regs, std::vector<cf>& lds) {
     constexpr int TF = N / 16, NP = fft_npass(N);
     for (int j = 0; j < kBlockThreads; ++j) {
@@ -23,7 +23,7 @@ static void run_passes(std::vector<cf (*)[16]>& regs, std::vector<cf>& lds) {
         constexpr bool two = TWO && PASS > 0 && fft_radix(N, PASS) == 16;
         if constexpr (two) load_twiddles6<N, PASS>(tw, g_table.data(), jl);
         else if constexpr (PASS > 0) load_twiddles<N, PASS>(tw, g_table.data(), jl);
-        fft_pass<N, PASS, TWO>(*regs[j], tw, inner_twiddles());
+        fft_pass<N, PASS, TWO, FMA>(*regs[j], tw, inner_twiddles());
         if constexpr (PASS + 1 < NP) lds_scatter<N, PASS>(*regs[j], lds.data(), b * lds_span(N), jl);
     }
     if constexpr (PASS + 1 < NP) {
@@ -31,11 +31,11 @@ static void run_passes(std::vector<cf (*)[16]>& regs, std::vector<cf>& lds) {
             const int b = j / TF, jl = j % TF;
             lds_gather<N>(*regs[j], lds.data(), b * lds_span(N), jl);
         }
-        run_passes<N, PASS + 1, TWO>(regs, lds);
+        run_passes<N, PASS + 1, TWO, FMA>(regs, lds);
     }
 }
 
-template <int N, bool TWO = false>
+template <int N, bool TWO = false, bool FMA = false>
 static double check() {
     constexpr int TF = N / 16, B = kBlockPoints / N;
     std::vector<cf> in(kBlockPoints), lds(kBlockPoints + kBlockPoints / 16 + 64);
@@ -47,7 +47,7 @@ static double check() {
         const int b = j / TF, jl = j % TF;
         for (int s = 0; s < 16; ++s) (*regs[j])[s] = in[b * N + jl + TF * s];
     }
-    run_passes<N, 0, TWO>(regs, lds);
+    run_passes<N, 0, TWO, FMA>(regs, lds);
     double worst = 0.0;
     for (int b = 0; b < B; ++b) {
         double norm = 0.0;
@@ -92,6 +92,11 @@ int main() {
     {
         const double e1 = check<4096, true>(), e2 = check<1024, true>(), e3 = check<256, true>();
         printf("two-step twiddles: N=4096 %.3e  N=1024 %.3e  N=256 %.3e\n", e1, e2, e3);
+        if (!(e1 < 2e-6 && e2 < 2e-6 && e3 < 2e-6)) ++bad;
+    }
+    {
+        const double e1 = check<4096, false, true>(), e2 = check<1024, false, true>(), e3 = check<16, false, true>();
+        printf("FMA-form butterflies: N=4096 %.3e  N=1024 %.3e  N=16 %.3e\n", e1, e2, e3);
         if (!(e1 < 2e-6 && e2 < 2e-6 && e3 < 2e-6)) ++bad;
     }
     CHECK(16) CHECK(32) CHECK(64) CHECK(128) CHECK(256) CHECK(512) CHECK(1024) CHECK(2048) CHECK(4096)
