@@ -740,8 +740,7 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
     double sum = 0.0;
     long long first = 0x7fffffffffffffffll;
     const bool in_noise = b0 < noise_bytes;                        // tile touches the K4 noise span
-    for (size_t i = tid; i < nvec; i += kScanThreads) {
-        const uint4 q = v[i];
+    auto body = [&](const uint4& q, size_t i) {
         unsigned v2 = 0, v1 = 0;
         acc_moments(q, v2, v1);
         s2 += v2;
@@ -764,7 +763,17 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
             }
         }
         sum += (double)part;
+    };
+    size_t i = tid;
+    // four 16-byte loads in flight per lane before the arithmetic starts
+    for (; i + 3 * kScanThreads < nvec; i += 4 * kScanThreads) {
+        const uint4 q0 = v[i], q1 = v[i + kScanThreads], q2 = v[i + 2 * kScanThreads], q3 = v[i + 3 * kScanThreads];
+        body(q0, i);
+        body(q1, i + kScanThreads);
+        body(q2, i + 2 * kScanThreads);
+        body(q3, i + 3 * kScanThreads);
     }
+    for (; i < nvec; i += kScanThreads) body(v[i], i);
     // ragged end of the stream (< 8 samples): one lane, scalar
     if (tid == 0 && (b0 + (nvec << 4)) < b1) {
         unsigned c = 0;
