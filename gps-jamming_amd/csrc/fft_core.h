@@ -388,7 +388,8 @@ GJ_HD void dft16_twiddled(c2 (&a)[16], const c2* tw6, const InnerTw& k) {
 // touches in one exchange is then "thread base + compile-time constant", so the 16 scatter
 // and 16 gather addresses fold into the DS instructions' immediate offsets instead of
 // occupying 64 loop-invariant VGPRs.  Writes are conflict free, reads 2-way
-// (tools/lds_bank_sim.py).
+// (tools/lds_bank_sim.py); N = 4096 in the Welch kernel uses the X4096 schedule below, which
+// is conflict free on both sides.
 GJ_HD int lds_slot(int base, int i) { return base + i + (i >> 4); }
 constexpr int lds_span(int n) { return n + n / 16; }   // slots one N-point transform occupies
 
@@ -481,6 +482,61 @@ template <int N>
 GJ_HD void lds_gather(c2 (&v)[16], const cf* lds, int base, int jl) {
 #pragma unroll
     for (int s = 0; s < 16; ++s) v[s] = to_c2(lds[lds_slot(base, jl + (N / 16) * s)]);
+}
+
+// ---------------------------------------------------------------------------------------
+// Conflict-free exchange schedule for N = 4096 (256 threads, three radix-16 passes)
+// ---------------------------------------------------------------------------------------
+// With the identity thread->butterfly map no additive layout is conflict free for both the
+// 16-lane write groups and the 32-lane read groups (tools/lds_bank_sim.py).  It becomes
+// possible when the thread changes role at the first exchange: thread `tid` computes
+// butterfly jl0 = tid in pass 0 (so the global loads stay coalesced) and butterfly
+// jl1 = 16 (tid & 15) + (tid >> 4) in passes 1 and 2, with one layout per exchange:
+//   exchange 0: slot(256 S + 16 M + T) = 286 S + 17 M + c0(T),  c0(T) = (T & ~1) + 16 (T & 1)
+//   exchange 1: slot(256 S + 16 M + T) = 287 S + 18 M + T
+// Every address is still "thread base + compile-time constant".  Bank arithmetic (8-byte
+// slots, 16 slots per write group, 32 per read group):
+//   exchange 0 write: 16 lanes = 16 M at one (S, T): 17 M covers every residue mod 16;
+//   exchange 0 read : 32 lanes = 16 M x T in {2h, 2h+1}: 17 M + {c0(2h), c0(2h) + 16} mod 32;
+//   exchange 1 write: 16 lanes = 16 S at one (M, T): 287 S is odd -> every residue mod 16;
+//   exchange 1 read : 32 lanes = 16 M x T in {2h, 2h+1}: 18 M covers the even residues mod 32.
+// tools/lds_bank_sim.py --xpose counts 1.0 cycles per group for all four; SQ_LDS_BANK_CONFLICT
+// reads 0 on MI355X (67 M per launch with the generic layout).
+// After the last pass thread tid holds X[jl1 + 256 s] in v[s].
+struct X4096 {
+    static constexpr int kSpan = 4592;   // slots per buffer (max of the two layouts)
+    static constexpr int c0(int t) { return (t & ~1) + 16 * (t & 1); }
+    GJ_HD static int jl1(int tid) { return 16 * (tid & 15) + (tid >> 4); }
+    GJ_HD static int slot0(int i) { return 286 * (i >> 8) + 17 * ((i >> 4) & 15) + c0(i & 15); }
+    GJ_HD static int slot1(int i) { return 287 * (i >> 8) + 18 * ((i >> 4) & 15) + (i & 15); }
+};
+
+// EX = 0: scatter the outputs of pass 0 (thread role jl0 = tid); EX = 1: of pass 1 (role jl1)
+template <int EX>
+GJ_HD void x4096_scatter(const c2 (&v)[16], cf* lds, int tid) {
+    if constexpr (EX == 0) {
+        const int base = 286 * (tid >> 4) + 17 * (tid & 15);        // slot0(16 tid + t) - c0(t)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) lds[base + X4096::c0(t)] = to_cf(v[t]);
+    } else {
+        const int base = 287 * (tid & 15) + (tid >> 4);             // slot1(256 (jl1 >> 4) + (jl1 & 15) + 16 t) - 18 t
+#pragma unroll
+        for (int t = 0; t < 16; ++t) lds[base + 18 * t] = to_cf(v[t]);
+    }
+}
+
+// gather in[jl1 + 256 s] for the next pass (role jl1 on both exchanges)
+template <int EX>
+GJ_HD void x4096_gather(c2 (&v)[16], const cf* lds, int tid) {
+    if constexpr (EX == 0) {
+        const int base = 17 * (tid & 15) + X4096::c0(tid >> 4);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) v[s] = to_c2(lds[base + 286 * s]);
+    } else {
+        const int base = 18 * (tid & 15) + (tid >> 4);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) v[s] = to_c2(lds[base + 287 * s]);
+    }
 }
 
 }   // namespace gj

@@ -36,6 +36,9 @@
 #ifndef GJ_W_DBUF
 #define GJ_W_DBUF 1      // 1: two LDS exchange buffers, one barrier per exchange; 0: one buffer, two barriers
 #endif
+#ifndef GJ_W_XPOSE
+#define GJ_W_XPOSE 1     // 1: N = 4096 uses the bank-conflict-free exchange schedule (fft_core.h X4096)
+#endif
 #define GJ_LOAD_RAW(x) (x)
 // GJ_STAMPS (diagnostic builds only, tools/ab_build.sh): s_memtime stamps around the phases of
 // a step, summed per wave and added to g_welch_stamps; read with gj_debug_welch_stamps().
@@ -102,6 +105,40 @@ __device__ __forceinline__ void welch_passes(c2 (&v)[16], cf* lds0, cf* lds1, un
     }
 }
 
+// N = 4096 with the conflict-free exchange schedule of fft_core.h (X4096): pass 0 in role
+// jl0 = tid, passes 1 and 2 in role jl1; buffer 0 carries exchange 0, buffer 1 exchange 1.
+__device__ __forceinline__ void welch_passes_x4096(c2 (&v)[16], cf* lds0, cf* lds1, int tid, const c2 (&tw)[3][15],
+                                                   const InnerTw& ktw, unsigned long long (&stamps)[8]) {
+    GJ_STAMP(t0);
+    fft_pass<4096, 0, false, GJ_W_FMA != 0>(v, tw[0], ktw);
+    GJ_STAMP(t1);
+    GJ_STAMP_ADD(0, t0, t1);
+    x4096_scatter<0>(v, lds0, tid);
+    GJ_STAMP(t2);
+    GJ_STAMP_ADD(1, t1, t2);
+    __syncthreads();
+    GJ_STAMP(t3);
+    GJ_STAMP_ADD(2, t2, t3);
+    x4096_gather<0>(v, lds0, tid);
+    GJ_STAMP(t4);
+    GJ_STAMP_ADD(3, t3, t4);
+    fft_pass<4096, 1, false, GJ_W_FMA != 0>(v, tw[1], ktw);
+    GJ_STAMP(t5);
+    GJ_STAMP_ADD(0, t4, t5);
+    x4096_scatter<1>(v, lds1, tid);
+    GJ_STAMP(t6);
+    GJ_STAMP_ADD(1, t5, t6);
+    __syncthreads();
+    GJ_STAMP(t7);
+    GJ_STAMP_ADD(2, t6, t7);
+    x4096_gather<1>(v, lds1, tid);
+    GJ_STAMP(t8);
+    GJ_STAMP_ADD(3, t7, t8);
+    fft_pass<4096, 2, false, GJ_W_FMA != 0>(v, tw[2], ktw);
+    GJ_STAMP(t9);
+    GJ_STAMP_ADD(0, t8, t9);
+}
+
 template <int N>
 __global__ __launch_bounds__(kBlockThreads, GJ_LB) void welch_kernel(const uint8_t* __restrict__ iq, WelchGeom g,
                                                               const cf* __restrict__ twtab,
@@ -109,11 +146,14 @@ __global__ __launch_bounds__(kBlockThreads, GJ_LB) void welch_kernel(const uint8
                                                               float* __restrict__ partial) {
     constexpr int TF = N / 16, B = kBlockPoints / N, NP = fft_npass(N);
     constexpr int WPF = (TF >= 64) ? TF / 64 : 1;   // waves per transform
-    __shared__ cf lds0[lds_span(kBlockPoints)];
-    __shared__ cf lds1[GJ_W_DBUF ? lds_span(kBlockPoints) : 1];
+    constexpr bool XP = (N == 4096) && GJ_W_XPOSE && GJ_W_DBUF && !GJ_W_TWOSTEP;
+    constexpr int SPAN = XP ? X4096::kSpan : lds_span(kBlockPoints);
+    __shared__ cf lds0[SPAN];
+    __shared__ cf lds1[GJ_W_DBUF ? SPAN : 1];
     __shared__ float wsum[2][B][WPF][2];
     const int tid = threadIdx.x;
-    const int b = tid / TF, jl = tid % TF;
+    const int b = tid / TF, jl0 = tid % TF;   // jl0: butterfly of pass 0 (input index jl0 + TF s)
+    const int jl = XP ? X4096::jl1(tid) : jl0;   // butterfly of the later passes = bins held at the end
     const unsigned c = blockIdx.x / g.splits, part = blockIdx.x % g.splits;
     const unsigned nseg = (c + 1 == g.nchunks) ? g.nseg_last : g.nseg_full;
     const unsigned seg_lo = (unsigned)((unsigned long long)part * nseg / g.splits);
@@ -139,7 +179,7 @@ __global__ __launch_bounds__(kBlockThreads, GJ_LB) void welch_kernel(const uint8
     c2 w2p[8], wcp[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        const float wa = wintab[jl + TF * (2 * s)], wb = wintab[jl + TF * (2 * s + 1)];
+        const float wa = wintab[jl0 + TF * (2 * s)], wb = wintab[jl0 + TF * (2 * s + 1)];
         w2p[s] = make_c2(2.0f * wa, 2.0f * wb);
         wcp[s] = make_c2(-255.0f * wa, -255.0f * wb);
     }
@@ -157,7 +197,7 @@ __global__ __launch_bounds__(kBlockThreads, GJ_LB) void welch_kernel(const uint8
     // one SGPR pair + one VGPR + immediates
     const uint8_t* chunk8 = iq + (size_t)c * g.chunk_samples * 2;
     auto load_step = [&](unsigned (&dst)[16], unsigned seg_idx) {
-        const unsigned byte0 = (seg_idx * (unsigned)(N / 2) + (unsigned)jl) * 2u;
+        const unsigned byte0 = (seg_idx * (unsigned)(N / 2) + (unsigned)jl0) * 2u;
 #pragma unroll
         for (int s = 0; s < 16; ++s)
             dst[s] = GJ_LOAD_RAW(*reinterpret_cast<const uint16_t*>(chunk8 + (byte0 + 2u * TF * s)));
@@ -198,7 +238,8 @@ __global__ __launch_bounds__(kBlockThreads, GJ_LB) void welch_kernel(const uint8
 
         GJ_STAMP(t_it1);
         GJ_STAMP_ADD(4, t_it0, t_it1);   // unpack + window + sums (+ waiting for the prefetched loads)
-        welch_passes<N, 0>(v, lds0, lds1, it, b * lds_span(N), jl, tw, ktw, stamps);
+        if constexpr (XP) welch_passes_x4096(v, lds0, lds1, tid, tw, ktw, stamps);
+        else welch_passes<N, 0>(v, lds0, lds1, it, b * lds_span(N), jl, tw, ktw, stamps);
         GJ_STAMP(t_it2);
 
         // detrend in the frequency domain on bins 0, 1, N-1

@@ -12,8 +12,13 @@ cover all 32 residues mod 32.  C hits every class mod 16 once, so the second set
 first one shifted by 16 (mod 32), i.e. the set C is invariant under the shift
 B[2h+1] - B[2h] - 16; any non-zero shift generates a subgroup of Z_32 that contains 16, which
 would put c and c + 16 (same class mod 16) both in C.  Hence B[2h+1] = B[2h] + 16 (mod 32),
-contradicting "B distinct mod 16".  The shipped layout (one pad slot per 16) keeps the stores
+contradicting "B distinct mod 16".  The generic layout (one pad slot per 16) keeps the stores
 conflict free and pays a 2-way conflict on the cheaper loads.
+
+That argument assumes thread tid computes butterfly jl = tid in every pass.  `--xpose` checks
+the N = 4096 schedule of fft_core.h (X4096) where the thread changes role at the first exchange
+(jl0 = tid, then jl1 = 16 (tid & 15) + (tid >> 4)) and each exchange has its own layout: all
+four access patterns come out at 1.0 (confirmed on MI355X: SQ_LDS_BANK_CONFLICT = 0).
 
 Prints, per FFT size / thread mapping / padding scheme, the average cycles per
 wave-instruction relative to the conflict-free count (1.0 = conflict free).
@@ -73,6 +78,31 @@ def simulate(N, mapping, pad, rs_extra):
         res.append((R, Ns, sum(wcost)/len(wcost), sum(rcost)/len(rcost)))
         Ns *= R
     return RS, res
+
+def xpose():
+    c0 = lambda t: (t & ~1) + 16 * (t & 1)
+    f0 = lambda i: 286 * (i >> 8) + 17 * ((i >> 4) & 15) + c0(i & 15)
+    f1 = lambda i: 287 * (i >> 8) + 18 * ((i >> 4) & 15) + (i & 15)
+    jl1 = lambda tid: 16 * (tid & 15) + (tid >> 4)
+    for f in (f0, f1):
+        assert len({f(i) for i in range(4096)}) == 4096 and max(f(i) for i in range(4096)) < 4592
+    res = {}
+    for wave in range(4):
+        tids = list(range(wave * 64, wave * 64 + 64))
+        for t in range(16):
+            res.setdefault('exchange 0 write', []).append(cost([f0(16 * tid + t) for tid in tids], 'w'))
+            res.setdefault('exchange 1 write', []).append(
+                cost([f1(256 * (jl1(tid) >> 4) + (jl1(tid) & 15) + 16 * t) for tid in tids], 'w'))
+        for s in range(16):
+            res.setdefault('exchange 0 read', []).append(cost([f0(jl1(tid) + 256 * s) for tid in tids], 'r'))
+            res.setdefault('exchange 1 read', []).append(cost([f1(jl1(tid) + 256 * s) for tid in tids], 'r'))
+    for k, v in sorted(res.items()):
+        print(f"X4096 {k:18s} avg {sum(v) / len(v):.2f}  worst {max(v):.2f}")
+
+
+if '--xpose' in sys.argv:
+    xpose()
+    sys.exit(0)
 
 pads = {
     'none': lambda i: i,
