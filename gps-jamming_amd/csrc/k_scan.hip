@@ -149,9 +149,16 @@ __device__ __forceinline__ float key_float(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-// Radix select over monotone uint keys of the power map, keys cached in LDS (one read of the
-// map from HBM), 256-bin histograms by LDS atomics, digit search by a parallel prefix scan.
-constexpr int kThrCache = 32768;   // keys held in LDS (128 KiB); longer maps re-read global memory
+// Radix select over monotone uint keys of the power map.  One 256-thread workgroup; every
+// thread keeps its 64 keys in VGPRs (16 384 chunks = a 1-GiB capture are read from HBM once),
+// longer maps re-read global memory (L2 hits).  256-bin histograms by LDS atomics, digit search
+// by a parallel prefix scan.  The footprint (1 KiB of LDS, < 112 VGPRs, one wave per SIMD) is
+// deliberate: the kernel must fit NEXT TO two resident Welch workgroups of a CU, because the
+// per-stream pipeline runs it on a second stream while K2 owns the chip -- the earlier
+// 128-KiB-LDS version waited ~0.75 ms for K2's grid to drain.
+constexpr int kThrThreads = 256;
+constexpr int kThrPerThread = 64;
+constexpr int kThrCache = kThrThreads * kThrPerThread;   // keys held in registers
 
 struct ThrShared {
     unsigned hist[256];
@@ -164,44 +171,61 @@ struct ThrShared {
     float thr;
 };
 
-__device__ __forceinline__ unsigned thr_key(const unsigned* __restrict__ keys, const float* __restrict__ power, bool cached,
-                                            size_t i) {
-    return cached ? keys[i] : float_key(power[i]);
+// f(key, index) over every element this thread owns (index = tid + 256 j, j < mine)
+template <typename F>
+__device__ __forceinline__ void thr_for_each(const unsigned (&reg)[kThrPerThread], const float* __restrict__ power,
+                                             bool cached, size_t n, F&& f) {
+    const unsigned tid = threadIdx.x;
+    if (cached) {
+        const unsigned n32 = (unsigned)n;
+        const unsigned mine = (n32 > tid) ? (n32 - tid + kThrThreads - 1) / kThrThreads : 0u;
+#pragma unroll
+        for (unsigned j = 0; j < (unsigned)kThrPerThread; ++j)
+            if (j < mine) f(reg[j], tid + kThrThreads * j);
+    } else {
+        for (size_t i = tid; i < n; i += kThrThreads) f(float_key(power[i]), i);
+    }
 }
 
 // key of rank `rank` (0-based, ascending, NaNs last) -- whole block must call
-__device__ unsigned block_select(const unsigned* __restrict__ keys, const float* __restrict__ power, bool cached, size_t n,
-                                 size_t rank, ThrShared& sh) {
+__device__ unsigned block_select(const unsigned (&reg)[kThrPerThread], const float* __restrict__ power, bool cached,
+                                 size_t n, size_t rank, ThrShared& sh) {
     unsigned prefix = 0, mask = 0;
     unsigned want = (unsigned)rank;
     const int tid = threadIdx.x;
     for (int shift = 24; shift >= 0; shift -= 8) {
-        if (tid < 256) sh.hist[tid] = 0;
+        sh.hist[tid] = 0;
         __syncthreads();
-        for (size_t i = tid; i < n; i += blockDim.x) {
-            const unsigned k = thr_key(keys, power, cached, i);
-            if ((k & mask) == prefix) atomicAdd(&sh.hist[(k >> shift) & 255u], 1u);
-        }
+        // equal digits are the rule (neighbouring powers share exponent and leading mantissa
+        // bits): count runs in registers and flush one atomic per run
+        unsigned run_digit = 0xffffffffu, run_len = 0;
+        thr_for_each(reg, power, cached, n, [&](unsigned k, size_t) {
+            if ((k & mask) == prefix) {
+                const unsigned d = (k >> shift) & 255u;
+                if (d != run_digit) {
+                    if (run_len) atomicAdd(&sh.hist[run_digit], run_len);
+                    run_digit = d;
+                    run_len = 0;
+                }
+                ++run_len;
+            }
+        });
+        if (run_len) atomicAdd(&sh.hist[run_digit], run_len);
         __syncthreads();
         // digit d with excl(d) <= want < excl(d) + hist[d]
-        unsigned h = 0, inc = 0;
-        if (tid < 256) {
-            h = sh.hist[tid];
-            inc = h;
+        const unsigned h = sh.hist[tid];
+        unsigned inc = h;
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned o = __shfl_up(inc, off, 64);
-                if ((tid & 63) >= off) inc += o;
-            }
-            if ((tid & 63) == 63) sh.wave_tot[tid >> 6] = inc;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_up(inc, off, 64);
+            if ((tid & 63) >= off) inc += o;
         }
+        if ((tid & 63) == 63) sh.wave_tot[tid >> 6] = inc;
         __syncthreads();
-        if (tid < 256) {
-            unsigned base = 0;
-            for (int w = 0; w < (tid >> 6); ++w) base += sh.wave_tot[w];
-            const unsigned excl = base + inc - h;
-            if (h && excl <= want && want < excl + h) { sh.digit = tid; sh.rest = want - excl; }
-        }
+        unsigned base = 0;
+        for (int w = 0; w < (tid >> 6); ++w) base += sh.wave_tot[w];
+        const unsigned excl = base + inc - h;
+        if (h && excl <= want && want < excl + h) { sh.digit = tid; sh.rest = want - excl; }
         __syncthreads();
         prefix |= sh.digit << shift;
         mask |= 255u << shift;
@@ -211,20 +235,31 @@ __device__ unsigned block_select(const unsigned* __restrict__ keys, const float*
     return prefix;
 }
 
-__global__ __launch_bounds__(1024) void power_threshold_kernel(const float* __restrict__ power, size_t n, float pct,
-                                                               float ratio, float* __restrict__ stats,
-                                                               uint8_t* __restrict__ mask) {
-    __shared__ unsigned keys[kThrCache];
+__global__ __launch_bounds__(kThrThreads) __attribute__((amdgpu_num_vgpr(104))) void power_threshold_kernel(const float* __restrict__ power, size_t n, float pct,
+                                                                      float ratio, float* __restrict__ stats,
+                                                                      uint8_t* __restrict__ mask) {
     __shared__ ThrShared sh;
     const int tid = threadIdx.x;
     const bool cached = n <= (size_t)kThrCache;
     if (tid == 0) { sh.nan_flag = 0; sh.above = 0; sh.count_le = 0; sh.next_key = 0xffffffffu; }
     __syncthreads();
+    unsigned reg[kThrPerThread];
     unsigned has_nan = 0;
-    for (size_t i = tid; i < n; i += blockDim.x) {
-        const float p = power[i];
-        has_nan |= (p != p);
-        if (cached) keys[i] = float_key(p);
+    if (cached) {
+#pragma unroll
+        for (int j = 0; j < kThrPerThread; ++j) {
+            const size_t i = (size_t)tid + (size_t)kThrThreads * j;
+            const float p = (i < n) ? power[i] : 0.0f;
+            has_nan |= (p != p);
+            reg[j] = float_key(p);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kThrPerThread; ++j) reg[j] = 0;
+        for (size_t i = tid; i < n; i += kThrThreads) {
+            const float p = power[i];
+            has_nan |= (p != p);
+        }
     }
     if (has_nan) atomicOr(&sh.nan_flag, 1u);
     // numpy 2.x: q = float32(pct)/float32(100); virtual index = float32(n-1) * q  (all float32)
@@ -234,16 +269,15 @@ __global__ __launch_bounds__(1024) void power_threshold_kernel(const float* __re
     if (lo > n - 1) lo = n - 1;
     const size_t hi = (lo + 1 < n) ? lo + 1 : n - 1;
     const float g = vidx - (float)lo;
-    const unsigned ka = block_select(keys, power, cached, n, lo, sh);
+    const unsigned ka = block_select(reg, power, cached, n, lo, sh);
     // rank lo+1: ka again when it occurs often enough, else the smallest key above it
     unsigned kb = ka;
     if (hi != lo) {
         unsigned cnt = 0, nxt = 0xffffffffu;
-        for (size_t i = tid; i < n; i += blockDim.x) {
-            const unsigned k = thr_key(keys, power, cached, i);
+        thr_for_each(reg, power, cached, n, [&](unsigned k, size_t) {
             cnt += (k <= ka);
             if (k > ka && k < nxt) nxt = k;
-        }
+        });
         cnt = wave_sum_u32(cnt);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -268,11 +302,11 @@ __global__ __launch_bounds__(1024) void power_threshold_kernel(const float* __re
     __syncthreads();
     const float thr = sh.thr;
     unsigned cnt = 0;
-    for (size_t i = tid; i < n; i += blockDim.x) {
-        const bool hot = power[i] > thr;
+    thr_for_each(reg, power, cached, n, [&](unsigned k, size_t i) {
+        const bool hot = key_float(k) > thr;
         cnt += hot;
         if (mask) mask[i] = hot;
-    }
+    });
     cnt = wave_sum_u32(cnt);
     if ((tid & 63) == 0) atomicAdd(&sh.above, (unsigned long long)cnt);
     __syncthreads();
@@ -283,7 +317,7 @@ int launch_power_threshold(gj_ctx* ctx, const float* d_power, size_t n, float pc
                            uint8_t* d_mask) {
     if (n == 0) return fail(ctx, GJ_ERR_INVALID, "empty power map");
     const float ratio = (float)pow(10.0, (double)rise_db / 10.0);
-    hipLaunchKernelGGL(power_threshold_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_power, n, pct, ratio, d_stats,
+    hipLaunchKernelGGL(power_threshold_kernel, dim3(1), dim3(kThrThreads), 0, ctx->stream, d_power, n, pct, ratio, d_stats,
                        d_mask);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;

@@ -17,6 +17,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import List, Optional
 
+import contextlib
+
 import numpy as np
 import torch
 
@@ -124,9 +126,25 @@ class AntennaStream:
     def __init__(self, dev, capture: torch.Tensor, *, chunk_bytes: int = 65536,
                  chunk_samples: int = 2048000, nperseg: int = 4096, fs: float = 2.048e6,
                  slice_samples: int = 1 << 19, noise_samples: int = 200000, window: int = 1000,
-                 factor: float = 50.0, rssi_threshold: float = 0.0, rank: int = 0, world_size: int = 1):
+                 factor: float = 50.0, rssi_threshold: float = 0.0, rank: int = 0, world_size: int = 1,
+                 overlap: Optional[bool] = None):
         assert capture.dtype == torch.uint8 and capture.is_contiguous()
         self.dev, self.cap = dev, capture
+        # K2 is VALU/LDS bound and leaves ~90 % of the HBM bandwidth idle, the fused scan is HBM
+        # bound: with ``overlap`` the scan, threshold and TDOA kernels run on a second HIP
+        # stream (own gpsjam context = own workspace) concurrently with K2 and join in pack().
+        if overlap is None:
+            overlap = capture.is_cuda and hasattr(dev, "_ctx")
+        self.overlap = bool(overlap)
+        self.dev_side = dev
+        if self.overlap:
+            self.dev_side = type(dev)(dev.index)
+            self._main = torch.cuda.current_stream(capture.device)
+            self._side = torch.cuda.Stream(device=capture.device)
+            self.dev_side.set_stream(self._side.cuda_stream)
+            self._ev_free = torch.cuda.Event()      # main: previous results consumed, buffers may be rewritten
+            self._ev_side = torch.cuda.Event()      # side: scan / TDOA results ready
+            self._ev_free.record(self._main)
         self.nbytes = capture.numel()
         self.rank, self.world = rank, world_size
         self.chunk_bytes, self.chunk_samples, self.nperseg, self.fs = chunk_bytes, chunk_samples, nperseg, fs
@@ -148,15 +166,28 @@ class AntennaStream:
         self._ar = torch.arange(slice_samples, dtype=torch.int64, device=d)
         self.result = torch.zeros(result_len(self.n_chunks, nperseg), dtype=torch.float64, device=d)
         self.cap16 = capture.view(torch.int16)
-        ws = max(dev.welch_workspace(self.nbytes, chunk_samples, nperseg),
-                 dev.xcorr_workspace(2, slice_samples, 1), self.nbytes // 48 + (1 << 20))
-        dev.reserve(ws)
+        ws_side = max(dev.xcorr_workspace(2, slice_samples, 1), self.nbytes // 48 + (1 << 20))
+        ws_main = dev.welch_workspace(self.nbytes, chunk_samples, nperseg)
+        if self.overlap:
+            dev.reserve(ws_main)
+            self.dev_side.reserve(ws_side)
+        else:
+            dev.reserve(max(ws_main, ws_side))
+
+    def _on_side(self):
+        """Context manager: torch's current stream = the side stream (no-op without overlap)."""
+        return torch.cuda.stream(self._side) if self.overlap else contextlib.nullcontext()
 
     def stream_scan(self):
         """K1 + K3 + K4 in one pass over the capture, then the noise-floor threshold."""
-        self.dev.stream_scan_dev(self.cap, self.nbytes, self.chunk_bytes, self.power, self.rssi_threshold,
-                                 self.amp, self.noise_samples, self.window, self.factor, self.onset)
-        self.dev.power_threshold_dev(self.power, self.n_chunks, self.stats, self.mask)
+        if self.overlap:
+            self._side.wait_event(self._ev_free)
+        d = self.dev_side
+        d.stream_scan_dev(self.cap, self.nbytes, self.chunk_bytes, self.power, self.rssi_threshold,
+                          self.amp, self.noise_samples, self.window, self.factor, self.onset)
+        d.power_threshold_dev(self.power, self.n_chunks, self.stats, self.mask)
+        if self.overlap:
+            self._ev_side.record(self._side)
 
     def welch(self):
         self.dev.welch_dev(self.cap, self.nbytes, self.chunk_samples, self.nperseg, self.fs, self.psd)
@@ -168,6 +199,12 @@ class AntennaStream:
 
     def tdoa(self):
         """Reference slice from rank 0 (broadcast), lag of this capture against it."""
+        with self._on_side():
+            self._tdoa(self.dev_side)
+            if self.overlap:
+                self._ev_side.record(self._side)
+
+    def _tdoa(self, dev):
         n = self.slice_samples
         nsamp = self.nbytes // 2
         if self.world > 1:
@@ -178,17 +215,21 @@ class AntennaStream:
             # rank 0's onset travels in the slice's validity: an un-found onset (-1) on rank 0
             # makes idx start at the clamp and the lag meaningless; rank 0 reports it.
             self.starts[1:2].copy_(self.onset[0:1])          # starts[0] stays 0: the slice is already aligned
-            self.dev.xcorr_lags_dev([self.ref_slice, self.cap], [2 * n, self.nbytes], self.starts, n,
+            dev.xcorr_lags_dev([self.ref_slice, self.cap], [2 * n, self.nbytes], self.starts, n,
                                     [(0, 1)], self.lag, self.peak)
         else:
             self.starts.copy_(self.onset[0:1].expand(2))
-            self.dev.xcorr_lags_dev([self.cap, self.cap], [self.nbytes, self.nbytes], self.starts, n,
+            dev.xcorr_lags_dev([self.cap, self.cap], [self.nbytes, self.nbytes], self.starts, n,
                                     [(0, 1)], self.lag, self.peak)
 
     def pack(self) -> torch.Tensor:
         """Result vector of this stream, built by one kernel (layout = pack_results)."""
+        if self.overlap:
+            self._main.wait_event(self._ev_side)
         self.dev.pack_result_dev(self.n_chunks, self.power, self.stats, self.amp, self.onset, self.lag, self.peak,
                                  self.psd, self.rows, self.nperseg, self.rank, self.result)
+        if self.overlap:
+            self._ev_free.record(self._main)
         return self.result
 
     def step(self):
