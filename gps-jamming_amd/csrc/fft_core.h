@@ -79,6 +79,47 @@ __device__ __forceinline__ c2 cmul_add_k(c2 a, c2 w, c2 c) {   // w wave-uniform
         : "v"(a), "s"(w), "v"(t));
     return r;
 }
+// The two halves of a complex multiply(-add) as separate operations.  gfx950 needs one wait
+// state between a packed-f32 op and a packed op that reads its result (hipcc pads with s_nop);
+// the butterflies below issue the first halves of two independent products, then the second
+// halves, so no dependent pair is adjacent.
+//   cmul_1(a, w)        = (a.x w.x,       a.x w.y)
+//   cmul_add_1(a, w, c) = (c.x + a.x w.x, c.y + a.x w.y)
+//   cmul_2(a, w, t)     = (t.x - a.y w.y, t.y + a.y w.x)
+__device__ __forceinline__ c2 cmul_1(c2 a, c2 w) {
+    c2 t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    return t;
+}
+__device__ __forceinline__ c2 cmul_add_1(c2 a, c2 w, c2 c) {
+    c2 t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "v"(w), "v"(c));
+    return t;
+}
+__device__ __forceinline__ c2 cmul_2(c2 a, c2 w, c2 t) {
+    c2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r)
+        : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+__device__ __forceinline__ c2 cmul_1_k(c2 a, c2 w) {   // _k: w wave-uniform, in SGPRs
+    c2 t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(w));
+    return t;
+}
+__device__ __forceinline__ c2 cmul_add_1_k(c2 a, c2 w, c2 c) {
+    c2 t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "s"(w), "v"(c));
+    return t;
+}
+__device__ __forceinline__ c2 cmul_2_k(c2 a, c2 w, c2 t) {
+    c2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r)
+        : "v"(a), "s"(w), "v"(t));
+    return r;
+}
 // 2 u - t   (the "other" butterfly output when t = u + w x is already known)
 __device__ __forceinline__ c2 twice_minus(c2 u, c2 t) {
     c2 r;
@@ -137,6 +178,12 @@ GJ_HD c2 cmul(c2 a, c2 b) { return c2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b
 GJ_HD c2 cmul_k(c2 a, c2 b) { return cmul(a, b); }
 GJ_HD c2 cmul_add(c2 a, c2 w, c2 c) { return c2{c.x + a.x * w.x - a.y * w.y, c.y + a.x * w.y + a.y * w.x}; }
 GJ_HD c2 cmul_add_k(c2 a, c2 w, c2 c) { return cmul_add(a, w, c); }
+GJ_HD c2 cmul_1(c2 a, c2 w) { return c2{a.x * w.x, a.x * w.y}; }
+GJ_HD c2 cmul_add_1(c2 a, c2 w, c2 c) { return c2{c.x + a.x * w.x, c.y + a.x * w.y}; }
+GJ_HD c2 cmul_2(c2 a, c2 w, c2 t) { return c2{t.x - a.y * w.y, t.y + a.y * w.x}; }
+GJ_HD c2 cmul_1_k(c2 a, c2 w) { return cmul_1(a, w); }
+GJ_HD c2 cmul_add_1_k(c2 a, c2 w, c2 c) { return cmul_add_1(a, w, c); }
+GJ_HD c2 cmul_2_k(c2 a, c2 w, c2 t) { return cmul_2(a, w, t); }
 GJ_HD c2 twice_minus(c2 u, c2 t) { return c2{2.0f * u.x - t.x, 2.0f * u.y - t.y}; }
 GJ_HD c2 cadd(c2 a, c2 b) { return c2{a.x + b.x, a.y + b.y}; }
 GJ_HD c2 csub(c2 a, c2 b) { return c2{a.x - b.x, a.y - b.y}; }
@@ -262,10 +309,13 @@ GJ_HD void dft<16>(c2 (&a)[16], const InnerTw& k) {
 // ---- FMA-form radix-4 butterflies: X = DFT4(x0, w1 x1, w2 x2, w3 x3) in 12 packed ops instead
 // of 3 complex multiplies + 8 additions = 14 (t0 = x0 + w2 x2 as two FMAs, t1 = 2 x0 - t0, ...).
 GJ_HD void bfly4_tw(c2& x0, c2& x1, c2& x2, c2& x3, c2 w1, c2 w2, c2 w3) {
-    const c2 t0 = cmul_add(x2, w2, x0);
+    const c2 t0a = cmul_add_1(x2, w2, x0);
+    const c2 u1a = cmul_1(x1, w1);
+    const c2 t0 = cmul_2(x2, w2, t0a);
+    const c2 u1 = cmul_2(x1, w1, u1a);
     const c2 t1 = twice_minus(x0, t0);
-    const c2 u1 = cmul(x1, w1);
-    const c2 t2 = cmul_add(x3, w3, u1);
+    const c2 t2a = cmul_add_1(x3, w3, u1);
+    const c2 t2 = cmul_2(x3, w3, t2a);
     const c2 t3 = twice_minus(u1, t2);
     x0 = cadd(t0, t2);
     x2 = csub(t0, t2);
@@ -273,10 +323,13 @@ GJ_HD void bfly4_tw(c2& x0, c2& x1, c2& x2, c2& x3, c2 w1, c2 w2, c2 w3) {
     x3 = add_pj(t1, t3);
 }
 GJ_HD void bfly4_tw_k(c2& x0, c2& x1, c2& x2, c2& x3, c2 w1, c2 w2, c2 w3) {   // constant (SGPR) twiddles
-    const c2 t0 = cmul_add_k(x2, w2, x0);
+    const c2 t0a = cmul_add_1_k(x2, w2, x0);
+    const c2 u1a = cmul_1_k(x1, w1);
+    const c2 t0 = cmul_2_k(x2, w2, t0a);
+    const c2 u1 = cmul_2_k(x1, w1, u1a);
     const c2 t1 = twice_minus(x0, t0);
-    const c2 u1 = cmul_k(x1, w1);
-    const c2 t2 = cmul_add_k(x3, w3, u1);
+    const c2 t2a = cmul_add_1_k(x3, w3, u1);
+    const c2 t2 = cmul_2_k(x3, w3, t2a);
     const c2 t3 = twice_minus(u1, t2);
     x0 = cadd(t0, t2);
     x2 = csub(t0, t2);
@@ -285,11 +338,15 @@ GJ_HD void bfly4_tw_k(c2& x0, c2& x1, c2& x2, c2& x3, c2 w1, c2 w2, c2 w3) {   /
 }
 // all four inputs twiddled: 14 packed ops instead of 16
 GJ_HD void bfly4_tw4(c2& x0, c2& x1, c2& x2, c2& x3, c2 w0, c2 w1, c2 w2, c2 w3) {
-    const c2 u0 = cmul(x0, w0);
-    const c2 t0 = cmul_add(x2, w2, u0);
+    const c2 u0a = cmul_1(x0, w0);
+    const c2 u1a = cmul_1(x1, w1);
+    const c2 u0 = cmul_2(x0, w0, u0a);
+    const c2 u1 = cmul_2(x1, w1, u1a);
+    const c2 t0a = cmul_add_1(x2, w2, u0);
+    const c2 t2a = cmul_add_1(x3, w3, u1);
+    const c2 t0 = cmul_2(x2, w2, t0a);
+    const c2 t2 = cmul_2(x3, w3, t2a);
     const c2 t1 = twice_minus(u0, t0);
-    const c2 u1 = cmul(x1, w1);
-    const c2 t2 = cmul_add(x3, w3, u1);
     const c2 t3 = twice_minus(u1, t2);
     x0 = cadd(t0, t2);
     x2 = csub(t0, t2);
@@ -304,9 +361,12 @@ GJ_HD void dft16_layer2(c2 (&a)[16], const InnerTw& k) {
     bfly4_tw_k(a[4], a[5], a[6], a[7], k.w16_1, k.w16_2, k.w16_3);   // k2 = 1
     {                                                                // k2 = 2: W16^2, -j, W16^6
         c2 &y0 = a[8], &y1 = a[9], &y2 = a[10], &y3 = a[11];
-        const c2 t0 = add_mj(y0, y2), t1 = add_pj(y0, y2);           // y0 -+ j y2
-        const c2 u1 = cmul_k(y1, k.w16_2);
-        const c2 t2 = cmul_add_k(y3, k.w16_6, u1);
+        const c2 u1a = cmul_1_k(y1, k.w16_2);
+        const c2 t0 = add_mj(y0, y2);                                // y0 - j y2
+        const c2 u1 = cmul_2_k(y1, k.w16_2, u1a);
+        const c2 t1 = add_pj(y0, y2);                                // y0 + j y2
+        const c2 t2a = cmul_add_1_k(y3, k.w16_6, u1);
+        const c2 t2 = cmul_2_k(y3, k.w16_6, t2a);
         const c2 t3 = twice_minus(u1, t2);
         y0 = cadd(t0, t2);
         y2 = csub(t0, t2);
