@@ -150,6 +150,7 @@ def main():
         total_samples = float(nsamp) * world * args.steps
         value = total_samples / elapsed / 1e6
         achieved = (nbytes / 1e9) / (welch_ms / 1e3) if welch_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(nbytes)
         line = {
             "metric": "Msamples/s uint8 I/Q through PSD+TDOA xcorr",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "precondition_steps": args.precondition,
@@ -162,7 +163,8 @@ def main():
                        "xcorr_slice": SLICE, "streams": world, "sharding": "one capture per GPU"},
             "roofline": {"bound": "hbm", "kernel": "welch_kernel<4096> + welch_finalize_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": welch_ms,
                          "overlap": bool(stream.overlap),
                          "solo": {"avg_launch_ms": solo_ms, "achieved": (nbytes / 1e9) / (solo_ms / 1e3),
@@ -182,6 +184,22 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     dev.close()
+
+
+def pmc_traffic(nbytes):
+    """HBM bytes per K2 launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate runs, gfx950 correction calibrated on K2's own access pattern: tools/pmc_welch.sh,
+    tools/pmc_summarize.py).  PMC collection cannot run inside the timed bench, so the figure is the
+    recorded one and only offered for the capture size it was measured on."""
+    path = os.path.join(REPO, "profiles", "r01_pmc_welch", "summary_final.json")
+    try:
+        with open(path) as f:
+            corr = json.load(f)["_hbm_bytes_corrected"]
+        if nbytes != CAPTURE_BYTES:
+            return None, "PMC summary is for the 1-GiB capture only"
+        return float(corr["hbm_bytes_per_launch"]), "profiles/r01_pmc_welch/summary_final.json (welch_kernel<4096> only)"
+    except (OSError, KeyError, ValueError):
+        return None, "no PMC summary found"
 
 
 def cpu_baseline(np, cap, n_chunks, stream, gpu_result):

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 --pmc passes of tools/pmc_welch.sh into one JSON summary (averages per
+dispatch of welch_kernel) with the HBM byte counts corrected as MI355X_MICROARCH.md prescribes:
+FETCH_SIZE is in KiB and, on gfx950, tallies 128-B requests at 64 B for wide streaming reads;
+the factor for K2's own 2-byte-per-lane pattern is calibrated by tools/calib_fetch (1 GiB read
+exactly once with each pattern) in the same session.
+    python tools/pmc_summarize.py gpurun_out/<dir> > profiles/r01_pmc_welch/summary_final.json"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def collect(root, kernel_substr):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if kernel_substr in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def main():
+    root = sys.argv[1]
+    k2 = collect(root, "welch_kernel")
+    u16 = collect(root, "calib_read_u16").get("FETCH_SIZE")
+    x4 = collect(root, "calib_read_x4").get("FETCH_SIZE")
+    out = dict(sorted(k2.items()))
+    gib_kib = float(1 << 20)
+    corr = {"FETCH_SIZE_KiB": k2.get("FETCH_SIZE"), "WRITE_SIZE_KiB": k2.get("WRITE_SIZE")}
+    if u16 and x4:
+        corr["calibration"] = {"read_1GiB_u16_FETCH_SIZE_KiB": u16, "read_1GiB_x4_FETCH_SIZE_KiB": x4,
+                               "factor_u16": gib_kib / u16, "factor_x4": gib_kib / x4}
+    factor = (gib_kib / u16) if u16 else 2.0
+    if k2.get("FETCH_SIZE") is not None:
+        corr["read_bytes"] = k2["FETCH_SIZE"] * 1024.0 * factor
+        corr["read_factor_applied"] = factor
+    if k2.get("WRITE_SIZE") is not None:
+        corr["write_bytes"] = k2["WRITE_SIZE"] * 1024.0
+    if "read_bytes" in corr and "write_bytes" in corr:
+        corr["hbm_bytes_per_launch"] = corr["read_bytes"] + corr["write_bytes"]
+    out["_hbm_bytes_corrected"] = corr
+    out["_note"] = ("rocprofv3 --pmc, separate passes (tools/pmc_welch.sh), welch_kernel<4096> on 2^30 bytes, "
+                    "averages per dispatch")
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
