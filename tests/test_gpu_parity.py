@@ -98,6 +98,32 @@ def test_percentile_rule_matches_numpy(dev, n):
     assert d_stats.download(np.float32)[0] == np.percentile(pm, 5)
 
 
+@pytest.mark.parametrize("n", [7, 1000, 16383, 16385, 33000])
+@pytest.mark.parametrize("kind", ["few_values", "constant", "negative_and_zero"])
+def test_percentile_rule_ties_and_signs(dev, n, kind):
+    """Radix select with heavy ties (run-length flushed histogram), one repeated value, and keys of
+    both signs; n straddles the 16 384 register-cached keys (longer maps re-read global memory)."""
+    rng = np.random.RandomState(n + len(kind))
+    if kind == "few_values":
+        pm = rng.randint(0, 5, n).astype(np.float32) * np.float32(0.37) + np.float32(1.5)
+    elif kind == "constant":
+        pm = np.full(n, 68.72, np.float32)
+    else:
+        pm = (rng.randn(n) * 3).astype(np.float32)
+        pm[::7] = 0.0
+    d_pow, d_stats, d_mask = dev.alloc(4 * n).upload(pm), dev.alloc(12), dev.alloc(n)
+    dev.power_threshold_dev(d_pow, n, d_stats, d_mask)
+    dev.synchronize()
+    stats = d_stats.download(np.float32)
+    want = np.float32(np.percentile(pm, 5))
+    base = want if want > 0 else np.float32(1.0)          # worker.py:243-244
+    assert stats[0] == base
+    thr = np.float32(base * np.float32(10.0 ** 0.6))
+    np.testing.assert_allclose(stats[1], thr, rtol=2e-7)
+    np.testing.assert_array_equal(d_mask.download(np.uint8, n).astype(bool), pm > stats[1])
+    assert int(stats[2]) == int((pm > stats[1]).sum())
+
+
 # ----------------------------------------------------------------------------- K2
 def rel_err(got, want, floor=1e-12):
     keep = want > floor

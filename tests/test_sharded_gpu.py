@@ -49,3 +49,37 @@ def test_antenna_stream_single_gpu():
     np.testing.assert_allclose(res.mean_spectrum, lin.mean(axis=0), rtol=1e-4)
     torch.cuda.set_stream(torch.cuda.default_stream())
     dev.close()
+
+
+def test_antenna_stream_overlap_matches_single_stream():
+    """Two-stream pipeline (scan / threshold / TDOA beside K2) against the single-stream order,
+    several steps back to back: the result vector must not depend on the overlap and must not
+    change from step to step (the cross-step events keep pack and the next scan apart)."""
+    import torch
+    import gpsjam
+    from gpsjam import sharded
+    from gpsjam.synth import StreamSpec, generate
+
+    n = 3_000_000
+    raw = generate(StreamSpec(seed=5, antenna=1, delay=2, jam_start=1_200_000, jam_end=2_100_000, jam_sigma=50.0), n)
+    dev = gpsjam.Device(0)
+    work = torch.cuda.Stream()
+    torch.cuda.set_stream(work)
+    dev.set_stream(work.cuda_stream)
+    cap = torch.from_numpy(raw).cuda()
+    vecs = {}
+    for overlap in (False, True):
+        st = sharded.AntennaStream(dev, cap, nperseg=4096, chunk_samples=500000, slice_samples=1 << 16, overlap=overlap)
+        assert st.overlap is overlap
+        outs = []
+        for _ in range(4):
+            outs.append(st.step()[0].clone())
+        torch.cuda.synchronize()
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
+        vecs[overlap] = outs[0].cpu().numpy()
+    np.testing.assert_array_equal(vecs[True], vecs[False])
+    res = sharded.unpack_results(torch.from_numpy(vecs[True]))
+    assert res.onset > 0 and res.lag == 0 and len(res.jamming_byte_ranges()) == 1
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    dev.close()
