@@ -36,6 +36,18 @@
 #ifndef GJ_W_DBUF
 #define GJ_W_DBUF 1      // 1: two LDS exchange buffers, one barrier per exchange; 0: one buffer, two barriers
 #endif
+#ifndef GJ_W_OCC3_MASK
+// Bit k set: transform size 2^k runs in the "three workgroups per CU" shape (<= 168 VGPRs, one
+// LDS buffer with two barriers per exchange, window kept as 16 floats, scalar |X|^2 accumulators:
+// +32 VALU instructions per step, but a third wave per SIMD to fill the issue slots -- a wave
+// issues at most one instruction every ~5 cycles, whatever its kind).  Measured on MI355X, 1 GiB,
+// same box, two-workgroup shape -> three-workgroup shape:
+//   N = 4096  1.296 -> 1.216 ms    256  0.975 -> 0.939    128  1.055 -> 1.042    64  1.278 -> 1.207
+//   N = 32    2.160 -> 2.119       16   1.673 -> 1.695 (kept)
+//   N = 512   1.217 -> 1.571, 1024  1.278 -> 1.868, 2048  1.290 -> 2.129: their last pass needs
+//   more twiddle registers and the 168-VGPR shape spills -> they keep two workgroups per CU.
+#define GJ_W_OCC3_MASK 0x11E0u
+#endif
 #ifndef GJ_W_XPOSE
 #define GJ_W_XPOSE 1     // 1: N = 4096 uses the bank-conflict-free exchange schedule (fft_core.h X4096)
 #endif
@@ -55,6 +67,17 @@
 #endif
 
 namespace gj {
+
+constexpr int welch_log2(int n) { return n <= 1 ? 0 : 1 + welch_log2(n / 2); }
+constexpr bool welch_occ3(int n) { return ((GJ_W_OCC3_MASK >> welch_log2(n)) & 1u) != 0; }
+template <int N>
+struct WelchCfg {
+    static constexpr bool occ3 = welch_occ3(N);
+    static constexpr int min_waves = occ3 ? 3 : GJ_LB;          // per SIMD, asked of the register allocator
+    static constexpr bool pkacc = (GJ_W_PKACC != 0) && !occ3;   // |X|^2 as (re^2, im^2) pairs
+    static constexpr bool dbuf = (GJ_W_DBUF != 0) && !occ3;     // two LDS exchange buffers
+    static constexpr bool win16 = occ3;                         // window as 16 floats instead of 16 pairs
+};
 
 #ifdef GJ_STAMPS
 __device__ unsigned long long g_welch_stamps[8];
@@ -90,7 +113,7 @@ __device__ __forceinline__ void welch_passes(c2 (&v)[16], cf* lds0, cf* lds1, un
     if constexpr (PASS + 1 < NP) {
         // exchanges per segment: NP-1.  Even count -> parity of PASS; odd count -> parity of (it + PASS)
         const bool second = ((NP - 1) % 2 == 0) ? (PASS & 1) : ((it + PASS) & 1);
-        cf* lds = (GJ_W_DBUF && second) ? lds1 : lds0;
+        cf* lds = (WelchCfg<N>::dbuf && second) ? lds1 : lds0;
         lds_scatter<N, PASS>(v, lds, base, jl);
         GJ_STAMP(t2);
         GJ_STAMP_ADD(1, t1, t2);   // scatter issued and landed (the stamp waits lgkmcnt(0))
@@ -100,7 +123,7 @@ __device__ __forceinline__ void welch_passes(c2 (&v)[16], cf* lds0, cf* lds1, un
         lds_gather<N>(v, lds, base, jl);
         GJ_STAMP(t4);
         GJ_STAMP_ADD(3, t3, t4);   // gather
-        if (!GJ_W_DBUF) __syncthreads();
+        if (!WelchCfg<N>::dbuf) __syncthreads();
         welch_passes<N, PASS + 1>(v, lds0, lds1, it, base, jl, tw, ktw, stamps);
     }
 }
@@ -120,36 +143,40 @@ __device__ __forceinline__ void welch_passes_x4096(c2 (&v)[16], cf* lds0, cf* ld
     GJ_STAMP(t3);
     GJ_STAMP_ADD(2, t2, t3);
     x4096_gather<0>(v, lds0, tid);
+    if (!WelchCfg<4096>::dbuf) __syncthreads();
     GJ_STAMP(t4);
     GJ_STAMP_ADD(3, t3, t4);
-    fft_pass<4096, 1, false, GJ_W_FMA != 0>(v, tw[1], ktw);
+    fft_pass<4096, 1, GJ_W_TWOSTEP != 0, GJ_W_FMA != 0>(v, tw[1], ktw);
     GJ_STAMP(t5);
     GJ_STAMP_ADD(0, t4, t5);
-    x4096_scatter<1>(v, lds1, tid);
+    cf* ldsx = WelchCfg<4096>::dbuf ? lds1 : lds0;
+    x4096_scatter<1>(v, ldsx, tid);
     GJ_STAMP(t6);
     GJ_STAMP_ADD(1, t5, t6);
     __syncthreads();
     GJ_STAMP(t7);
     GJ_STAMP_ADD(2, t6, t7);
-    x4096_gather<1>(v, lds1, tid);
+    x4096_gather<1>(v, ldsx, tid);
+    if (!WelchCfg<4096>::dbuf) __syncthreads();
     GJ_STAMP(t8);
     GJ_STAMP_ADD(3, t7, t8);
-    fft_pass<4096, 2, false, GJ_W_FMA != 0>(v, tw[2], ktw);
+    fft_pass<4096, 2, GJ_W_TWOSTEP != 0, GJ_W_FMA != 0>(v, tw[2], ktw);
     GJ_STAMP(t9);
     GJ_STAMP_ADD(0, t8, t9);
 }
 
 template <int N>
-__global__ __launch_bounds__(kBlockThreads, GJ_LB) void welch_kernel(const uint8_t* __restrict__ iq, WelchGeom g,
+__global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_kernel(const uint8_t* __restrict__ iq, WelchGeom g,
                                                               const cf* __restrict__ twtab,
                                                               const float* __restrict__ wintab,
                                                               float* __restrict__ partial) {
     constexpr int TF = N / 16, B = kBlockPoints / N, NP = fft_npass(N);
     constexpr int WPF = (TF >= 64) ? TF / 64 : 1;   // waves per transform
-    constexpr bool XP = (N == 4096) && GJ_W_XPOSE && GJ_W_DBUF && !GJ_W_TWOSTEP;
+    constexpr bool XP = (N == 4096) && GJ_W_XPOSE;
     constexpr int SPAN = XP ? X4096::kSpan : lds_span(kBlockPoints);
     __shared__ cf lds0[SPAN];
-    __shared__ cf lds1[GJ_W_DBUF ? SPAN : 1];
+    using Cfg = WelchCfg<N>;
+    __shared__ cf lds1[Cfg::dbuf ? SPAN : 1];
     __shared__ float wsum[2][B][WPF][2];
     const int tid = threadIdx.x;
     const int b = tid / TF, jl0 = tid % TF;   // jl0: butterfly of pass 0 (input index jl0 + TF s)
@@ -176,22 +203,21 @@ __global__ __launch_bounds__(kBlockThreads, GJ_LB) void welch_kernel(const uint8
 
     // window folded into the unpack: w (2u - 255) = u (2w) + (-255 w); (w[2i], w[2i+1]) share a
     // VGPR pair and op_sel picks the half, so 16 points cost 16 register pairs
-    c2 w2p[8], wcp[8];
+    c2 w2p[8], wcp[Cfg::win16 ? 1 : 8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const float wa = wintab[jl0 + TF * (2 * s)], wb = wintab[jl0 + TF * (2 * s + 1)];
         w2p[s] = make_c2(2.0f * wa, 2.0f * wb);
-        wcp[s] = make_c2(-255.0f * wa, -255.0f * wb);
+        if constexpr (!Cfg::win16) wcp[s] = make_c2(-255.0f * wa, -255.0f * wb);
     }
-#if GJ_W_PKACC
-    c2 acc[16];   // (sum re^2, sum im^2): one packed FMA per bin and step
+    [[maybe_unused]] const c2 khalf = make_c2(-127.5f, -127.5f);
+    c2 accp[Cfg::pkacc ? 16 : 1];      // (sum re^2, sum im^2): one packed FMA per bin and step
+    float accs[Cfg::pkacc ? 1 : 16];   // or scalar sums (two FMAs per bin and step, 16 VGPRs fewer)
 #pragma unroll
-    for (int s = 0; s < 16; ++s) acc[s] = make_c2(0.f, 0.f);
-#else
-    float acc[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) acc[s] = 0.f;
-#endif
+    for (int s = 0; s < 16; ++s) {
+        if constexpr (Cfg::pkacc) accp[s] = make_c2(0.f, 0.f);
+        else accs[s] = 0.f;
+    }
 
     // wave-uniform chunk base + 32-bit per-lane byte offsets: the loads keep their addresses in
     // one SGPR pair + one VGPR + immediates
@@ -219,7 +245,10 @@ __global__ __launch_bounds__(kBlockThreads, GJ_LB) void welch_kernel(const uint8
         for (int s = 0; s < 16; ++s) {
             const unsigned u = raw[s];
             const c2 f = make_c2((float)(u & 255u), (float)((u >> 8) & 255u));
-            v[s] = (s & 1) ? fma_hi(f, w2p[s >> 1], wcp[s >> 1]) : fma_lo(f, w2p[s >> 1], wcp[s >> 1]);
+            if constexpr (Cfg::win16)   // w (2u - 255) = (u - 127.5) (2w)
+                v[s] = (s & 1) ? scale_hi(cadd(f, khalf), w2p[s >> 1]) : scale_lo(cadd(f, khalf), w2p[s >> 1]);
+            else
+                v[s] = (s & 1) ? fma_hi(f, w2p[s >> 1], wcp[s >> 1]) : fma_lo(f, w2p[s >> 1], wcp[s >> 1]);
             fsum = cadd(fsum, f);
         }
         if (GJ_W_PREFETCH) load_step(raw, (seg + B < seg_hi) ? seg + B : seg_lo);
@@ -265,11 +294,10 @@ __global__ __launch_bounds__(kBlockThreads, GJ_LB) void welch_kernel(const uint8
         }
         if (active) {
 #pragma unroll
-#if GJ_W_PKACC
-            for (int s = 0; s < 16; ++s) acc_sq(acc[s], v[s]);
-#else
-            for (int s = 0; s < 16; ++s) acc[s] = fmaf(v[s].x, v[s].x, fmaf(v[s].y, v[s].y, acc[s]));
-#endif
+            for (int s = 0; s < 16; ++s) {
+                if constexpr (Cfg::pkacc) acc_sq(accp[s], v[s]);
+                else accs[s] = fmaf(v[s].x, v[s].x, fmaf(v[s].y, v[s].y, accs[s]));
+            }
         }
         GJ_STAMP(t_it3);
         GJ_STAMP_ADD(5, t_it2, t_it3);   // detrend fix + |X|^2
@@ -285,11 +313,10 @@ __global__ __launch_bounds__(kBlockThreads, GJ_LB) void welch_kernel(const uint8
 #endif
     float* out = partial + ((size_t)blockIdx.x * B + b) * N + jl;
 #pragma unroll
-#if GJ_W_PKACC
-    for (int s = 0; s < 16; ++s) out[TF * s] = acc[s].x + acc[s].y;
-#else
-    for (int s = 0; s < 16; ++s) out[TF * s] = acc[s];
-#endif
+    for (int s = 0; s < 16; ++s) {
+        if constexpr (Cfg::pkacc) out[TF * s] = accp[s].x + accp[s].y;
+        else out[TF * s] = accs[s];
+    }
 }
 
 __global__ __launch_bounds__(256) void welch_finalize_kernel(const float* __restrict__ partial, int n, unsigned per_chunk,
@@ -335,7 +362,7 @@ static bool welch_plan(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int npe
     // Workgroups per chunk: 2 workgroups are resident per CU (VGPR-limited), the grid runs in
     // ceil(workgroups / slots) rounds of about (steps per workgroup + start-up) each, and a
     // nearly empty last round is pure loss -- pick the split that minimises rounds x length.
-    const size_t slots = (size_t)ctx->num_cus * 2;
+    const size_t slots = (size_t)ctx->num_cus * (welch_occ3(nperseg) ? 3 : 2);
     size_t cap = pl.g.nseg_full / (2 * (size_t)pl.batch);   // at least ~2 steps per workgroup
     if (cap < 1) cap = 1;
     if (cap > 256) cap = 256;
