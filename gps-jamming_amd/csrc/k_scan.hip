@@ -751,6 +751,20 @@ __device__ __forceinline__ float amp_of_pair(unsigned iq16) {   // iq16 = I | Q 
     return __fsqrt_rn((float)m) * (1.0f / 255.0f);
 }
 
+// Same value for sample `HI` (0: bytes 0-1, 1: bytes 2-3) of the dword w, in three integer
+// instructions instead of seven: v_perm_b32 spreads (I, Q) into the two 16-bit halves,
+// v_pk_mad_i16 forms (2I-255, 2Q-255), v_dot2_i32_i16 squares and adds.  k2 = 0x00020002,
+// km255 = 0xFF01FF01 (packed -255) are loop-invariant registers.
+template <int HI>
+__device__ __forceinline__ float amp_of_half(unsigned w, unsigned k2, unsigned km255) {
+    const unsigned spread = __builtin_amdgcn_perm(w, w, HI ? 0x0C030C02u : 0x0C010C00u);
+    unsigned h;
+    int m;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(h) : "v"(spread), "v"(k2), "v"(km255));
+    asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(m) : "v"(h));
+    return __fsqrt_rn((float)m) * (1.0f / 255.0f);
+}
+
 template <bool TRACK_FIRST>
 __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
                                                                    size_t nbytes, size_t chunk_bytes,
@@ -774,6 +788,8 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
     double sum = 0.0;
     long long first = 0x7fffffffffffffffll;
     const bool in_noise = b0 < noise_bytes;                        // tile touches the K4 noise span
+    unsigned k2 = 0x00020002u, km255 = 0xFF01FF01u;
+    asm volatile("" : "+v"(k2), "+v"(km255));                      // keep both in VGPRs (one constant-bus slot per op)
     auto body = [&](const uint4& q, size_t i) {
         unsigned v2 = 0, v1 = 0;
         acc_moments(q, v2, v1);
@@ -787,7 +803,7 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
         float part = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float a0 = amp_of_pair(ws[k] & 0xffffu), a1 = amp_of_pair(ws[k] >> 16);
+            const float a0 = amp_of_half<0>(ws[k], k2, km255), a1 = amp_of_half<1>(ws[k], k2, km255);
             part += a0;
             part += a1;
             if constexpr (TRACK_FIRST) {
