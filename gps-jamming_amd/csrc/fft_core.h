@@ -528,20 +528,43 @@ GJ_HD void load_twiddles(c2* tw, const cf* table, int jl) {
         for (int t = 1; t < R; ++t) tw[u * (R - 1) + t - 1] = to_c2(table[twiddle_index<N, PASS>(jl, u, t)]);
 }
 
+// The slot of index i0 + c is slot(i0) + c + c/16 whenever c is a multiple of 16 (adding a
+// multiple of 16 leaves the low four bits alone), so every address below is written as
+// "slot of the thread's own base index + compile-time constant" explicitly -- hipcc does not
+// derive that from (i0 + c) >> 4 by itself and otherwise spends a VGPR per address.
 template <int N, int PASS>
 GJ_HD void lds_scatter(const c2 (&v)[16], cf* lds, int base, int jl) {
     constexpr int R = fft_radix(N, PASS);
     constexpr int G = 16 / R;
+    constexpr int NS = fft_ns(N, PASS);
 #pragma unroll
-    for (int u = 0; u < G; ++u)
+    for (int u = 0; u < G; ++u) {
+        if constexpr (NS % 16 == 0) {
+            const int s0 = lds_slot(base, out_index<N, PASS>(jl, u, 0));
 #pragma unroll
-        for (int t = 0; t < R; ++t) lds[lds_slot(base, out_index<N, PASS>(jl, u, t))] = to_cf(v[u + t * G]);
+            for (int t = 0; t < R; ++t) lds[s0 + t * NS + t * NS / 16] = to_cf(v[u + t * G]);
+        } else if constexpr (NS == 1 && R == 16) {
+            const int s0 = lds_slot(base, out_index<N, PASS>(jl, u, 0));   // index 16 q: slot 17 q
+#pragma unroll
+            for (int t = 0; t < R; ++t) lds[s0 + t] = to_cf(v[u + t * G]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < R; ++t) lds[lds_slot(base, out_index<N, PASS>(jl, u, t))] = to_cf(v[u + t * G]);
+        }
+    }
 }
 
 template <int N>
 GJ_HD void lds_gather(c2 (&v)[16], const cf* lds, int base, int jl) {
+    constexpr int TF = N / 16;
+    if constexpr (TF % 16 == 0) {
+        const int s0 = lds_slot(base, jl);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) v[s] = to_c2(lds[lds_slot(base, jl + (N / 16) * s)]);
+        for (int s = 0; s < 16; ++s) v[s] = to_c2(lds[s0 + TF * s + TF * s / 16]);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) v[s] = to_c2(lds[lds_slot(base, jl + TF * s)]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -42,11 +42,12 @@
 // +32 VALU instructions per step, but a third wave per SIMD to fill the issue slots -- a wave
 // issues at most one instruction every ~5 cycles, whatever its kind).  Measured on MI355X, 1 GiB,
 // same box, two-workgroup shape -> three-workgroup shape:
-//   N = 4096  1.296 -> 1.216 ms    256  0.975 -> 0.939    128  1.055 -> 1.042    64  1.278 -> 1.207
-//   N = 32    2.160 -> 2.119       16   1.673 -> 1.695 (kept)
-//   N = 512   1.217 -> 1.571, 1024  1.278 -> 1.868, 2048  1.290 -> 2.129: their last pass needs
-//   more twiddle registers and the 168-VGPR shape spills -> they keep two workgroups per CU.
-#define GJ_W_OCC3_MASK 0x11E0u
+//   N = 4096  1.328 -> 1.257 ms   2048  1.348 -> 1.320   1024  1.284 -> 1.211   512  1.242 -> 1.142
+//   N = 256   1.001 -> 0.960      128   1.055 -> 1.042   64    1.278 -> 1.207   32   2.160 -> 2.119
+//   N = 16    1.669 -> 1.707 (stays in the two-workgroup shape)
+// (512..2048 fit 168 VGPRs only since the exchange addresses are written as base + constant,
+// fft_core.h lds_scatter/lds_gather: 236-246 -> 192-206 VGPRs in the two-workgroup shape.)
+#define GJ_W_OCC3_MASK 0x1FE0u
 #endif
 #ifndef GJ_W_XPOSE
 #define GJ_W_XPOSE 1     // 1: N = 4096 uses the bank-conflict-free exchange schedule (fft_core.h X4096)
