@@ -4,6 +4,10 @@
 #include <new>
 #include <vector>
 
+#include <atomic>
+#include <thread>
+#include <vector>
+
 #include "gj_common.h"
 
 namespace gj {
@@ -125,7 +129,7 @@ int gj_destroy(gj_ctx* ctx) {
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->stage) (void)hipFree(ctx->stage);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < gj_ctx::kPinBufs; ++k) {
         if (ctx->pin[k]) (void)hipHostFree(ctx->pin[k]);
         if (ctx->pin_ev[k]) (void)hipEventDestroy(ctx->pin_ev[k]);
     }
@@ -333,6 +337,11 @@ int gj_synth_u8_dev(gj_ctx* ctx, const gj_synth_params* params, int64_t first_sa
 constexpr size_t kPinBytes = 32u << 20;
 constexpr size_t kPinThreshold = 64u << 20;
 
+// Host buffer -> ctx->stage.  Large pageable buffers go through pinned bounce buffers: kFillThreads
+// host threads each copy their share of 32-MiB pieces into their own pair of pinned buffers and
+// queue the DMA (one memcpy thread tops out at ~31 GB/s end to end, below what the link carries).
+constexpr int kFillThreads = gj_ctx::kPinBufs / 2;
+
 static int stage_in(gj_ctx* ctx, const uint8_t* host, size_t nbytes, size_t offset = 0) {
     int rc = ensure_stage(ctx, offset + align_up(nbytes, 256) + 256);
     if (rc) return rc;
@@ -341,22 +350,34 @@ static int stage_in(gj_ctx* ctx, const uint8_t* host, size_t nbytes, size_t offs
         GJ_HIP(ctx, hipMemcpyAsync(ctx->stage + offset, host, nbytes, hipMemcpyHostToDevice, ctx->stream));
         return GJ_OK;
     }
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < gj_ctx::kPinBufs; ++k) {
         if (!ctx->pin[k]) GJ_HIP(ctx, hipHostMalloc(&ctx->pin[k], kPinBytes, hipHostMallocDefault));
         if (!ctx->pin_ev[k]) GJ_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_ev[k], hipEventDisableTiming));
     }
-    size_t piece = 0;
-    for (size_t off = 0; off < nbytes; off += kPinBytes, ++piece) {
-        const size_t len = (nbytes - off < kPinBytes) ? nbytes - off : kPinBytes;
-        const int b = (int)(piece & 1);
-        if (piece >= 2) GJ_HIP(ctx, hipEventSynchronize(ctx->pin_ev[b]));   // its previous DMA has drained
-        memcpy(ctx->pin[b], host + off, len);
-        GJ_HIP(ctx, hipMemcpyAsync(ctx->stage + offset + off, ctx->pin[b], len, hipMemcpyHostToDevice, ctx->stream));
-        GJ_HIP(ctx, hipEventRecord(ctx->pin_ev[b], ctx->stream));
-    }
-    // the bounce buffers are reused by the next call: make sure the tail pieces have left them
-    GJ_HIP(ctx, hipEventSynchronize(ctx->pin_ev[0]));
-    GJ_HIP(ctx, hipEventSynchronize(ctx->pin_ev[1]));
+    const size_t npieces = (nbytes + kPinBytes - 1) / kPinBytes;
+    const int nthreads = (int)(npieces < (size_t)kFillThreads ? npieces : (size_t)kFillThreads);
+    std::atomic<int> failed{0};
+    auto fill = [&](int t) {
+        if (hipSetDevice(ctx->device) != hipSuccess) { failed.store(1); return; }
+        size_t mine = 0;
+        for (size_t piece = (size_t)t; piece < npieces; piece += (size_t)nthreads, ++mine) {
+            const size_t off = piece * kPinBytes;
+            const size_t len = (nbytes - off < kPinBytes) ? nbytes - off : kPinBytes;
+            const int b = 2 * t + (int)(mine & 1);
+            if (mine >= 2 && hipEventSynchronize(ctx->pin_ev[b]) != hipSuccess) { failed.store(1); return; }
+            memcpy(ctx->pin[b], host + off, len);
+            if (hipMemcpyAsync(ctx->stage + offset + off, ctx->pin[b], len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                hipEventRecord(ctx->pin_ev[b], ctx->stream) != hipSuccess) { failed.store(1); return; }
+        }
+        // the bounce buffers are reused by the next call: the tail pieces must have left them
+        for (int k = 0; k < 2; ++k)
+            if (mine > (size_t)k && hipEventSynchronize(ctx->pin_ev[2 * t + k]) != hipSuccess) failed.store(1);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(fill, t);
+    fill(0);
+    for (auto& th : pool) th.join();
+    if (failed.load()) return fail(ctx, GJ_ERR_HIP, "host-to-device staging failed");
     return GJ_OK;
 }
 
