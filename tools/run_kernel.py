@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(REPO, "gps-jamming_amd"))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["welch", "scan", "fscan", "thr", "xcorr", "k1", "k3", "k4"])
+    ap.add_argument("what", choices=["welch", "scan", "fscan", "thr", "xcorr", "xcorr3", "k1", "k3", "k4"])
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--nperseg", type=int, default=4096)
     ap.add_argument("--bytes", type=int, default=1 << 30)
@@ -38,6 +38,8 @@ def main():
     d_amp, d_on = dev.alloc(32), dev.alloc(16)
     d_starts, d_lags, d_peaks = dev.alloc(16), dev.alloc(4), dev.alloc(4)
     d_starts.upload(np.array([int(0.4 * ns), int(0.4 * ns) + 3], np.int64))
+    d_starts3, d_lags3, d_peaks3 = dev.alloc(24), dev.alloc(12), dev.alloc(12)
+    d_starts3.upload(np.array([int(0.4 * ns), int(0.4 * ns) + 3, int(0.4 * ns) - 5], np.int64))
 
     def once():
         if args.what == "welch":
@@ -57,6 +59,9 @@ def main():
             dev.power_threshold_dev(d_pow, nch, d_stats, d_mask)
             dev.amp_stats_dev(cap, nbytes, 0.0, d_amp)
             dev.onset_dev(cap, nbytes, 200000, 1000, 50.0, d_on)
+        elif args.what == "xcorr3":   # BASELINE configs[3]: 3 antennas, pairs (0,1), (0,2), (1,2), N = 2^19
+            dev.xcorr_lags_dev([cap, cap, cap], [nbytes] * 3, d_starts3, 1 << 19, [(0, 1), (0, 2), (1, 2)],
+                               d_lags3, d_peaks3)
         else:
             dev.xcorr_lags_dev([cap, cap], [nbytes, nbytes], d_starts, 1 << 19, [(0, 1)], d_lags, d_peaks)
 
@@ -71,6 +76,8 @@ def main():
         extra = f" onset={d_on.download(np.int64, 1)[0]}"
     if args.what == "xcorr":
         extra = f" lag={d_lags.download(np.int32)[0]}"
+    if args.what == "xcorr3":
+        extra = f" lags={d_lags3.download(np.int32).tolist()} (195 MiB four-step floor -> {195 * 1.048576 / ms:.0f} GB/s)"
     print(f"{args.what}: {ms:.4f} ms per repetition over {nbytes} bytes -> {nbytes / ms / 1e6:.1f} GB/s algorithmic{extra}")
     dev.close()
 
