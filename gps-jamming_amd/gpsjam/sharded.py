@@ -137,9 +137,12 @@ class AntennaStream:
             overlap = capture.is_cuda and hasattr(dev, "_ctx")
         self.overlap = bool(overlap)
         self.dev_side = dev
+        if capture.is_cuda and hasattr(dev, "_ctx"):
+            # the pipeline's torch ops, its events and the gpsjam kernels must share one stream
+            self._main = torch.cuda.current_stream(capture.device)
+            dev.set_stream(self._main.cuda_stream)
         if self.overlap:
             self.dev_side = type(dev)(dev.index)
-            self._main = torch.cuda.current_stream(capture.device)
             self._side = torch.cuda.Stream(device=capture.device)
             self.dev_side.set_stream(self._side.cuda_stream)
             self._ev_free = torch.cuda.Event()      # main: previous results consumed, buffers may be rewritten

@@ -51,7 +51,8 @@ def test_antenna_stream_single_gpu():
     dev.close()
 
 
-def test_antenna_stream_overlap_matches_single_stream():
+@pytest.mark.parametrize("own_stream", [True, False])
+def test_antenna_stream_overlap_matches_single_stream(own_stream):
     """Two-stream pipeline (scan / threshold / TDOA beside K2) against the single-stream order,
     several steps back to back: the result vector must not depend on the overlap and must not
     change from step to step (the cross-step events keep pack and the next scan apart)."""
@@ -63,9 +64,12 @@ def test_antenna_stream_overlap_matches_single_stream():
     n = 3_000_000
     raw = generate(StreamSpec(seed=5, antenna=1, delay=2, jam_start=1_200_000, jam_end=2_100_000, jam_sigma=50.0), n)
     dev = gpsjam.Device(0)
-    work = torch.cuda.Stream()
-    torch.cuda.set_stream(work)
-    dev.set_stream(work.cuda_stream)
+    if own_stream:
+        work = torch.cuda.Stream()
+        torch.cuda.set_stream(work)
+        dev.set_stream(work.cuda_stream)
+    else:                                   # torch's default stream, context never told about it
+        torch.cuda.set_stream(torch.cuda.default_stream())
     cap = torch.from_numpy(raw).cuda()
     vecs = {}
     for overlap in (False, True):
