@@ -331,6 +331,20 @@ __device__ __forceinline__ float amp_of(unsigned i8, unsigned q8) {
     return __fsqrt_rn((float)(vi * vi + vq * vq)) * (1.0f / 255.0f);
 }
 
+// amp_of for sample `HI` (0: bytes 0-1, 1: bytes 2-3) of the dword w, in three integer
+// instructions instead of seven: v_perm_b32 spreads (I, Q) into the two 16-bit halves,
+// v_pk_mad_i16 forms (2I-255, 2Q-255), v_dot2_i32_i16 squares and adds.  k2 = 0x00020002,
+// km255 = 0xFF01FF01 (packed -255) are loop-invariant registers.
+template <int HI>
+__device__ __forceinline__ float amp_of_half(unsigned w, unsigned k2, unsigned km255) {
+    const unsigned spread = __builtin_amdgcn_perm(w, w, HI ? 0x0C030C02u : 0x0C010C00u);
+    unsigned h;
+    int m;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(h) : "v"(spread), "v"(k2), "v"(km255));
+    asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(m) : "v"(h));
+    return __fsqrt_rn((float)m) * (1.0f / 255.0f);
+}
+
 constexpr size_t kAmpTileSamples = kScanTile / 2;
 
 struct AmpTile {
@@ -351,6 +365,8 @@ __global__ __launch_bounds__(kScanThreads) void amp_tiles_kernel(const uint8_t* 
     const bool aligned = ((reinterpret_cast<uintptr_t>(iq) & 15) == 0);
     const size_t nfull = aligned ? ((s1 - s0) >> 3) : 0;   // groups of 8 samples = 16 bytes
     const uint4* v = reinterpret_cast<const uint4*>(iq + 2 * s0);
+    unsigned k2 = 0x00020002u, km255 = 0xFF01FF01u;
+    asm volatile("" : "+v"(k2), "+v"(km255));   // both in VGPRs (one constant-bus slot per op)
     for (size_t gidx = tid; gidx < nfull; gidx += kScanThreads) {
         const uint4 w = v[gidx];
         const unsigned ws[4] = {w.x, w.y, w.z, w.w};
@@ -358,8 +374,7 @@ __global__ __launch_bounds__(kScanThreads) void amp_tiles_kernel(const uint8_t* 
         const long long base = (long long)(s0 + gidx * 8);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float a0 = amp_of(ws[k] & 255u, (ws[k] >> 8) & 255u);
-            const float a1 = amp_of((ws[k] >> 16) & 255u, ws[k] >> 24);
+            const float a0 = amp_of_half<0>(ws[k], k2, km255), a1 = amp_of_half<1>(ws[k], k2, km255);
             part += a0;
             part += a1;
             if (a0 > thr && base + 2 * k < first) first = base + 2 * k;
@@ -748,20 +763,6 @@ __device__ __forceinline__ float amp_of_pair(unsigned iq16) {   // iq16 = I | Q 
     const gj_short2 u = __builtin_bit_cast(gj_short2, spread);
     const gj_short2 h = u * (short)2 - (short)255;                             // packed 16-bit: no borrow across halves
     const int m = __builtin_amdgcn_sdot2(h, h, 0, false);
-    return __fsqrt_rn((float)m) * (1.0f / 255.0f);
-}
-
-// Same value for sample `HI` (0: bytes 0-1, 1: bytes 2-3) of the dword w, in three integer
-// instructions instead of seven: v_perm_b32 spreads (I, Q) into the two 16-bit halves,
-// v_pk_mad_i16 forms (2I-255, 2Q-255), v_dot2_i32_i16 squares and adds.  k2 = 0x00020002,
-// km255 = 0xFF01FF01 (packed -255) are loop-invariant registers.
-template <int HI>
-__device__ __forceinline__ float amp_of_half(unsigned w, unsigned k2, unsigned km255) {
-    const unsigned spread = __builtin_amdgcn_perm(w, w, HI ? 0x0C030C02u : 0x0C010C00u);
-    unsigned h;
-    int m;
-    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(h) : "v"(spread), "v"(k2), "v"(km255));
-    asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(m) : "v"(h));
     return __fsqrt_rn((float)m) * (1.0f / 255.0f);
 }
 
