@@ -1,0 +1,23 @@
+"""The C-ABI consumed from plain C (tests/c_abi_smoke.c): gcc against include/gpsjam.h, linked
+with the in-tree libgpsjam_hip.so, run on the GPU."""
+import os
+import subprocess
+import tempfile
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_c_program_links_and_runs():
+    libdir = os.path.join(REPO, "gps-jamming_amd", "csrc")
+    assert os.path.exists(os.path.join(libdir, "libgpsjam_hip.so")), "build the library first (__graft_entry__.build())"
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "c_abi_smoke")
+        subprocess.run(["gcc", "-std=c11", "-O2", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"),
+                        os.path.join(REPO, "tests", "c_abi_smoke.c"), "-o", exe, "-L", libdir, "-lgpsjam_hip",
+                        "-lm", f"-Wl,-rpath,{libdir}"], check=True)
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "c_abi_smoke OK" in out.stdout
