@@ -187,6 +187,40 @@ __global__ __launch_bounds__(kBlockThreads) void xc_rows_kernel(XcParams P, cons
     }
 }
 
+// One pair only (the per-stream pipeline: this capture against the reference slice): the two
+// forward row transforms, the product conj(Z_j) Z_i and the inverse row transform of row k1 in ONE
+// kernel -- the spectra never go back to memory, one launch less on the tail after K2.
+__global__ __launch_bounds__(kBlockThreads) void xc_rows_pair_kernel(XcParams P, const cf* __restrict__ twtab,
+                                                                     const cf* __restrict__ spec, cf* __restrict__ dbuf) {
+    constexpr int N = kRow, TF = N / 16;
+    __shared__ cf lds[lds_span(kBlockPoints)];
+    const int jl = threadIdx.x;
+    const int r = blockIdx.x;   // k1
+    const cf* si = spec + (size_t)P.pair_i[0] * P.L + (size_t)r * N;
+    const cf* sj = spec + (size_t)P.pair_j[0] * P.L + (size_t)r * N;
+    c2 vi[16], vj[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) vi[s] = to_c2(si[jl + TF * s]);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) vj[s] = to_c2(sj[jl + TF * s]);
+    xc_passes<N, 0>(vi, lds, 0, jl, twtab);
+    xc_passes<N, 0>(vj, lds, 0, jl, twtab);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {   // conj(Z_j) * Z_i, same expression as xc_rows_kernel<1>
+        const c2 a = vj[s], bb = vi[s];
+        vi[s] = make_c2(a.x * bb.x + a.y * bb.y, a.x * bb.y - a.y * bb.x);
+    }
+    xc_passes<N, 0>(vi, lds, 0, jl, twtab);
+    cf* dst = dbuf + (size_t)r * N;
+    c2 w = twiddle_big((unsigned long long)r * jl, P.L);
+    const c2 step = twiddle_big(((unsigned long long)r * TF) & (P.L - 1), P.L);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        dst[jl + TF * s] = to_cf(cmul(vi[s], w));
+        w = cmul(w, step);
+    }
+}
+
 __global__ __launch_bounds__(256) void xc_finalize_kernel(XcParams P, const XcCand* __restrict__ cand, unsigned ncand,
                                                           const int* __restrict__ valid, int* __restrict__ lags,
                                                           float* __restrict__ peaks) {
@@ -293,12 +327,18 @@ int launch_xcorr(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, 
     GJ_LAUNCH_CHECK(ctx);
     xc_cols(ctx, 0, P, n_ant, eff, valid, spec, nullptr);
     GJ_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL((xc_rows_kernel<0>), dim3((unsigned)P.L1, (unsigned)n_ant), dim3(kBlockThreads), 0, ctx->stream,
-                       P, ctx->d_twiddle, spec, dbuf);
-    GJ_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL((xc_rows_kernel<1>), dim3((unsigned)P.L1, (unsigned)n_pairs), dim3(kBlockThreads), 0,
-                       ctx->stream, P, ctx->d_twiddle, spec, dbuf);
-    GJ_LAUNCH_CHECK(ctx);
+    if (n_pairs == 1) {
+        hipLaunchKernelGGL(xc_rows_pair_kernel, dim3((unsigned)P.L1), dim3(kBlockThreads), 0, ctx->stream, P, ctx->d_twiddle,
+                           spec, dbuf);
+        GJ_LAUNCH_CHECK(ctx);
+    } else {
+        hipLaunchKernelGGL((xc_rows_kernel<0>), dim3((unsigned)P.L1, (unsigned)n_ant), dim3(kBlockThreads), 0, ctx->stream,
+                           P, ctx->d_twiddle, spec, dbuf);
+        GJ_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL((xc_rows_kernel<1>), dim3((unsigned)P.L1, (unsigned)n_pairs), dim3(kBlockThreads), 0,
+                           ctx->stream, P, ctx->d_twiddle, spec, dbuf);
+        GJ_LAUNCH_CHECK(ctx);
+    }
     xc_cols(ctx, 1, P, n_pairs, eff, valid, dbuf, cand);
     GJ_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(xc_finalize_kernel, dim3((unsigned)n_pairs), dim3(256), 0, ctx->stream, P, cand, (unsigned)ncand,
