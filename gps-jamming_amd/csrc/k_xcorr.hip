@@ -87,20 +87,31 @@ __global__ __launch_bounds__(kBlockThreads) void xc_cols_kernel(XcParams P, cons
     if constexpr (MODE == 0) {
         const bool ok = valid[t] != 0;
         const uint16_t* src = reinterpret_cast<const uint16_t*>(P.iq[t]) + (ok ? eff[t] : 0);
+        // L <= 2^24: every index fits 32 bits.  Branch-free: out-of-slice points read the slice's
+        // first sample and are zeroed by a select (per-element branches made hipcc shuffle the
+        // whole register array through AGPRs: 4800 instructions, 236 VGPRs)
+        const unsigned nlim = ok ? (unsigned)P.n : 0u;
+        unsigned raw[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) raw[s] = 0u;
+        if (nlim) {   // workgroup-uniform: an invalid antenna's pointer is never dereferenced
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const unsigned n = (unsigned)(jl + TF * s) * (unsigned)kRow + (unsigned)n2;
+                raw[s] = src[n < nlim ? n : 0u];
+            }
+        }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const unsigned long long n = (unsigned long long)(jl + TF * s) * kRow + n2;
-            if (ok && n < P.n) {
-                const unsigned u = src[n];
-                v[s] = make_c2((float)(2 * (int)(u & 255u) - 255), (float)(2 * (int)(u >> 8) - 255));
-            } else {
-                v[s] = make_c2(0.f, 0.f);
-            }
+            const unsigned n = (unsigned)(jl + TF * s) * (unsigned)kRow + (unsigned)n2;
+            const unsigned u = raw[s];
+            const c2 x = make_c2((float)(2 * (int)(u & 255u) - 255), (float)(2 * (int)(u >> 8) - 255));
+            v[s] = (n < nlim) ? x : make_c2(0.f, 0.f);
         }
     } else {
         const cf* src = buf + (size_t)t * P.L;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) v[s] = to_c2(src[(size_t)(jl + TF * s) * kRow + n2]);
+        for (int s = 0; s < 16; ++s) v[s] = to_c2(src[(unsigned)(jl + TF * s) * (unsigned)kRow + (unsigned)n2]);
     }
     xc_passes<L1, 0>(v, lds, b * RS, jl, twtab);
     if constexpr (MODE == 0) {
@@ -110,8 +121,8 @@ __global__ __launch_bounds__(kBlockThreads) void xc_cols_kernel(XcParams P, cons
         const c2 step = twiddle_big(((unsigned long long)TF * n2) & (P.L - 1), P.L);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const int k1 = jl + TF * s;
-            dst[(size_t)k1 * kRow + n2] = to_cf(cmul(v[s], w));
+            const unsigned k1 = (unsigned)(jl + TF * s);
+            dst[k1 * (unsigned)kRow + (unsigned)n2] = to_cf(cmul(v[s], w));
             w = cmul(w, step);
         }
     } else {
