@@ -320,10 +320,11 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
     }
 }
 
-__global__ __launch_bounds__(256) void welch_finalize_kernel(const float* __restrict__ partial, int n, unsigned per_chunk,
-                                                             unsigned nchunks, float scale_full, float scale_last,
-                                                             int shift, float* __restrict__ psd,
-                                                             float* __restrict__ psd_db) {
+// one bin per thread: used when the caller's output arrays are not 16-byte aligned
+__global__ __launch_bounds__(256) void welch_finalize_scalar_kernel(const float* __restrict__ partial, int n,
+                                                                    unsigned per_chunk, unsigned nchunks, float scale_full,
+                                                                    float scale_last, int shift, float* __restrict__ psd,
+                                                                    float* __restrict__ psd_db) {
     const unsigned c = blockIdx.y;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -334,6 +335,31 @@ __global__ __launch_bounds__(256) void welch_finalize_kernel(const float* __rest
     const int o = shift ? ((k + n / 2) & (n - 1)) : k;
     psd[(size_t)c * n + o] = val;
     if (psd_db) psd_db[(size_t)c * n + o] = 10.0f * log10f(val + 1e-15f);
+}
+
+// four consecutive bins per thread: 16-byte loads of the partial rows, 16-byte stores
+__global__ __launch_bounds__(256) void welch_finalize_kernel(const float* __restrict__ partial, int n, unsigned per_chunk,
+                                                             unsigned nchunks, float scale_full, float scale_last,
+                                                             int shift, float* __restrict__ psd,
+                                                             float* __restrict__ psd_db) {
+    const unsigned c = blockIdx.y;
+    const int k = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (k >= n) return;
+    const float4* p = reinterpret_cast<const float4*>(partial + (size_t)c * per_chunk * n + k);
+    const size_t stride = (size_t)n / 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (unsigned i = 0; i < per_chunk; ++i) {   // fixed order: bit-identical from run to run
+        const float4 q = p[(size_t)i * stride];
+        s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+    }
+    const float sc = (c + 1 == nchunks) ? scale_last : scale_full;
+    const float4 val = make_float4(s.x * sc, s.y * sc, s.z * sc, s.w * sc);
+    const int o = shift ? ((k + n / 2) & (n - 1)) : k;   // n/2 is a multiple of 4: the group stays contiguous
+    *reinterpret_cast<float4*>(psd + (size_t)c * n + o) = val;
+    if (psd_db)
+        *reinterpret_cast<float4*>(psd_db + (size_t)c * n + o) =
+            make_float4(10.0f * log10f(val.x + 1e-15f), 10.0f * log10f(val.y + 1e-15f), 10.0f * log10f(val.z + 1e-15f),
+                        10.0f * log10f(val.w + 1e-15f));
 }
 
 struct WelchPlan {
@@ -433,9 +459,15 @@ int launch_welch(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_s
         default: welch_launch<4096>(ctx, d_iq, pl, partial); break;
     }
     GJ_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(welch_finalize_kernel, dim3((nperseg + 255) / 256, pl.g.nchunks), dim3(256), 0, ctx->stream,
-                       partial, nperseg, pl.g.splits * (unsigned)pl.batch, pl.g.nchunks, (float)pl.scale_full,
-                       (float)pl.scale_last, (flags & GJ_WELCH_SHIFT) ? 1 : 0, d_psd, d_psd_db);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(d_psd) | reinterpret_cast<uintptr_t>(d_psd_db)) & 15) == 0;
+    if (aligned)
+        hipLaunchKernelGGL(welch_finalize_kernel, dim3((nperseg / 4 + 255) / 256, pl.g.nchunks), dim3(256), 0, ctx->stream,
+                           partial, nperseg, pl.g.splits * (unsigned)pl.batch, pl.g.nchunks, (float)pl.scale_full,
+                           (float)pl.scale_last, (flags & GJ_WELCH_SHIFT) ? 1 : 0, d_psd, d_psd_db);
+    else
+        hipLaunchKernelGGL(welch_finalize_scalar_kernel, dim3((nperseg + 255) / 256, pl.g.nchunks), dim3(256), 0,
+                           ctx->stream, partial, nperseg, pl.g.splits * (unsigned)pl.batch, pl.g.nchunks,
+                           (float)pl.scale_full, (float)pl.scale_last, (flags & GJ_WELCH_SHIFT) ? 1 : 0, d_psd, d_psd_db);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
 }

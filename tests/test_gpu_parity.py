@@ -155,6 +155,24 @@ def test_k2_all_sizes_vs_oracle(dev, nperseg):
     np.testing.assert_array_equal(np.fft.fftshift(unshifted, axes=1), psd)
 
 
+def test_k2_unaligned_output_arrays(dev):
+    """Output arrays that are only 4-byte aligned take the one-bin-per-thread finalize; same values
+    as the 16-byte (float4) path."""
+    raw = generate(StreamSpec(seed=31, jam_start=20000, jam_end=70000, jam_sigma=35.0), 150000)
+    nperseg, chunk = 1024, 50000
+    rows = dev.welch_rows(raw.size, chunk, nperseg)
+    d_iq = dev.alloc(raw.size).upload(raw)
+    a_psd, a_db = dev.alloc(4 * rows * nperseg), dev.alloc(4 * rows * nperseg)
+    u_psd, u_db = dev.alloc(4 * rows * nperseg + 16), dev.alloc(4 * rows * nperseg + 16)
+    dev.welch_dev(d_iq, raw.size, chunk, nperseg, 2.048e6, a_psd, a_db)
+    dev.welch_dev(d_iq, raw.size, chunk, nperseg, 2.048e6, u_psd.ptr + 4, u_db.ptr + 4)
+    dev.synchronize()
+    np.testing.assert_array_equal(u_psd.download(np.float32)[1:1 + rows * nperseg], a_psd.download(np.float32))
+    np.testing.assert_array_equal(u_db.download(np.float32)[1:1 + rows * nperseg], a_db.download(np.float32))
+    lin, _, _ = orc.widmo_waterfall(raw, nperseg=nperseg, chunk_samples=chunk)
+    assert rel_err(a_psd.download(np.float32).reshape(rows, nperseg), lin) < 1e-4
+
+
 def test_k2_partial_chunk_rule(dev):
     nperseg = 1024
     base = generate(StreamSpec(seed=9), 3000)
