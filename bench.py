@@ -122,8 +122,7 @@ def main():
         stream.welch()                  # K2
         ev[k][1].record()
         stream.tdoa()
-        from gpsjam.sharded import gather_results
-        gathered = gather_results(stream.pack(), rank, world, 0)
+        gathered = stream.exchange(0)   # pack (after the join) + RCCL gather, issued on the second stream
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()

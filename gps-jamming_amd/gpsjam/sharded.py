@@ -167,7 +167,13 @@ class AntennaStream:
         self.peak = torch.zeros(1, dtype=torch.float32, device=d)
         self.ref_slice = torch.zeros(slice_samples, dtype=torch.int16, device=d)
         self._ar = torch.arange(slice_samples, dtype=torch.int64, device=d)
-        self.result = torch.zeros(result_len(self.n_chunks, nperseg), dtype=torch.float64, device=d)
+        # two result vectors, used alternately: the gather of step k (second stream) may still be
+        # reading one while step k + 1 packs into the other
+        self._results = [torch.zeros(result_len(self.n_chunks, nperseg), dtype=torch.float64, device=d) for _ in range(2)]
+        self._result_idx = 0
+        self.result = self._results[0]
+        if self.overlap:
+            self._ev_packed = torch.cuda.Event()
         self.cap16 = capture.view(torch.int16)
         ws_side = max(dev.xcorr_workspace(2, slice_samples, 1), self.nbytes // 48 + (1 << 20))
         ws_main = dev.welch_workspace(self.nbytes, chunk_samples, nperseg)
@@ -229,14 +235,32 @@ class AntennaStream:
         """Result vector of this stream, built by one kernel (layout = pack_results)."""
         if self.overlap:
             self._main.wait_event(self._ev_side)
+        self._result_idx ^= 1
+        self.result = self._results[self._result_idx]
         self.dev.pack_result_dev(self.n_chunks, self.power, self.stats, self.amp, self.onset, self.lag, self.peak,
                                  self.psd, self.rows, self.nperseg, self.rank, self.result)
         if self.overlap:
             self._ev_free.record(self._main)
+            self._ev_packed.record(self._main)
         return self.result
+
+    def exchange(self, dst: int = 0) -> Optional[List[torch.Tensor]]:
+        """Pack this step's result vector and gather every rank's on ``dst``.  With two streams the
+        collective is issued on the second one (after the packing kernel), so the main stream goes
+        straight on to the next step's K2 instead of waiting for the gather; the next step's scan
+        follows the gather in stream order, and a result buffer is rewritten only two steps later,
+        after a join that lies behind it."""
+        vec = self.pack()
+        if self.world == 1:
+            return [vec]
+        if not self.overlap:
+            return gather_results(vec, self.rank, self.world, dst)
+        self._side.wait_event(self._ev_packed)
+        with torch.cuda.stream(self._side):
+            return gather_results(vec, self.rank, self.world, dst)
 
     def step(self):
         """One pass of the hot path over this rank's capture + the exchange."""
         self.scan()
         self.tdoa()
-        return gather_results(self.pack(), self.rank, self.world, 0)
+        return self.exchange(0)
