@@ -49,6 +49,9 @@
 // fft_core.h lds_scatter/lds_gather: 236-246 -> 192-206 VGPRs in the two-workgroup shape.)
 #define GJ_W_OCC3_MASK 0x1FE0u
 #endif
+#ifndef GJ_W_HALFSUM
+#define GJ_W_HALFSUM 1   // 1: (one transform per workgroup) half-segment sums carried from step to step
+#endif
 #ifndef GJ_W_XPOSE
 #define GJ_W_XPOSE 1     // 1: N = 4096 uses the bank-conflict-free exchange schedule (fft_core.h X4096)
 #endif
@@ -177,8 +180,10 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
     constexpr int SPAN = XP ? X4096::kSpan : lds_span(kBlockPoints);
     __shared__ cf lds0[SPAN];
     using Cfg = WelchCfg<N>;
+    constexpr bool HS = (B == 1) && (GJ_W_HALFSUM != 0);
     __shared__ cf lds1[Cfg::dbuf ? SPAN : 1];
-    __shared__ float wsum[2][B][WPF][2];
+    // (sum I, sum Q) per wave; three slots when half-segment sums are carried over (see HS below)
+    __shared__ float wsum[3][B][WPF][2];
     const int tid = threadIdx.x;
     const int b = tid / TF, jl0 = tid % TF;   // jl0: butterfly of pass 0 (input index jl0 + TF s)
     const int jl = XP ? X4096::jl1(tid) : jl0;   // butterfly of the later passes = bins held at the end
@@ -234,6 +239,7 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
     unsigned raw[16];
     load_step(raw, (seg_lo + b < seg_hi) ? seg_lo + b : seg_lo);
     unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    [[maybe_unused]] unsigned ws_cur = 0, ws_prv = 2;   // HS: slot of this step's half-sum / of the previous step's
     GJ_STAMP(t_begin);
     for (unsigned it = 0; it < nsteps; ++it) {
         GJ_STAMP(t_it0);
@@ -241,6 +247,20 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
         const bool active = seg < seg_hi;
         c2 v[16];
         if (!GJ_W_PREFETCH && it > 0) load_step(raw, active ? seg : seg_lo);
+        // HS (one transform per workgroup = consecutive segments per step): the first half of a
+        // segment is the second half of the previous one, so only the second half is summed each
+        // step and the previous step's half-sum is read back from its slot (eight packed adds less)
+        const unsigned cur = HS ? ws_cur : (it & 1), prv = HS ? ws_prv : 0;
+        if (HS && it == 0) {   // first step of the workgroup: the first half has no predecessor
+            c2 flo = make_c2(0.f, 0.f);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) flo = cadd(flo, make_c2((float)(raw[s] & 255u), (float)((raw[s] >> 8) & 255u)));
+            const float li = group_sum_dpp_f<64>(flo.x), lq = group_sum_dpp_f<64>(flo.y);
+            if ((tid & 63) == 0) {
+                wsum[prv][b][(tid >> 6) % WPF][0] = li;
+                wsum[prv][b][(tid >> 6) % WPF][1] = lq;
+            }
+        }
         c2 fsum = make_c2(0.f, 0.f);   // (sum I, sum Q) of the raw bytes: integers < 2^24, exact in f32
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -250,7 +270,7 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
                 v[s] = (s & 1) ? scale_hi(cadd(f, khalf), w2p[s >> 1]) : scale_lo(cadd(f, khalf), w2p[s >> 1]);
             else
                 v[s] = (s & 1) ? fma_hi(f, w2p[s >> 1], wcp[s >> 1]) : fma_lo(f, w2p[s >> 1], wcp[s >> 1]);
-            fsum = cadd(fsum, f);
+            if (!HS || s >= 8) fsum = cadd(fsum, f);
         }
         if (GJ_W_PREFETCH) load_step(raw, (seg + B < seg_hi) ? seg + B : seg_lo);
         float si, sq;
@@ -258,8 +278,8 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
             si = group_sum_dpp_f<64>(fsum.x);   // wave-uniform
             sq = group_sum_dpp_f<64>(fsum.y);
             if ((tid & 63) == 0) {
-                wsum[it & 1][b][(tid >> 6) % WPF][0] = si;
-                wsum[it & 1][b][(tid >> 6) % WPF][1] = sq;
+                wsum[cur][b][(tid >> 6) % WPF][0] = si;
+                wsum[cur][b][(tid >> 6) % WPF][1] = sq;
             }
         } else {
             si = group_sum_dpp_f<TF>(fsum.x);
@@ -277,7 +297,11 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
             if (jl <= 1 || jl == TF - 1) {
                 si = 0.f; sq = 0.f;
 #pragma unroll
-                for (int k = 0; k < WPF; ++k) { si += wsum[it & 1][b][k][0]; sq += wsum[it & 1][b][k][1]; }
+                for (int k = 0; k < WPF; ++k) { si += wsum[cur][b][k][0]; sq += wsum[cur][b][k][1]; }
+                if constexpr (HS) {
+#pragma unroll
+                    for (int k = 0; k < WPF; ++k) { si += wsum[prv][b][k][0]; sq += wsum[prv][b][k][1]; }
+                }
             }
         }
         const float Sx = fmaf(2.0f, si, -255.0f * N), Sy = fmaf(2.0f, sq, -255.0f * N);   // sum of (2u - 255)
@@ -302,6 +326,7 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
         }
         GJ_STAMP(t_it3);
         GJ_STAMP_ADD(5, t_it2, t_it3);   // detrend fix + |X|^2
+        if constexpr (HS) { ws_prv = ws_cur; ws_cur = (ws_cur == 2) ? 0 : ws_cur + 1; }
     }
 #ifdef GJ_STAMPS
     {
