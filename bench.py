@@ -6,23 +6,32 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one synthetic antenna capture per GPU
-(BASELINE.json configs[1], one stream per rank = configs[4] for N > 1):
+(BASELINE.json configs[1]; one stream per rank = configs[4] for N > 1):
   one fused HBM pass for K1 per-chunk power (+ 5th-percentile/+6 dB threshold), K3 amplitude
-  statistics and K4 onset; K2 fused unpack + 4096-pt Welch PSD (1-s chunks); K5 2^20-pt FFT
-  cross-correlation of the rank's onset-aligned 2^19-sample slice against the reference
-  antenna's slice (rank 0, broadcast over RCCL), then an RCCL gather of the per-stream result
-  vector to rank 0.  K2 (VALU/LDS bound) runs on one HIP stream, the HBM-bound scan and the
-  TDOA kernels concurrently on a second one; they join before the result is packed.
+  statistics and K4 onset; K2 fused unpack + 4096-pt Welch PSD (1-s chunks); the rank's
+  onset-aligned 2^19-sample slice cut into a TDOA slot; the slots gathered to rank 0 (RCCL),
+  which solves EVERY antenna pair with one multi-pair K5 launch (2^20-pt FFT
+  cross-correlations); a second RCCL gather of the per-stream result vectors to rank 0.
+  At N = 1 the K5 solve is BASELINE configs[3]: this capture's slot against the slots of two
+  further antennas (prepared before the timed region, as if gathered) = 3 antennas, 3 pairs.
+  K2 (VALU/LDS bound) runs on one HIP stream, the HBM-bound scan, the gathers and K5
+  concurrently on a second one; they join before the result vector is packed.
 Captures are generated in HBM before the timed region (2^30 bytes = 536 870 912 I/Q samples
 per GPU, integer-only generator, seeds 1234 + rank) -- inputs are resident when timing starts.
 
 Rank 0 prints ONE JSON line.  ``roofline`` is for the dominant kernel (K2 welch_kernel<4096>
 + its finalize): algorithmic bytes = 2 B x samples per launch, duration from HIP events
-recorded on the launch stream around every K2 launch of the timed steps.  ``cpu_baseline``
-(N = 1 only) times the numpy/scipy oracle (oracle/gpsjam_oracle.py, kind "port") on a
-bounded prefix of the same capture on the host's cores.
+recorded on the launch stream around every K2 launch of the timed steps; ``roofline_valu``
+prices the same launch against the measured VALU issue ceiling (what actually bounds it);
+``secondary`` holds the scan and the K5 solve.  ``self_check`` validates the gathered results
+against what the synthetic captures were built to contain (known delays, known burst span), so a
+wrong multi-GPU exchange cannot print a plausible number.  ``cpu_baseline`` times the
+numpy/scipy oracle (oracle/gpsjam_oracle.py, kind "port") on a bounded prefix of the same
+capture on the host's cores (one process per rank for N > 1).  ``end_to_end`` (N = 1) is the
+file / host buffer -> result rate with PCIe included; it is never ``value``.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -39,6 +48,14 @@ NPERSEG = 4096
 CHUNK_SAMPLES = 2048000
 SLICE = 1 << 19
 DELAYS = (0, 3, -5, 7, -2, 4, -6, 1)
+JAM_GAIN = (1.0, 0.7, 0.5, 0.8)
+JAM_SPAN = (0.4, 0.7)      # burst in source time, as fractions of the capture
+
+
+def stream_spec(StreamSpec, antenna, nsamp):
+    return StreamSpec(seed=1234, antenna=antenna, delay=DELAYS[antenna % len(DELAYS)],
+                      jam_start=int(JAM_SPAN[0] * nsamp), jam_end=int(JAM_SPAN[1] * nsamp), noise_sigma=6.25,
+                      jam_sigma=60.0 * JAM_GAIN[antenna % 4])
 
 
 def main():
@@ -48,21 +65,24 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--capture-bytes", type=int, default=CAPTURE_BYTES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--transport", default="torch", choices=("torch", "rccl"),
+                    help="collectives through torch.distributed, or through the library's own gj_comm_* (RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (with --backend gloo) on a one-GPU box")
     ap.add_argument("--precondition", type=int, default=30,
                     help="untimed steps run before the warm-up to settle clocks (not counted in --warmup)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the scan/TDOA kernels on the K2 stream instead of concurrently on a second one")
-    ap.add_argument("--cpu-sample-chunks", type=int, default=24,
-                    help="1-s chunks of the capture given to the CPU oracle (bounded sample)")
+    ap.add_argument("--cpu-sample-chunks", type=int, default=None,
+                    help="1-s chunks of the capture given to the CPU oracle (default 24 at N = 1, 8 per rank otherwise)")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import gpsjam
-    from gpsjam.sharded import AntennaStream, unpack_results
+    from gpsjam.sharded import AntennaStream
     from gpsjam.synth import StreamSpec
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -75,6 +95,7 @@ def main():
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if args.backend == "nccl":
@@ -91,11 +112,26 @@ def main():
     nbytes = args.capture_bytes
     nsamp = nbytes // 2
     cap = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    spec = StreamSpec(seed=1234, antenna=rank, delay=DELAYS[rank % len(DELAYS)], jam_start=int(0.4 * nsamp),
-                      jam_end=int(0.7 * nsamp), noise_sigma=6.25, jam_sigma=60.0 * (1.0, 0.7, 0.5, 0.8)[rank % 4])
-    dev.synth_dev(spec, nsamp, cap)
+    dev.synth_dev(stream_spec(StreamSpec, rank, nsamp), nsamp, cap)
+
+    # N = 1: the slots of antennas 1 and 2 (BASELINE configs[3]), cut by the same kernels from their
+    # own captures before the timed region -- on N ranks they would arrive through the slot gather
+    aux, aux_onsets = None, []
+    if world == 1:
+        sb = dev.tdoa_slot_bytes(SLICE)
+        aux = torch.zeros((2, sb), dtype=torch.uint8, device="cuda")
+        tmp = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        d_on = torch.zeros(4, dtype=torch.int64, device="cuda")
+        for a in (1, 2):
+            dev.synth_dev(stream_spec(StreamSpec, a, nsamp), nsamp, tmp)
+            dev.onset_dev(tmp, nbytes, 200000, 1000, 50.0, d_on)
+            dev.tdoa_slot_dev(tmp, nbytes, d_on, SLICE, aux[a - 1])
+            torch.cuda.synchronize()
+            aux_onsets.append(int(d_on[0].item()))
+        del tmp
     stream = AntennaStream(dev, cap, nperseg=NPERSEG, chunk_samples=CHUNK_SAMPLES, slice_samples=SLICE,
-                           rank=rank, world_size=world, overlap=not args.no_overlap)
+                           rank=rank, world_size=world, overlap=not args.no_overlap, aux_slots=aux,
+                           transport=args.transport)
     torch.cuda.synchronize()
 
     def barrier():
@@ -117,26 +153,43 @@ def main():
     gathered = None
     for k in range(args.steps):
         # the step, with HIP events on the launch stream around the dominant kernel
-        stream.stream_scan()            # K1 + K3 + K4 in one HBM pass, + noise-floor threshold
+        stream.stream_scan()            # K1 + K3 + K4 in one HBM pass, + noise-floor threshold (second stream)
         ev[k][0].record()
         stream.welch()                  # K2
         ev[k][1].record()
-        stream.tdoa()
-        gathered = stream.exchange(0)   # pack (after the join) + RCCL gather, issued on the second stream
+        stream.tdoa()                   # slot, slot gather, all-pairs K5 on rank 0 (second stream)
+        gathered = stream.exchange(0)   # pack (after the join) + result gather, issued on the second stream
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    # K2 alone (nothing else in flight), after the timed region: reported next to the as-run
-    # figure, which includes whatever the concurrently running scan/TDOA kernels cost it
-    solo = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
-    for a, b in solo:
-        a.record()
-        stream.welch()
-        b.record()
-    torch.cuda.synchronize()
-    solo_ms = sum(a.elapsed_time(b) for a, b in solo) / len(solo)
+    # solo figures (nothing else in flight), after the timed region: K2 next to its as-run figure,
+    # which includes whatever the concurrently running scan/TDOA kernels cost it; the scan and the K5 solve
+    def timed(fn, on, reps=5):
+        out = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            a.record(on)
+            fn()
+            b.record(on)
+            torch.cuda.synchronize()
+            out.append(a.elapsed_time(b))
+        return sum(out) / len(out)
+
+    side = stream._side
+    solo_ms = timed(stream.welch, work_stream)
+    scan_ms = timed(stream.stream_scan, side)
+    k5_ms = None
+    if stream.is_root and stream.pairs:
+        def k5():
+            with stream._on_side():
+                stream.dev_side.xcorr_slots_dev(stream.slots, stream.slot_bytes, stream.n_ant, SLICE, stream.pairs,
+                                                stream._lags[0], stream._peaks[0], stream._margins[0])
+        k5_ms = timed(k5, side)
+        stream.step()                   # leaves the result buffers as a step does
+        torch.cuda.synchronize()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -144,26 +197,46 @@ def main():
     elapsed = float(t.item())
     welch_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
 
+    # CPU baseline: every rank times the oracle on a prefix of ITS capture at the same moment
+    cpu = None
+    if not args.no_cpu_baseline:
+        chunks = args.cpu_sample_chunks or (24 if world == 1 else 8)
+        barrier()
+        cpu = cpu_baseline(np, cap, chunks, stream, gathered if rank == 0 else None, world)
+        if world > 1:
+            r = torch.tensor([cpu["value"]], dtype=torch.float64, device="cuda")
+            dist.all_reduce(r, op=dist.ReduceOp.SUM)
+            cpu["value"] = float(r.item())
+            cpu["cores"] = world
+            cpu["sample"] = f"{world} processes at once, one per capture, each: " + cpu["sample"]
+
     if rank == 0:
-        results = [unpack_results(v) for v in gathered]
+        results, tdoa = gathered.unpack()
         total_samples = float(nsamp) * world * args.steps
         value = total_samples / elapsed / 1e6
         achieved = (nbytes / 1e9) / (welch_ms / 1e3) if welch_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(nbytes)
+        pmc = pmc_summary(nbytes)
+        onsets = [r.onset for r in results] + aux_onsets
         line = {
             "metric": "Msamples/s uint8 I/Q through PSD+TDOA xcorr",
-            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "precondition_steps": args.precondition,
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "precondition_steps": args.precondition,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: fused uint8->complex64 + 4096-pt Welch PSD + jamming power "
-                                   "threshold on 1 GiB synthetic I/Q per GPU (+ K3 amp stats, K4 onset, "
-                                   "K5 2^20-pt xcorr vs reference antenna, RCCL gather)",
+                                   "threshold on 1 GiB synthetic I/Q per GPU (+ K3 amp stats, K4 onset, TDOA slot; "
+                                   + ("configs[3]: 3 antennas / 3 pairs 2^20-pt xcorr solve on this GPU)" if world == 1
+                                      else f"configs[4]: slots gathered over RCCL, all {len(tdoa.pairs)} pairs of "
+                                           f"{world} antennas solved on rank 0, result vectors gathered)"),
                        "capture_bytes_per_gpu": nbytes, "nperseg": NPERSEG, "chunk_samples": CHUNK_SAMPLES,
-                       "xcorr_slice": SLICE, "streams": world, "sharding": "one capture per GPU"},
+                       "xcorr_slice": SLICE, "xcorr_antennas": stream.n_ant, "xcorr_pairs": len(tdoa.pairs),
+                       "streams": world, "sharding": "one capture per GPU", "backend": args.backend if world > 1 else None,
+                       "transport": args.transport if world > 1 else None},
+            "rccl_ranks": world if (world > 1 and (args.backend == "nccl" or args.transport == "rccl")) else 0,
             "roofline": {"bound": "hbm", "kernel": "welch_kernel<4096> + welch_finalize_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-                         "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic"], "traffic_unit": "HBM bytes per launch",
+                         "traffic_source": pmc["source"], "traffic_measured_on_this_source": pmc["matches_build"],
                          "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": welch_ms,
                          "overlap": bool(stream.overlap),
                          "solo": {"avg_launch_ms": solo_ms, "achieved": (nbytes / 1e9) / (solo_ms / 1e3),
@@ -172,42 +245,188 @@ def main():
                                  "'achieved' is K2 as run in the timed steps, i.e. with the HBM-bound "
                                  "scan + TDOA kernels executing concurrently on a second stream when "
                                  "overlap is true; 'solo' is K2 with nothing else in flight"},
-            "results": {"lags": [r.lag for r in results], "onsets": [r.onset for r in results],
+            "roofline_valu": valu_roofline(pmc, welch_ms, solo_ms),
+            "secondary": {
+                "stream_scan_kernel (K1+K3+K4 fused) + threshold + tail kernels, solo": {
+                    "bound": "hbm", "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": scan_ms,
+                    "achieved": (nbytes / 1e9) / (scan_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": (nbytes / 1e9) / (scan_ms / 1e3) / HBM_PEAK_GBS},
+            },
+            "results": {"pairs": [list(p) for p in tdoa.pairs], "lags": tdoa.lags,
+                        "lag_margins": [round(m, 4) for m in tdoa.margins], "onsets": onsets,
                         "jamming_ranges_rank0": results[0].jamming_byte_ranges()[:4],
                         "baseline_rank0": results[0].baseline, "amp_mean": [r.amp_mean for r in results]},
+            "self_check": self_check(results, tdoa, onsets, nsamp, stream.n_ant),
+            "host": host_info(),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(np, cap, args.cpu_sample_chunks, stream, results[0])
+        if k5_ms is not None:
+            # ingest 2N B per antenna + 32 L B per transform (four-step floor), A + P transforms
+            L, A, P = 2 * SLICE, stream.n_ant, len(tdoa.pairs)
+            k5_bytes = 2 * SLICE * A + 32 * L * (A + P)
+            line["secondary"][f"K5 xcorr solve, {A} antennas / {P} pairs, L = 2^20, solo"] = {
+                "bound": "hbm", "algorithmic_bytes_per_launch": k5_bytes, "avg_launch_ms": k5_ms,
+                "achieved": (k5_bytes / 1e9) / (k5_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (k5_bytes / 1e9) / (k5_ms / 1e3) / HBM_PEAK_GBS,
+                "note": "working set (spectra) is L2 / Infinity-Cache resident"}
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        if world == 1 and not args.no_end_to_end:
+            line["end_to_end"] = end_to_end(np, dev, cap, nbytes)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    stream.close()
     dev.close()
 
 
-def pmc_traffic(nbytes):
-    """HBM bytes per K2 launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate runs, gfx950 correction calibrated on K2's own access pattern: tools/pmc_welch.sh,
-    tools/pmc_summarize.py).  PMC collection cannot run inside the timed bench, so the figure is the
-    recorded one and only offered for the capture size it was measured on."""
-    path = os.path.join(REPO, "profiles", "r01_pmc_welch", "summary_final.json")
+def self_check(results, tdoa, onsets, nsamp, n_ant):
+    """The synthetic captures carry a known answer: antenna a sees the common burst DELAYS[a]
+    samples late, so for every solved pair  lag(i, j) + onset_j - onset_i == DELAYS[j] - DELAYS[i];
+    every stream's jammed byte range must be the burst span (to one 64-KiB chunk)."""
+    ok_pairs = []
+    for (i, j), lag in zip(tdoa.pairs, tdoa.lags):
+        ok_pairs.append(lag + onsets[j] - onsets[i] == DELAYS[j % len(DELAYS)] - DELAYS[i % len(DELAYS)])
+    ok_ranges, ok_rank = [], []
+    for k, r in enumerate(results):
+        rng = r.jamming_byte_ranges()
+        want0 = 2 * (int(JAM_SPAN[0] * nsamp) + DELAYS[r.rank % len(DELAYS)])
+        want1 = 2 * (int(JAM_SPAN[1] * nsamp) + DELAYS[r.rank % len(DELAYS)])
+        ok_ranges.append(len(rng) == 1 and abs(rng[0][0] - want0) <= 65536 and abs(rng[0][1] - want1) <= 65536)
+        ok_rank.append(r.rank == k and r.amp_first == 0 and r.amp_count == nsamp and r.onset > 0)
+    n_pairs = n_ant * (n_ant - 1) // 2
+    return {"tdoa_pairs_ok": bool(ok_pairs) and all(ok_pairs) and len(ok_pairs) == n_pairs,
+            "pairs_checked": len(ok_pairs), "jamming_ranges_ok": all(ok_ranges), "streams_ok": all(ok_rank),
+            "streams_checked": len(results),
+            "passed": bool(ok_pairs) and all(ok_pairs) and len(ok_pairs) == n_pairs and all(ok_ranges) and all(ok_rank)}
+
+
+def host_info():
+    model = "unknown"
     try:
-        with open(path) as f:
-            corr = json.load(f)["_hbm_bytes_corrected"]
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count()
+    return {"cpu_model": model, "cpu_count": os.cpu_count(), "cpus_usable": usable}
+
+
+def source_hash():
+    """sha256 over the K2 sources: ties a committed PMC summary to the kernel it was measured on."""
+    h = hashlib.sha256()
+    for name in ("k_welch.hip", "fft_core.h", "gj_common.h"):
+        with open(os.path.join(REPO, "gps-jamming_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_summary(nbytes):
+    """HBM bytes and VALU instructions per K2 launch from the committed PMC passes (rocprofv3 --pmc
+    in separate runs, gfx950 FETCH_SIZE correction calibrated on K2's own access pattern:
+    tools/pmc_welch.sh, tools/pmc_summarize.py).  PMC collection cannot run inside the timed bench,
+    so the figures are the recorded ones, offered only for the capture size they were measured on, and
+    flagged when the kernel sources have changed since."""
+    out = {"traffic": None, "valu_insts": None, "source": "no PMC summary found", "matches_build": None}
+    for rel in ("profiles/r02_pmc_welch/summary.json", "profiles/r01_pmc_welch/summary_final.json"):
+        try:
+            with open(os.path.join(REPO, rel)) as f:
+                js = json.load(f)
+            corr = js["_hbm_bytes_corrected"]
+        except (OSError, KeyError, ValueError):
+            continue
         if nbytes != CAPTURE_BYTES:
-            return None, "PMC summary is for the 1-GiB capture only"
-        return float(corr["hbm_bytes_per_launch"]), "profiles/r01_pmc_welch/summary_final.json (welch_kernel<4096> only)"
-    except (OSError, KeyError, ValueError):
-        return None, "no PMC summary found"
+            out["source"] = "PMC summary is for the 1-GiB capture only"
+            return out
+        out["traffic"] = float(corr["hbm_bytes_per_launch"])
+        out["valu_insts"] = js.get("_valu", {}).get("sq_insts_valu_per_launch")
+        out["source"] = rel + " (welch_kernel<4096> only; commit " + str(js.get("_commit", "not recorded")) + ")"
+        out["matches_build"] = (js.get("_source_hash") == source_hash()) if js.get("_source_hash") else None
+        return out
+    return out
 
 
-def cpu_baseline(np, cap, n_chunks, stream, gpu_result):
+def valu_roofline(pmc, welch_ms, solo_ms):
+    """K2 against what binds it: wave-instructions issued per second over the packed-f32 issue
+    ceiling measured on this chip (tools/ubench_valu.hip: 504-570 G wave-instr/s for v_pk_*_f32,
+    profiles/r01_ubench_valu_lds.txt)."""
+    if not pmc.get("valu_insts"):
+        return {"bound": "valu_issue", "achieved": None, "note": "no SQ_INSTS_VALU figure in the PMC summary"}
+    ceiling = (504e9, 570e9)
+    ach = pmc["valu_insts"] / (welch_ms / 1e3)
+    solo = pmc["valu_insts"] / (solo_ms / 1e3)
+    return {"bound": "valu_issue", "unit": "wave-instr/s", "achieved": ach, "achieved_solo": solo,
+            "peak_range": list(ceiling), "frac_range": [ach / ceiling[1], ach / ceiling[0]],
+            "frac_range_solo": [solo / ceiling[1], solo / ceiling[0]],
+            "inputs": {"sq_insts_valu_per_launch": pmc["valu_insts"], "avg_launch_ms": welch_ms,
+                       "solo_launch_ms": solo_ms, "pmc_source": pmc["source"],
+                       "ceiling_source": "profiles/r01_ubench_valu_lds.txt (packed f32 issue, all CUs)"}}
+
+
+def end_to_end(np, dev, cap, nbytes):
+    """File / host buffer -> results, wall clock, PCIe included (never `value`): one upload of the
+    capture (pinned bounce buffers, four fill threads) + scan + threshold + Welch + the D2H of the
+    power map and the PSD rows.  The file leg reads a scratch copy of the same capture."""
+    import tempfile
+    import gpsjam
+    host = cap.cpu().numpy()
+    out = {}
+
+    def run(source):
+        t0 = time.perf_counter()
+        c = dev.capture(source)
+        t1 = time.perf_counter()
+        pm = dev.chunk_power(c)
+        psd, _ = dev.welch(c, chunk_samples=CHUNK_SAMPLES, nperseg=NPERSEG, want_db=False)
+        st = dev.amp_stats(c, 0.0)
+        on = dev.onset(c)
+        t2 = time.perf_counter()
+        c.free()
+        assert pm.size and psd.size and st.count and on.start_index
+        return t1 - t0, t2 - t0
+
+    run(host[:1 << 26])                                     # pinned buffers allocated, code paths warm
+    up, tot = run(host)
+    out["host_buffer"] = {"upload_ms": up * 1e3, "total_ms": tot * 1e3, "upload_GBps": nbytes / up / 1e9,
+                          "msamples_per_s": nbytes / 2 / tot / 1e6}
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    path = os.path.join(d, f"gpsjam_bench_{os.getpid()}.bin")
+    try:
+        host.tofile(path)
+        up, tot = run(path)
+        out["file"] = {"upload_ms": up * 1e3, "total_ms": tot * 1e3, "upload_GBps": nbytes / up / 1e9,
+                       "msamples_per_s": nbytes / 2 / tot / 1e6, "where": d + " (page-cache resident)"}
+    finally:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    out["what"] = ("one H2D per capture (gpsjam.Capture), then K1 power map + K2 Welch 4096 + K3 amp stats + K4 onset "
+                   "and the D2H of their results; wall clock")
+    out["uploads"] = gpsjam.Capture.uploads
+    return out
+
+
+def cpu_baseline(np, cap, n_chunks, stream, gathered, world):
     """The oracle (a numpy/scipy port of the reference path) on a bounded prefix of the same
-    capture, single process / single thread, with parity of the GPU results on that prefix."""
+    capture, single process / single thread per rank, with parity of the GPU results on that
+    prefix (rank 0)."""
     from oracle import gpsjam_oracle as orc
+    from gpsjam import sharded
     sample_bytes = min(cap.numel(), n_chunks * 2 * CHUNK_SAMPLES)
     raw = cap[:sample_bytes].cpu().numpy()
     ns = sample_bytes // 2
+    n = min(SLICE, ns)
+    slices = None
+    if world == 1 and stream.n_ant > 1:                     # the same three slices K5 correlates
+        torch_slots = stream.slots.cpu()
+        slices = [orc.tdoa_unpack(sharded.slot_fields(torch_slots[a], SLICE)[2]) for a in range(stream.n_ant)]
     t0 = time.perf_counter()
     pm = orc.chunk_power(raw)
     orc.power_threshold(pm)
@@ -215,19 +434,29 @@ def cpu_baseline(np, cap, n_chunks, stream, gpu_result):
     _, avg = orc.rssi_amp_stats(raw, 0.0)
     z = orc.tdoa_unpack(raw)
     orc.tdoa_onset(z)
-    n = min(SLICE, ns)
-    orc.xcorr_lag(z[:n], z[:n])
+    cpu_lags = []
+    if slices is not None:
+        for i, j in stream.pairs:
+            cpu_lags.append(int(orc.xcorr_lag(slices[j], slices[i])[0]))
+    else:
+        orc.xcorr_lag(z[:n], z[:n])
     dt = time.perf_counter() - t0
-    # parity of the GPU path on the same bytes (not timed)
-    psd = stream.psd[:lin.shape[0]].cpu().numpy()
-    keep = lin > 1e-12
-    psd_err = float(np.max(np.abs(psd[keep] - lin[keep]) / lin[keep]))
-    pm_err = float(np.max(np.abs(gpu_result.power_map[:pm.size] - pm) / pm))
-    return {"value": ns / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": f"first {sample_bytes} bytes ({ns} samples, {lin.shape[0]} 1-s chunks) of the same capture: "
-                      f"chunk power + threshold + Welch 4096 + amp stats + onset + one 2^19 xcorr, "
-                      f"numpy {np.__version__} single thread, {dt:.2f} s",
-            "parity_on_sample": {"psd_max_rel_err": psd_err, "power_map_max_rel_err": pm_err}}
+    out = {"value": ns / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+           "sample": f"first {sample_bytes} bytes ({ns} samples, {lin.shape[0]} 1-s chunks) of the same capture: "
+                     f"chunk power + threshold + Welch 4096 + amp stats + onset + "
+                     + (f"{len(cpu_lags)} 2^19-sample xcorr pairs" if slices is not None else "one 2^19 xcorr")
+                     + f", numpy {np.__version__} single thread, {dt:.2f} s"}
+    if gathered is not None:
+        # parity of the GPU path on the same bytes (not timed)
+        results, tdoa = gathered.unpack()
+        psd = stream.psd[:lin.shape[0]].cpu().numpy()
+        keep = lin > 1e-12
+        out["parity_on_sample"] = {
+            "psd_max_rel_err": float(np.max(np.abs(psd[keep] - lin[keep]) / lin[keep])),
+            "power_map_max_rel_err": float(np.max(np.abs(results[0].power_map[:pm.size] - pm) / pm))}
+        if slices is not None:
+            out["parity_on_sample"]["lags_equal"] = cpu_lags == tdoa.lags
+    return out
 
 
 if __name__ == "__main__":

@@ -196,8 +196,9 @@ class GPSAnalysisThread(QThread):
             if self.stop_requested:
                 self.power_map = np.array([])
             else:
-                dev = gpsjam.default_device()
-                self.power_map = dev.chunk_power(gpsjam.read_capture(path), chunk_bytes=chunk_bytes, eps=1e-10)
+                cap = gpsjam.resident_capture(path)     # one upload; the triangulation reuses it
+                dev = cap.dev
+                self.power_map = dev.chunk_power(cap, chunk_bytes=chunk_bytes, eps=1e-10)
                 self.scan_kernel_ms = dev.last_kernel_ms
                 if self.scan_kernel_ms > 0:
                     rate = self.total_file_bytes / 2 / self.scan_kernel_ms / 1e3

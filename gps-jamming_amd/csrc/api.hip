@@ -306,10 +306,39 @@ int gj_stream_scan_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t c
 }
 
 int gj_xcorr_lags_dev(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, int n_ant, const int64_t* d_starts,
-                      size_t n_samples, const int32_t* pairs, int n_pairs, int32_t* d_lags, float* d_peaks) {
+                      size_t n_samples, const int32_t* pairs, int n_pairs, int32_t* d_lags, float* d_peaks,
+                      float* d_margins) {
     GJ_ENTER(ctx);
     if (!d_iq || !nbytes || !d_starts || !pairs || !d_lags || !d_peaks) return fail(ctx, GJ_ERR_INVALID, "null buffer");
-    return launch_xcorr(ctx, d_iq, nbytes, n_ant, d_starts, n_samples, pairs, n_pairs, d_lags, d_peaks);
+    return launch_xcorr(ctx, d_iq, nbytes, n_ant, d_starts, 1, n_samples, pairs, n_pairs, d_lags, d_peaks, d_margins);
+}
+
+size_t gj_tdoa_slot_bytes(size_t n_samples) { return align_up(GJ_SLOT_HEADER + 2 * n_samples, 256); }
+
+int gj_tdoa_slot_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, const int64_t* d_start, size_t n_samples,
+                     uint8_t* d_slot) {
+    GJ_ENTER(ctx);
+    if (!d_iq || !d_start || !d_slot) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    return launch_tdoa_slot(ctx, d_iq, nbytes, d_start, n_samples, d_slot);
+}
+
+int gj_xcorr_slots_dev(gj_ctx* ctx, const uint8_t* d_slots, size_t slot_stride, int n_ant, size_t n_samples,
+                       const int32_t* pairs, int n_pairs, int32_t* d_lags, float* d_peaks, float* d_margins) {
+    GJ_ENTER(ctx);
+    if (!d_slots || !pairs || !d_lags || !d_peaks) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    if (n_ant < 1 || n_ant > GJ_MAX_ANTENNAS) return fail(ctx, GJ_ERR_INVALID, "n_ant must be 1..%d", GJ_MAX_ANTENNAS);
+    if (slot_stride < GJ_SLOT_HEADER + 2 * n_samples || (slot_stride & 15) || (reinterpret_cast<uintptr_t>(d_slots) & 15))
+        return fail(ctx, GJ_ERR_INVALID, "slot stride %zu too small for %zu samples or not 16-byte aligned", slot_stride,
+                    n_samples);
+    const uint8_t* ptrs[GJ_MAX_ANTENNAS];
+    size_t sizes[GJ_MAX_ANTENNAS];
+    for (int a = 0; a < n_ant; ++a) {
+        ptrs[a] = d_slots + (size_t)a * slot_stride + GJ_SLOT_HEADER;
+        sizes[a] = 2 * n_samples;
+    }
+    // start words = the slots' flag words (0 valid / -1 invalid), slot_stride bytes apart
+    return launch_xcorr(ctx, ptrs, sizes, n_ant, reinterpret_cast<const int64_t*>(d_slots), slot_stride / 8, n_samples,
+                        pairs, n_pairs, d_lags, d_peaks, d_margins);
 }
 
 int gj_pack_result_dev(gj_ctx* ctx, size_t n_chunks, const float* d_power, const float* d_stats, const gj_amp_stats* d_amp,
@@ -328,6 +357,12 @@ int gj_synth_u8_dev(gj_ctx* ctx, const gj_synth_params* params, int64_t first_sa
     return launch_synth(ctx, *params, first_sample, n_samples, d_out);
 }
 
+}   // extern "C"
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 // ---------------------------------------------------------------- host-buffer entry points
 // Stage the capture into HBM (grow-only staging arena), run the same kernels, copy the small
 // results back.  kernel_ms excludes the copies.
@@ -342,6 +377,44 @@ constexpr size_t kPinThreshold = 64u << 20;
 // queue the DMA (one memcpy thread tops out at ~31 GB/s end to end, below what the link carries).
 constexpr int kFillThreads = gj_ctx::kPinBufs / 2;
 
+// `fill(dst, off, len)` puts bytes [off, off+len) of the source into a pinned buffer: memcpy from a
+// numpy array, or pread from a capture file (then the file goes page cache -> pinned -> HBM with no
+// pageable copy in between)
+template <typename Fill>
+static int staged_copy(gj_ctx* ctx, unsigned char* d_dst, size_t nbytes, Fill&& fill) {
+    if (nbytes == 0) return GJ_OK;
+    for (int k = 0; k < gj_ctx::kPinBufs; ++k) {
+        if (!ctx->pin[k]) GJ_HIP(ctx, hipHostMalloc(&ctx->pin[k], kPinBytes, hipHostMallocDefault));
+        if (!ctx->pin_ev[k]) GJ_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_ev[k], hipEventDisableTiming));
+    }
+    const size_t npieces = (nbytes + kPinBytes - 1) / kPinBytes;
+    const int nthreads = (int)(npieces < (size_t)kFillThreads ? npieces : (size_t)kFillThreads);
+    std::atomic<int> failed{0};
+    auto worker = [&](int t) {
+        if (hipSetDevice(ctx->device) != hipSuccess) { failed.store(1); return; }
+        size_t mine = 0;
+        for (size_t piece = (size_t)t; piece < npieces; piece += (size_t)nthreads, ++mine) {
+            const size_t off = piece * kPinBytes;
+            const size_t len = (nbytes - off < kPinBytes) ? nbytes - off : kPinBytes;
+            const int b = 2 * t + (int)(mine & 1);
+            if (mine >= 2 && hipEventSynchronize(ctx->pin_ev[b]) != hipSuccess) { failed.store(1); return; }
+            if (!fill(static_cast<unsigned char*>(ctx->pin[b]), off, len)) { failed.store(2); return; }
+            if (hipMemcpyAsync(d_dst + off, ctx->pin[b], len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                hipEventRecord(ctx->pin_ev[b], ctx->stream) != hipSuccess) { failed.store(1); return; }
+        }
+        // the bounce buffers are reused by the next call: the tail pieces must have left them
+        for (int k = 0; k < 2; ++k)
+            if (mine > (size_t)k && hipEventSynchronize(ctx->pin_ev[2 * t + k]) != hipSuccess) failed.store(1);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto& th : pool) th.join();
+    if (failed.load() == 2) return fail(ctx, GJ_ERR_INVALID, "reading the capture failed");
+    if (failed.load()) return fail(ctx, GJ_ERR_HIP, "host-to-device staging failed");
+    return GJ_OK;
+}
+
 static int stage_in(gj_ctx* ctx, const uint8_t* host, size_t nbytes, size_t offset = 0) {
     int rc = ensure_stage(ctx, offset + align_up(nbytes, 256) + 256);
     if (rc) return rc;
@@ -350,34 +423,81 @@ static int stage_in(gj_ctx* ctx, const uint8_t* host, size_t nbytes, size_t offs
         GJ_HIP(ctx, hipMemcpyAsync(ctx->stage + offset, host, nbytes, hipMemcpyHostToDevice, ctx->stream));
         return GJ_OK;
     }
-    for (int k = 0; k < gj_ctx::kPinBufs; ++k) {
-        if (!ctx->pin[k]) GJ_HIP(ctx, hipHostMalloc(&ctx->pin[k], kPinBytes, hipHostMallocDefault));
-        if (!ctx->pin_ev[k]) GJ_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_ev[k], hipEventDisableTiming));
+    return staged_copy(ctx, ctx->stage + offset, nbytes, [host](unsigned char* dst, size_t off, size_t len) {
+        memcpy(dst, host + off, len);
+        return true;
+    });
+}
+
+extern "C" {
+
+// ---------------------------------------------------------------- resident captures
+// One upload per capture, then any number of *_dev calls on it (gpsjam.Capture): the host-buffer
+// entry points below re-stage their input on every call (21 ms per GiB of PCIe against 0.2-1.3 ms
+// of kernel time).
+int gj_upload(gj_ctx* ctx, const uint8_t* host, size_t nbytes, void** dptr) {
+    GJ_ENTER(ctx);
+    if (!dptr || (nbytes && !host)) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    *dptr = nullptr;
+    void* p = nullptr;
+    if (hipMalloc(&p, align_up(nbytes, 256) + 256) != hipSuccess) return fail(ctx, GJ_ERR_NOMEM, "hipMalloc(%zu)", nbytes);
+    int rc = GJ_OK;
+    if (nbytes && nbytes < kPinThreshold) {
+        if (hipMemcpyAsync(p, host, nbytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            rc = fail(ctx, GJ_ERR_HIP, "hipMemcpyAsync failed");
+    } else {
+        rc = staged_copy(ctx, static_cast<unsigned char*>(p), nbytes, [host](unsigned char* dst, size_t off, size_t len) {
+            memcpy(dst, host + off, len);
+            return true;
+        });
     }
-    const size_t npieces = (nbytes + kPinBytes - 1) / kPinBytes;
-    const int nthreads = (int)(npieces < (size_t)kFillThreads ? npieces : (size_t)kFillThreads);
-    std::atomic<int> failed{0};
-    auto fill = [&](int t) {
-        if (hipSetDevice(ctx->device) != hipSuccess) { failed.store(1); return; }
-        size_t mine = 0;
-        for (size_t piece = (size_t)t; piece < npieces; piece += (size_t)nthreads, ++mine) {
-            const size_t off = piece * kPinBytes;
-            const size_t len = (nbytes - off < kPinBytes) ? nbytes - off : kPinBytes;
-            const int b = 2 * t + (int)(mine & 1);
-            if (mine >= 2 && hipEventSynchronize(ctx->pin_ev[b]) != hipSuccess) { failed.store(1); return; }
-            memcpy(ctx->pin[b], host + off, len);
-            if (hipMemcpyAsync(ctx->stage + offset + off, ctx->pin[b], len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                hipEventRecord(ctx->pin_ev[b], ctx->stream) != hipSuccess) { failed.store(1); return; }
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, GJ_ERR_HIP, "upload failed");
+    if (rc) {
+        (void)hipFree(p);
+        return rc;
+    }
+    *dptr = p;
+    return GJ_OK;
+}
+
+// The reference's ingest (np.fromfile / f.read, worker.py:209-217, triangulateRSSI.py:29) as file ->
+// pinned bounce buffers (pread, four threads) -> HBM.  max_bytes = 0: to the end of the file.
+int gj_upload_file(gj_ctx* ctx, const char* path, size_t offset, size_t max_bytes, void** dptr, size_t* nbytes_out) {
+    GJ_ENTER(ctx);
+    if (!path || !dptr || !nbytes_out) return fail(ctx, GJ_ERR_INVALID, "null argument");
+    *dptr = nullptr;
+    *nbytes_out = 0;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(ctx, GJ_ERR_INVALID, "cannot open %s", path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+        close(fd);
+        return fail(ctx, GJ_ERR_INVALID, "cannot stat %s", path);
+    }
+    size_t nbytes = (size_t)st.st_size > offset ? (size_t)st.st_size - offset : 0;
+    if (max_bytes && nbytes > max_bytes) nbytes = max_bytes;
+    void* p = nullptr;
+    if (hipMalloc(&p, align_up(nbytes, 256) + 256) != hipSuccess) {
+        close(fd);
+        return fail(ctx, GJ_ERR_NOMEM, "hipMalloc(%zu)", nbytes);
+    }
+    int rc = staged_copy(ctx, static_cast<unsigned char*>(p), nbytes, [fd, offset](unsigned char* dst, size_t off, size_t len) {
+        size_t done = 0;
+        while (done < len) {
+            const ssize_t k = pread(fd, dst + done, len - done, (off_t)(offset + off + done));
+            if (k <= 0) return false;
+            done += (size_t)k;
         }
-        // the bounce buffers are reused by the next call: the tail pieces must have left them
-        for (int k = 0; k < 2; ++k)
-            if (mine > (size_t)k && hipEventSynchronize(ctx->pin_ev[2 * t + k]) != hipSuccess) failed.store(1);
-    };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nthreads; ++t) pool.emplace_back(fill, t);
-    fill(0);
-    for (auto& th : pool) th.join();
-    if (failed.load()) return fail(ctx, GJ_ERR_HIP, "host-to-device staging failed");
+        return true;
+    });
+    close(fd);
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, GJ_ERR_HIP, "upload failed");
+    if (rc) {
+        (void)hipFree(p);
+        return rc;
+    }
+    *dptr = p;
+    *nbytes_out = nbytes;
     return GJ_OK;
 }
 
@@ -465,11 +585,11 @@ int gj_onset_u8(gj_ctx* ctx, const uint8_t* iq, size_t nbytes, int noise_samples
 }
 
 int gj_xcorr_lags_u8(gj_ctx* ctx, const uint8_t* const* slices, int n_ant, size_t n_samples, const int32_t* pairs,
-                     int n_pairs, int32_t* lags, float* peaks, float* kernel_ms) {
+                     int n_pairs, int32_t* lags, float* peaks, float* margins, float* kernel_ms) {
     GJ_ENTER(ctx);
     if (!slices || !pairs || !lags || !peaks) return fail(ctx, GJ_ERR_INVALID, "null buffer");
     if (n_ant < 1 || n_ant > GJ_MAX_ANTENNAS) return fail(ctx, GJ_ERR_INVALID, "n_ant must be 1..%d", GJ_MAX_ANTENNAS);
-    if (n_pairs < 1 || (size_t)n_pairs * 8 + 256 > kResultScratch) return fail(ctx, GJ_ERR_INVALID, "bad n_pairs");
+    if (n_pairs < 1 || (size_t)n_pairs * 12 + 256 > kResultScratch) return fail(ctx, GJ_ERR_INVALID, "bad n_pairs");
     const size_t slot = align_up(2 * n_samples, 256);
     int rc = ensure_stage(ctx, slot * n_ant + 256);
     if (rc) return rc;
@@ -485,10 +605,12 @@ int gj_xcorr_lags_u8(gj_ctx* ctx, const uint8_t* const* slices, int n_ant, size_
     int64_t* d_starts = reinterpret_cast<int64_t*>(sc);   // zeros: slices start at their first sample
     int32_t* d_lags = reinterpret_cast<int32_t*>(sc + 128);
     float* d_peaks = reinterpret_cast<float*>(sc + 128 + 4 * (size_t)n_pairs);
+    float* d_margins = reinterpret_cast<float*>(sc + 128 + 8 * (size_t)n_pairs);
     GJ_HIP(ctx, hipMemsetAsync(d_starts, 0, 128, ctx->stream));
     GJ_TIMED(ctx, kernel_ms,
-             launch_xcorr(ctx, d_ptrs, nbytes, n_ant, d_starts, n_samples, pairs, n_pairs, d_lags, d_peaks));
+             launch_xcorr(ctx, d_ptrs, nbytes, n_ant, d_starts, 1, n_samples, pairs, n_pairs, d_lags, d_peaks, d_margins));
     GJ_HIP(ctx, hipMemcpyAsync(peaks, d_peaks, 4 * (size_t)n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+    if (margins) GJ_HIP(ctx, hipMemcpyAsync(margins, d_margins, 4 * (size_t)n_pairs, hipMemcpyDeviceToHost, ctx->stream));
     return fetch(ctx, lags, d_lags, 4 * (size_t)n_pairs);
 }
 

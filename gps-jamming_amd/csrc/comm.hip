@@ -1,0 +1,149 @@
+// gj_comm_*: the one real exchange of the path (TDOA slots and per-stream result vectors to the
+// solving rank) as RCCL collectives over xGMI, one communicator rank per GPU / process, for hosts
+// that do not bring torch.distributed.  The reference has no equivalent (single process, numpy).
+//
+// RCCL is bound at run time (dlopen): the hot-path library keeps no link dependency on the
+// 570-MB librccl, and inside a PyTorch process the copy torch already loaded is reused instead
+// of mapping a second one.  Search order: $GPSJAM_RCCL, an already-loaded librccl, librccl.so.1,
+// /opt/rocm/lib/librccl.so.1.
+#include <dlfcn.h>
+
+#include <rccl/rccl.h>   // types and prototypes only; nothing is linked
+
+#include "gj_common.h"
+
+struct gj_comm {
+    gj_ctx* ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, n_ranks = 1;
+};
+
+namespace gj {
+
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGather) Gather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    char why[256] = {0};
+};
+
+static Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* env = getenv("GPSJAM_RCCL");
+        const char* tries[] = {env, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+        for (int pass = 0; pass < 2 && !r.handle; ++pass)       // pass 0: only what the process already holds
+            for (const char* name : tries) {
+                if (!name || !*name) continue;
+                r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                if (r.handle) break;
+            }
+        if (!r.handle) {
+            snprintf(r.why, sizeof(r.why), "cannot load librccl (%s)", dlerror());
+            return;
+        }
+#define GJ_SYM(field, name)                                                                  \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, name));                    \
+    if (!r.field && !r.why[0]) snprintf(r.why, sizeof(r.why), "librccl has no symbol %s", name)
+        GJ_SYM(GetUniqueId, "ncclGetUniqueId");
+        GJ_SYM(CommInitRank, "ncclCommInitRank");
+        GJ_SYM(CommDestroy, "ncclCommDestroy");
+        GJ_SYM(Gather, "ncclGather");   // RCCL extension (rccl.h:745)
+        GJ_SYM(Broadcast, "ncclBroadcast");
+        GJ_SYM(GetErrorString, "ncclGetErrorString");
+#undef GJ_SYM
+    });
+    return &r;
+}
+
+static int rccl_fail(gj_ctx* ctx, const char* what, ncclResult_t rc) {
+    Rccl* r = rccl();
+    return fail(ctx, GJ_ERR_HIP, "%s failed: %s", what, r->GetErrorString ? r->GetErrorString(rc) : "?");
+}
+
+}   // namespace gj
+
+using namespace gj;
+
+extern "C" {
+
+int gj_comm_unique_id(void* id) {
+    if (!id) return GJ_ERR_INVALID;
+    Rccl* r = rccl();
+    if (!r->handle || r->why[0]) return GJ_ERR_UNSUPPORTED;
+    static_assert(sizeof(ncclUniqueId) == GJ_COMM_ID_BYTES, "gpsjam.h promises 128 bytes");
+    ncclUniqueId u;
+    if (r->GetUniqueId(&u) != ncclSuccess) return GJ_ERR_HIP;
+    memcpy(id, &u, sizeof(u));
+    return GJ_OK;
+}
+
+int gj_comm_init_rank(gj_ctx* ctx, const void* id, int rank, int n_ranks, gj_comm** out) {
+    if (!ctx || !id || !out) return GJ_ERR_INVALID;
+    *out = nullptr;
+    Guard g(ctx);
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(ctx, GJ_ERR_INVALID, "rank %d of %d", rank, n_ranks);
+    Rccl* r = rccl();
+    if (!r->handle || r->why[0]) return fail(ctx, GJ_ERR_UNSUPPORTED, "%s", r->why);
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    gj_comm* c = new (std::nothrow) gj_comm();
+    if (!c) return GJ_ERR_NOMEM;
+    c->ctx = ctx;
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    const ncclResult_t rc = r->CommInitRank(&c->comm, n_ranks, u, rank);   // binds to the current device = ctx's
+    if (rc != ncclSuccess) {
+        delete c;
+        return rccl_fail(ctx, "ncclCommInitRank", rc);
+    }
+    *out = c;
+    return GJ_OK;
+}
+
+int gj_comm_rank(gj_comm* c, int* rank, int* n_ranks) {
+    if (!c) return GJ_ERR_INVALID;
+    if (rank) *rank = c->rank;
+    if (n_ranks) *n_ranks = c->n_ranks;
+    return GJ_OK;
+}
+
+int gj_comm_gather_dev(gj_comm* c, const void* d_send, size_t bytes, void* d_recv, int root) {
+    if (!c) return GJ_ERR_INVALID;
+    gj_ctx* ctx = c->ctx;
+    Guard g(ctx);
+    if (root < 0 || root >= c->n_ranks) return fail(ctx, GJ_ERR_INVALID, "root %d of %d", root, c->n_ranks);
+    if (!d_send || (c->rank == root && !d_recv)) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    const ncclResult_t rc = rccl()->Gather(d_send, d_recv, bytes, ncclUint8, root, c->comm, ctx->stream);
+    if (rc != ncclSuccess) return rccl_fail(ctx, "ncclGather", rc);
+    return GJ_OK;
+}
+
+int gj_comm_bcast_dev(gj_comm* c, void* d_buf, size_t bytes, int root) {
+    if (!c) return GJ_ERR_INVALID;
+    gj_ctx* ctx = c->ctx;
+    Guard g(ctx);
+    if (root < 0 || root >= c->n_ranks) return fail(ctx, GJ_ERR_INVALID, "root %d of %d", root, c->n_ranks);
+    if (!d_buf) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    const ncclResult_t rc = rccl()->Broadcast(d_buf, d_buf, bytes, ncclUint8, root, c->comm, ctx->stream);
+    if (rc != ncclSuccess) return rccl_fail(ctx, "ncclBroadcast", rc);
+    return GJ_OK;
+}
+
+int gj_comm_destroy(gj_comm* c) {
+    if (!c) return GJ_OK;
+    {
+        Guard g(c->ctx);
+        (void)hipStreamSynchronize(c->ctx->stream);
+        if (c->comm) (void)rccl()->CommDestroy(c->comm);
+    }
+    delete c;
+    return GJ_OK;
+}
+
+}   // extern "C"

@@ -497,6 +497,13 @@ struct OnsetScratch {
     unsigned long long noise_m1;
     float noise;
     float thr;
+    // decision margin (gj_onset.margin_before): the largest window sum that stayed below the
+    // threshold -- exact over the positions the scan kernel looked at, and the screening bound
+    // (scaled to one window: U covers `cb` blocks) over the blocks proven quiet.  A workgroup that
+    // runs ahead of the first crossing may add values from positions BEHIND it: that only makes the
+    // reported margin smaller (the guard more cautious), never larger.
+    unsigned max_below;
+    unsigned max_screen;
 };
 
 __device__ __forceinline__ float onset_threshold(const OnsetScratch* sc, int noise_samples, float factor, float* noise_out) {
@@ -605,16 +612,23 @@ __global__ __launch_bounds__(kScanThreads) void onset_coarse_kernel(const uint8_
     __syncthreads();
     const double scale = 0.25 / (double)window;
     unsigned long long best = ~0ull;
+    unsigned quiet = 0;   // largest U among the blocks this thread proved quiet
     for (int k = tid; k < nloc; k += kScanThreads) {
         const unsigned U = pre[onset_pad(k + cb)] - pre[onset_pad(k)];
         if ((double)U * scale > thr) { best = (unsigned long long)(j0 + k) * BS; break; }
+        quiet = U > quiet ? U : quiet;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned long long o = __shfl_xor(best, off, 64);
         best = o < best ? o : best;
+        const unsigned oq = __shfl_xor(quiet, off, 64);
+        quiet = oq > quiet ? oq : quiet;
     }
-    if ((tid & 63) == 0 && best != ~0ull) atomicMax(&sc->cand_inv, ~best);
+    if ((tid & 63) == 0) {
+        if (best != ~0ull) atomicMax(&sc->cand_inv, ~best);
+        if (quiet) atomicMax(&sc->max_screen, quiet);
+    }
 }
 
 // Exact scan from the candidate on: prefix sums of 4|z|^2 in LDS, window sums by difference.
@@ -680,17 +694,24 @@ __global__ __launch_bounds__(kScanThreads) void onset_scan_kernel(const uint8_t*
         const double thr = (double)sc->thr;
         const double scale = 0.25 / (double)window;
         unsigned long long best = ~0ull;
+        unsigned below = 0;   // largest window sum at the positions in front of this thread's first crossing
         const int nloc = (int)(o1 - o0);
         for (int k = tid; k < nloc; k += kScanThreads) {
             const unsigned S = pre[onset_pad(k + window)] - pre[onset_pad(k)];
             if ((double)S * scale > thr) { best = o0 + k; break; }
+            below = S > below ? S : below;
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const unsigned long long o = __shfl_xor(best, off, 64);
             best = o < best ? o : best;
+            const unsigned ob = __shfl_xor(below, off, 64);
+            below = ob > below ? ob : below;
         }
-        if ((tid & 63) == 0 && best != ~0ull) atomicMax(&sc->first_inv, ~best);
+        if ((tid & 63) == 0) {
+            if (best != ~0ull) atomicMax(&sc->first_inv, ~best);
+            if (below) atomicMax(&sc->max_below, below);
+        }
         __syncthreads();   // LDS is reused by the next tile
     }
 }
@@ -703,14 +724,35 @@ __global__ void onset_set_cand_kernel(OnsetScratch* __restrict__ sc, int noise_s
     sc->noise = noise;
 }
 
-__global__ void onset_finalize_kernel(const OnsetScratch* __restrict__ sc, int window, int valid, gj_onset* __restrict__ out) {
+// One wave.  Besides the index: the two decision margins of gj_onset (exact window sum at the
+// crossing, recomputed here from the capture; largest sum that stayed below, from the scratch).
+__global__ __launch_bounds__(64) void onset_finalize_kernel(const uint8_t* __restrict__ iq, const OnsetScratch* __restrict__ sc,
+                                                            int window, int valid, gj_onset* __restrict__ out) {
+    const int tid = threadIdx.x;
     if (!valid) {
-        out->start_index = -1; out->noise_power = 0.f; out->threshold = 0.f;
+        if (tid == 0) {
+            out->start_index = -1; out->noise_power = 0.f; out->threshold = 0.f;
+            out->margin_hit = 0.f; out->margin_before = 0.f; out->reserved = 0;
+        }
         return;
     }
-    out->start_index = (sc->first_inv == 0ull) ? -1 : (long long)(~sc->first_inv) + window / 2;
-    out->noise_power = sc->noise;
-    out->threshold = sc->thr;
+    const bool found = sc->first_inv != 0ull;
+    const unsigned long long i0 = ~sc->first_inv;
+    unsigned long long S = 0;
+    if (found)
+        for (int k = tid; k < window; k += 64) S += m_of(iq[2 * (i0 + k)], iq[2 * (i0 + k) + 1]);
+    S = wave_sum_u64(S);
+    if (tid == 0) {
+        const double thr = (double)sc->thr, scale = 0.25 / (double)window;
+        // the screening sums cover cb blocks >= one window: they bound every window sum inside
+        const unsigned mb = sc->max_below > sc->max_screen ? sc->max_below : sc->max_screen;
+        out->start_index = found ? (long long)i0 + window / 2 : -1;
+        out->noise_power = sc->noise;
+        out->threshold = sc->thr;
+        out->margin_hit = found ? (float)(((double)S * scale - thr) / thr) : 0.f;
+        out->margin_before = (float)((thr - (double)mb * scale) / thr);
+        out->reserved = 0;
+    }
 }
 
 int launch_onset(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, int noise_samples, int window, float factor,
@@ -742,7 +784,7 @@ int launch_onset(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, int noise_samp
                            ctx->stream, d_iq, nsamples, window, sc);
         GJ_LAUNCH_CHECK(ctx);
     }
-    hipLaunchKernelGGL(onset_finalize_kernel, dim3(1), dim3(1), 0, ctx->stream, sc, window, valid, d_out);
+    hipLaunchKernelGGL(onset_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, d_iq, sc, window, valid, d_out);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
 }
@@ -791,14 +833,17 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
     const bool in_noise = b0 < noise_bytes;                        // tile touches the K4 noise span
     unsigned k2 = 0x00020002u, km255 = 0xFF01FF01u;
     asm volatile("" : "+v"(k2), "+v"(km255));                      // keep both in VGPRs (one constant-bus slot per op)
-    auto body = [&](const uint4& q, size_t i) {
+    // `live` is false only for the lanes past the end of a partial last tile (see below): they take
+    // part in the wave-wide reductions with zero contributions
+    auto body = [&](const uint4& q, size_t i, const bool live) {
         unsigned v2 = 0, v1 = 0;
-        acc_moments(q, v2, v1);
+        acc_moments(q, v2, v1);   // a dead lane carries a zero vector: v2 = v1 = 0
         s2 += v2;
         s1 += v1;
         if (in_noise && b0 + (i << 4) < noise_bytes) { n2 += v2; n1 += v1; }   // noise_bytes % 16 == 0
         // block sum of 4|z|^2 over the wave = one 512-sample block (wave-uniform after the reduction)
-        const int c512 = group_sum_dpp<64>((int)(4u * v2 - 1020u * v1 + 16u * 65025u));
+        const unsigned m8 = 4u * v2 - 1020u * v1 + 16u * 65025u;
+        const int c512 = group_sum_dpp<64>((int)(live ? m8 : 0u));
         if ((tid & 63) == 0) cblk[(b0 >> 10) + (i >> 6)] = (unsigned)c512;
         const unsigned ws[4] = {q.x, q.y, q.z, q.w};
         float part = 0.f;
@@ -809,22 +854,33 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
             part += a1;
             if constexpr (TRACK_FIRST) {
                 const long long base = (long long)((b0 >> 1) + i * 8 + 2 * k);
-                if (a0 > thr && base < first) first = base;
-                if (a1 > thr && base + 1 < first) first = base + 1;
+                if (live && a0 > thr && base < first) first = base;
+                if (live && a1 > thr && base + 1 < first) first = base + 1;
             }
         }
-        sum += (double)part;
+        sum += (double)(live ? part : 0.f);
     };
-    size_t i = tid;
-    // four 16-byte loads in flight per lane before the arithmetic starts
-    for (; i + 3 * kScanThreads < nvec; i += 4 * kScanThreads) {
-        const uint4 q0 = v[i], q1 = v[i + kScanThreads], q2 = v[i + 2 * kScanThreads], q3 = v[i + 3 * kScanThreads];
-        body(q0, i);
-        body(q1, i + kScanThreads);
-        body(q2, i + 2 * kScanThreads);
-        body(q3, i + 3 * kScanThreads);
+    if (nvec == kScanTile / 16) {
+        // full tile: 16 vectors per lane, four 16-byte loads in flight before the arithmetic starts
+        for (size_t i = tid; i < nvec; i += 4 * kScanThreads) {
+            const uint4 q0 = v[i], q1 = v[i + kScanThreads], q2 = v[i + 2 * kScanThreads], q3 = v[i + 3 * kScanThreads];
+            body(q0, i, true);
+            body(q1, i + kScanThreads, true);
+            body(q2, i + 2 * kScanThreads, true);
+            body(q3, i + 3 * kScanThreads, true);
+        }
+    } else {
+        // partial last tile: the trip count is WAVE-uniform (the 512-sample block sums are reduced
+        // and stored per wave inside body(), so a wave must never split here); lanes past the end
+        // run on a zero vector and are masked out of every sum
+        const size_t lane = tid & 63;
+        for (size_t ib = (size_t)tid - lane; ib < nvec; ib += kScanThreads) {
+            const size_t i = ib + lane;
+            const bool live = i < nvec;
+            const uint4 q = live ? v[i] : uint4{0u, 0u, 0u, 0u};
+            body(q, i, live);
+        }
     }
-    for (; i < nvec; i += kScanThreads) body(v[i], i);
     // ragged end of the stream (< 8 samples): one lane, scalar
     if (tid == 0 && (b0 + (nvec << 4)) < b1) {
         unsigned c = 0;
@@ -960,7 +1016,7 @@ int launch_stream_scan(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t c
                            d_iq, nsamples, window, sc);
         GJ_LAUNCH_CHECK(ctx);
     }
-    hipLaunchKernelGGL(onset_finalize_kernel, dim3(1), dim3(1), 0, ctx->stream, sc, window, valid, d_onset);
+    hipLaunchKernelGGL(onset_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, d_iq, sc, window, valid, d_onset);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
 }

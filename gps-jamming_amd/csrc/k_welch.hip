@@ -398,6 +398,8 @@ struct WelchPlan {
 static bool welch_plan(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int nperseg, double fs, WelchPlan& pl) {
     if (nperseg < 16 || nperseg > 4096 || (nperseg & (nperseg - 1))) return false;
     if (chunk_samples < (size_t)nperseg) return false;
+    // the kernel addresses a chunk with 32-bit byte offsets from a 64-bit chunk base
+    if (2ull * chunk_samples + 2ull * (unsigned long long)nperseg > (1ull << 32)) return false;
     pl.rows = gj_welch_rows(nbytes, chunk_samples, nperseg);
     pl.batch = kBlockPoints / nperseg;
     pl.g.chunk_samples = chunk_samples;
@@ -465,7 +467,7 @@ int launch_welch(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_s
     WelchPlan pl;
     if (!(fs > 0.0)) return fail(ctx, GJ_ERR_INVALID, "fs must be > 0");
     if (!welch_plan(ctx, nbytes, chunk_samples, nperseg, fs, pl))
-        return fail(ctx, GJ_ERR_UNSUPPORTED, "nperseg must be a power of two in [16, 4096] and <= chunk_samples");
+        return fail(ctx, GJ_ERR_UNSUPPORTED, "nperseg must be a power of two in [16, 4096] and <= chunk_samples, chunk_samples < 2^31 - nperseg");
     if ((reinterpret_cast<uintptr_t>(d_iq) & 1) != 0) return fail(ctx, GJ_ERR_INVALID, "capture must be 2-byte aligned");
     if (pl.rows == 0) return GJ_OK;
     if ((unsigned long long)pl.g.nchunks * pl.g.splits > 0x7fffffffull) return fail(ctx, GJ_ERR_UNSUPPORTED, "too many chunks");

@@ -31,9 +31,20 @@ struct XcParams {
 constexpr int kMaxPairs = GJ_MAX_ANTENNAS * GJ_MAX_ANTENNAS / 2 + 8;
 
 struct XcCand {
-    float val;
-    int m;
+    float val;    // largest |c|^2
+    int m;        // its 'full'-mode index (first one on a tie: numpy.argmax)
+    float val2;   // largest |c|^2 at any OTHER index (decision margin, gj_xcorr_lags_dev d_margins)
+    int pad;
 };
+
+// winner of two candidates; the loser's peak becomes a runner-up of the winner
+__device__ __forceinline__ XcCand xc_merge(XcCand a, XcCand b) {
+    const bool take_b = b.val > a.val || (b.val == a.val && b.m < a.m);
+    XcCand w = take_b ? b : a;
+    const XcCand l = take_b ? a : b;
+    w.val2 = fmaxf(w.val2, l.val);
+    return w;
+}
 
 __device__ __forceinline__ c2 twiddle_big(unsigned long long m, unsigned long long L) {
     // exp(-2 pi i m / L), m < L <= 2^24: the ratio is exact in float
@@ -57,11 +68,12 @@ __device__ __forceinline__ void xc_passes(c2 (&v)[16], cf* lds, int base, int jl
     }
 }
 
-__global__ void xc_prepare_kernel(XcParams P, const long long* __restrict__ starts, long long* __restrict__ eff,
-                                  int* __restrict__ valid) {
+// starts[a * stride]: contiguous array (stride 1) or the header words of TDOA slots
+__global__ void xc_prepare_kernel(XcParams P, const long long* __restrict__ starts, size_t stride,
+                                  long long* __restrict__ eff, int* __restrict__ valid) {
     const int a = threadIdx.x;
     if (a >= P.n_ant) return;
-    const long long s = starts[a];
+    const long long s = starts[(size_t)a * stride];
     const bool ok = s >= 0 && (unsigned long long)s + P.n <= P.nsamples[a];
     valid[a] = ok;
     eff[a] = ok ? s : 0;
@@ -126,8 +138,7 @@ __global__ __launch_bounds__(kBlockThreads) void xc_cols_kernel(XcParams P, cons
             w = cmul(w, step);
         }
     } else {
-        float best = -1.f;
-        int best_m = 0x7fffffff;
+        XcCand c{-1.f, 0x7fffffff, -1.f, 0};
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const unsigned long long n = (unsigned long long)(jl + TF * s) * kRow + n2;
@@ -136,20 +147,22 @@ __global__ __launch_bounds__(kBlockThreads) void xc_cols_kernel(XcParams P, cons
             else if (n > P.L - P.n) m = (long long)n - (long long)P.L + (long long)P.n - 1;   // lag = n - L < 0
             else continue;
             const float val = v[s].x * v[s].x + v[s].y * v[s].y;
-            if (val > best || (val == best && (int)m < best_m)) { best = val; best_m = (int)m; }
+            c = xc_merge(c, XcCand{val, (int)m, -1.f, 0});
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(best, off, 64);
-            const int om = __shfl_xor(best_m, off, 64);
-            if (ov > best || (ov == best && om < best_m)) { best = ov; best_m = om; }
+            XcCand o;
+            o.val = __shfl_xor(c.val, off, 64);
+            o.m = __shfl_xor(c.m, off, 64);
+            o.val2 = __shfl_xor(c.val2, off, 64);
+            o.pad = 0;
+            c = xc_merge(c, o);
         }
-        if ((tid & 63) == 0) red[tid >> 6] = XcCand{best, best_m};
+        if ((tid & 63) == 0) red[tid >> 6] = c;
         __syncthreads();
         if (tid == 0) {
             XcCand r = red[0];
-            for (int k = 1; k < kBlockThreads / 64; ++k)
-                if (red[k].val > r.val || (red[k].val == r.val && red[k].m < r.m)) r = red[k];
+            for (int k = 1; k < kBlockThreads / 64; ++k) r = xc_merge(r, red[k]);
             cand[(size_t)t * gridDim.x + blockIdx.x] = r;
         }
     }
@@ -234,22 +247,15 @@ __global__ __launch_bounds__(kBlockThreads) void xc_rows_pair_kernel(XcParams P,
 
 __global__ __launch_bounds__(256) void xc_finalize_kernel(XcParams P, const XcCand* __restrict__ cand, unsigned ncand,
                                                           const int* __restrict__ valid, int* __restrict__ lags,
-                                                          float* __restrict__ peaks) {
+                                                          float* __restrict__ peaks, float* __restrict__ margins) {
     __shared__ XcCand red[256];
     const int p = blockIdx.x;
-    XcCand r{-1.f, 0x7fffffff};
-    for (unsigned k = threadIdx.x; k < ncand; k += blockDim.x) {
-        const XcCand c = cand[(size_t)p * ncand + k];
-        if (c.val > r.val || (c.val == r.val && c.m < r.m)) r = c;
-    }
+    XcCand r{-1.f, 0x7fffffff, -1.f, 0};
+    for (unsigned k = threadIdx.x; k < ncand; k += blockDim.x) r = xc_merge(r, cand[(size_t)p * ncand + k]);
     red[threadIdx.x] = r;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) {
-            const XcCand c = red[threadIdx.x + off];
-            XcCand& mine = red[threadIdx.x];
-            if (c.val > mine.val || (c.val == mine.val && c.m < mine.m)) mine = c;
-        }
+        if ((int)threadIdx.x < off) red[threadIdx.x] = xc_merge(red[threadIdx.x], red[threadIdx.x + off]);
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -257,6 +263,8 @@ __global__ __launch_bounds__(256) void xc_finalize_kernel(XcParams P, const XcCa
         lags[p] = ok ? red[0].m - (int)(P.n - 1) : GJ_LAG_INVALID;
         // inputs were 2(u-127.5): |c| = sqrt(val) / L / 4
         peaks[p] = ok ? sqrtf(red[0].val) * (0.25f / (float)P.L) : 0.f;
+        // relative gap between the peak and the largest |c| at any other lag
+        if (margins) margins[p] = (ok && red[0].val > 0.f) ? 1.0f - sqrtf(fmaxf(red[0].val2, 0.f) / red[0].val) : 0.f;
     }
 }
 
@@ -301,7 +309,8 @@ static void xc_cols(gj_ctx* ctx, int mode, const XcParams& P, int count, const l
 }
 
 int launch_xcorr(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, int n_ant, const int64_t* d_starts,
-                 size_t n_samples, const int32_t* pairs, int n_pairs, int32_t* d_lags, float* d_peaks) {
+                 size_t starts_stride, size_t n_samples, const int32_t* pairs, int n_pairs, int32_t* d_lags,
+                 float* d_peaks, float* d_margins) {
     if (n_ant < 1 || n_ant > GJ_MAX_ANTENNAS) return fail(ctx, GJ_ERR_INVALID, "n_ant must be 1..%d", GJ_MAX_ANTENNAS);
     if (n_pairs < 1 || n_pairs > kMaxPairs) return fail(ctx, GJ_ERR_INVALID, "n_pairs must be 1..%d", kMaxPairs);
     if (n_samples < 1) return fail(ctx, GJ_ERR_INVALID, "n_samples must be >= 1");
@@ -334,7 +343,8 @@ int launch_xcorr(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, 
     long long* eff = reinterpret_cast<long long*>(cand + (size_t)n_pairs * ncand);
     int* valid = reinterpret_cast<int*>(eff + GJ_MAX_ANTENNAS);
 
-    hipLaunchKernelGGL(xc_prepare_kernel, dim3(1), dim3(64), 0, ctx->stream, P, (const long long*)d_starts, eff, valid);
+    hipLaunchKernelGGL(xc_prepare_kernel, dim3(1), dim3(64), 0, ctx->stream, P, (const long long*)d_starts, starts_stride,
+                       eff, valid);
     GJ_LAUNCH_CHECK(ctx);
     xc_cols(ctx, 0, P, n_ant, eff, valid, spec, nullptr);
     GJ_LAUNCH_CHECK(ctx);
@@ -353,7 +363,49 @@ int launch_xcorr(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, 
     xc_cols(ctx, 1, P, n_pairs, eff, valid, dbuf, cand);
     GJ_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(xc_finalize_kernel, dim3((unsigned)n_pairs), dim3(256), 0, ctx->stream, P, cand, (unsigned)ncand,
-                       valid, d_lags, d_peaks);
+                       valid, d_lags, d_peaks, d_margins);
+    GJ_LAUNCH_CHECK(ctx);
+    return GJ_OK;
+}
+
+// ---- TDOA slot: the onset-aligned slice of one capture + a validity header, as one message ----
+// [int64 flag: 0 = valid, -1 = invalid][int64 start sample in the sender's capture][2 n bytes of I/Q]
+__global__ __launch_bounds__(256) void tdoa_slot_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
+                                                        const long long* __restrict__ start, size_t n,
+                                                        uint8_t* __restrict__ slot) {
+    const long long s = *start;
+    const bool ok = s >= 0 && (unsigned long long)s + n <= nsamples;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        long long* h = reinterpret_cast<long long*>(slot);
+        h[0] = ok ? 0 : -1;
+        h[1] = s;
+    }
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(iq) + (ok ? s : 0);
+    uint4* dst = reinterpret_cast<uint4*>(slot + GJ_SLOT_HEADER);
+    const size_t ngroups = (n + 7) / 8;   // the slot is padded to a multiple of 256 bytes
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < ngroups; g += (size_t)gridDim.x * blockDim.x) {
+        unsigned w[4] = {0, 0, 0, 0};
+        if (ok) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const size_t i = g * 8 + k;
+                const unsigned v = (i < n) ? src[i] : 0u;
+                w[k >> 1] |= v << (16 * (k & 1));
+            }
+        }
+        dst[g] = uint4{w[0], w[1], w[2], w[3]};
+    }
+}
+
+int launch_tdoa_slot(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, const int64_t* d_start, size_t n_samples,
+                     uint8_t* d_slot) {
+    if (n_samples < 1) return fail(ctx, GJ_ERR_INVALID, "n_samples must be >= 1");
+    if ((reinterpret_cast<uintptr_t>(d_iq) & 1) != 0) return fail(ctx, GJ_ERR_INVALID, "capture must be 2-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(d_slot) & 15) != 0) return fail(ctx, GJ_ERR_INVALID, "slot must be 16-byte aligned");
+    size_t blocks = ((n_samples + 7) / 8 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(tdoa_slot_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_iq, nbytes / 2,
+                       (const long long*)d_start, n_samples, d_slot);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
 }

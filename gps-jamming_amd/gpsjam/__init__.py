@@ -24,8 +24,9 @@ from . import _ffi
 from ._ffi import (AmpStats, GpsJamError, GpsJamLibraryError, Onset, SynthParams,  # noqa: F401
                    GJ_LAG_INVALID, GJ_MAX_ANTENNAS)
 
-__all__ = ["Device", "DevBuf", "GpsJamError", "GpsJamLibraryError", "device_count",
-           "library_path", "as_u8", "default_device", "read_capture"]
+__all__ = ["Device", "DevBuf", "Capture", "GpsJamError", "GpsJamLibraryError", "device_count",
+           "library_path", "as_u8", "default_device", "read_capture", "resident_capture",
+           "release_resident"]
 
 _default = None
 _default_lock = __import__("threading").Lock()
@@ -48,6 +49,40 @@ def read_capture(path) -> np.ndarray:
     if os.path.getsize(path) == 0:
         return np.zeros(0, np.uint8)
     return np.memmap(path, dtype=np.uint8, mode="r")
+
+
+_resident = {}            # (realpath, size, mtime_ns) -> Capture, insertion order = LRU order
+_resident_lock = __import__("threading").Lock()
+
+
+def resident_capture(path) -> "Capture":
+    """The capture file ``path`` in HBM on the default device, uploaded on first use and kept
+    (process-wide, least-recently-used eviction above GPSJAM_RESIDENT_GIB, default 64 of the
+    288 GB): the worker's power scan, the RSSI solver and the PSD script all read the same
+    files (worker.py:209-217 -> :590-600 -> triangulateRSSI.py:29), and each used to pay its own
+    host->device pass.  Raises FileNotFoundError like open()."""
+    import os
+    st = os.stat(path)
+    key = (os.path.realpath(path), st.st_size, st.st_mtime_ns)
+    dev = default_device()
+    with _resident_lock:
+        cap = _resident.pop(key, None)
+        if cap is not None and cap.ptr and cap.dev is dev:
+            _resident[key] = cap                      # most recently used last
+            return cap
+        limit = int(float(os.environ.get("GPSJAM_RESIDENT_GIB", "64")) * (1 << 30))
+        while _resident and sum(c.nbytes for c in _resident.values()) + st.st_size > limit:
+            _resident.pop(next(iter(_resident))).free()
+        cap = dev.capture(path)
+        _resident[key] = cap
+        return cap
+
+
+def release_resident():
+    """Free every cached capture (tests; long-running hosts that switch file sets)."""
+    with _resident_lock:
+        while _resident:
+            _resident.popitem()[1].free()
 
 
 def library_path() -> str:
@@ -75,7 +110,7 @@ def _ptr(x) -> int:
         return 0
     if isinstance(x, int):
         return x
-    if isinstance(x, DevBuf):
+    if isinstance(x, (DevBuf, Capture)):
         return x.ptr
     if hasattr(x, "data_ptr"):
         return int(x.data_ptr())
@@ -120,6 +155,67 @@ class DevBuf:
             pass
 
 
+class Capture:
+    """One capture resident in HBM: uploaded ONCE (file -> pinned bounce buffers -> HBM, or from
+    a uint8 array), then handed to ``Device.chunk_power / welch / amp_stats / onset /
+    byte_histogram / xcorr_lags_at`` any number of times.  The array-taking forms of those calls
+    stage their input on every call (21 ms per GiB of PCIe against 0.2-1.3 ms of kernel time), so
+    a caller that runs scan + PSD + RSSI on one file (widmo_plot, the worker's scan ->
+    triangulation flow) uses this instead.  ``uploads`` counts host->device passes (tests)."""
+
+    uploads = 0
+
+    def __init__(self, dev: "Device", source, offset: int = 0, max_bytes: int = 0):
+        import os
+        self.dev = dev
+        p, n = C.c_void_p(), C.c_size_t(0)
+        if isinstance(source, (str, bytes, os.PathLike)):
+            self.path = os.fspath(source)
+            dev._check(dev._lib.gj_upload_file(dev._ctx, os.fsencode(self.path), int(offset), int(max_bytes),
+                                               C.byref(p), C.byref(n)))
+            self.nbytes = n.value
+        else:
+            self.path = None
+            raw = as_u8(source)
+            if offset or max_bytes:
+                raw = raw[offset:offset + max_bytes] if max_bytes else raw[offset:]
+            dev._check(dev._lib.gj_upload(dev._ctx, raw.ctypes.data if raw.size else None, raw.size, C.byref(p)))
+            self.nbytes = int(raw.size)
+        self.ptr = p.value or 0
+        Capture.uploads += 1
+
+    @property
+    def nsamples(self) -> int:
+        return self.nbytes // 2
+
+    def download(self, offset: int = 0, count: Optional[int] = None) -> np.ndarray:
+        """Bytes [offset, offset + count) back on the host (tests, near-tie re-evaluation)."""
+        if count is None:
+            count = self.nbytes - offset
+        count = max(0, min(count, self.nbytes - offset))
+        out = np.empty(count, np.uint8)
+        if count:
+            self.dev._check(self.dev._lib.gj_memcpy_d2h(self.dev._ctx, out.ctypes.data, self.ptr + offset, count))
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", 0) and getattr(self.dev, "_ctx", None):
+            self.dev._lib.gj_free(self.dev._ctx, self.ptr)
+        self.ptr = 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.free()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Device:
     def __init__(self, index: int = 0):
         self._lib = _ffi.load()
@@ -130,6 +226,7 @@ class Device:
         self._ctx = ctx
         self.index = int(index)
         self.last_kernel_ms = 0.0
+        self._scratch = None          # grow-only device buffer for the results of calls on a Capture
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc: int):
@@ -137,7 +234,24 @@ class Device:
             detail = self._lib.gj_last_error(self._ctx).decode(errors="replace")
             raise GpsJamError(rc, f"{self._lib.gj_strerror(rc).decode()}: {detail}")
 
+    def capture(self, source, offset: int = 0, max_bytes: int = 0) -> Capture:
+        """Upload a capture file (path) or a uint8 array once; see ``Capture``."""
+        return Capture(self, source, offset, max_bytes)
+
+    def _out(self, nbytes: int) -> DevBuf:
+        if self._scratch is None or self._scratch.nbytes < nbytes:
+            if self._scratch is not None:
+                self._scratch.free()
+            self._scratch = DevBuf(self, max(int(nbytes) + 256, 1 << 16))
+        return self._scratch
+
     def close(self):
+        if getattr(self, "_scratch", None) is not None:
+            try:
+                self._scratch.free()
+            except Exception:
+                pass
+            self._scratch = None
         if getattr(self, "_ctx", None):
             self._lib.gj_destroy(self._ctx)
             self._ctx = None
@@ -185,6 +299,16 @@ class Device:
     # ------------------------------------------------------------------ host arrays
     def chunk_power(self, raw, chunk_bytes: int = 65536, eps: float = 1e-10,
                     odd_chunk_zero: bool = False) -> np.ndarray:
+        if isinstance(raw, Capture):
+            n = self._lib.gj_chunk_count(raw.nbytes, chunk_bytes)
+            if n == 0:
+                return np.empty(0, np.float32)
+            d = self._out(4 * n)
+            self.timer_start()
+            self.chunk_power_dev(raw, raw.nbytes, chunk_bytes, d, eps,
+                                 _ffi.GJ_CP_ODD_CHUNK_ZERO if odd_chunk_zero else 0)
+            self.last_kernel_ms = self.timer_stop()
+            return d.download(np.float32, n)
         raw = as_u8(raw)
         n = self._lib.gj_chunk_count(raw.size, chunk_bytes)
         out = np.empty(n, np.float32)
@@ -199,6 +323,20 @@ class Device:
     def welch(self, raw, chunk_samples: int = 2048000, nperseg: int = 1024, fs: float = 2.048e6,
               shift: bool = True, want_db: bool = True):
         """(psd[rows, nperseg], psd_db[rows, nperseg] | None), float32."""
+        if isinstance(raw, Capture):
+            rows = self._lib.gj_welch_rows(raw.nbytes, chunk_samples, nperseg)
+            if rows == 0:
+                if nperseg < 16 or nperseg > 4096 or (nperseg & (nperseg - 1)):
+                    raise GpsJamError(-5, "unsupported size or parameter: nperseg must be a power of two in [16, 4096]")
+                return np.empty((0, nperseg), np.float32), (np.empty((0, nperseg), np.float32) if want_db else None)
+            nfl = rows * nperseg
+            d = self._out(8 * nfl)
+            self.timer_start()
+            self.welch_dev(raw, raw.nbytes, chunk_samples, nperseg, fs, d.ptr, d.ptr + 4 * nfl if want_db else None, shift)
+            self.last_kernel_ms = self.timer_stop()
+            psd = d.download(np.float32, nfl).reshape(rows, nperseg)
+            db = d.download(np.float32, nfl, offset=4 * nfl).reshape(rows, nperseg) if want_db else None
+            return psd, db
         raw = as_u8(raw)
         rows = self._lib.gj_welch_rows(raw.size, chunk_samples, nperseg)
         psd = np.empty((rows, nperseg), np.float32)
@@ -212,6 +350,12 @@ class Device:
         return psd, db
 
     def amp_stats(self, raw, threshold: float) -> AmpStats:
+        if isinstance(raw, Capture):
+            d = self._out(64)
+            self.timer_start()
+            self.amp_stats_dev(raw, raw.nbytes, threshold, d)
+            self.last_kernel_ms = self.timer_stop()
+            return AmpStats.from_buffer_copy(d.download(np.uint8, C.sizeof(AmpStats)).tobytes())
         raw = as_u8(raw)
         out, ms = AmpStats(), C.c_float(0)
         self._check(self._lib.gj_amp_stats_u8(self._ctx, raw.ctypes.data, raw.size, threshold,
@@ -221,6 +365,12 @@ class Device:
 
     def onset(self, raw, noise_samples: int = 200000, window: int = 1000,
               factor: float = 50.0) -> Onset:
+        if isinstance(raw, Capture):
+            d = self._out(64)
+            self.timer_start()
+            self.onset_dev(raw, raw.nbytes, noise_samples, window, factor, d)
+            self.last_kernel_ms = self.timer_stop()
+            return Onset.from_buffer_copy(d.download(np.uint8, C.sizeof(Onset)).tobytes())
         raw = as_u8(raw)
         out, ms = Onset(), C.c_float(0)
         self._check(self._lib.gj_onset_u8(self._ctx, raw.ctypes.data, raw.size, noise_samples,
@@ -228,8 +378,38 @@ class Device:
         self.last_kernel_ms = ms.value
         return out
 
-    def xcorr_lags(self, slices: Sequence, pairs: Sequence[Sequence[int]]):
-        """lags[p], peaks[p] for pairs (i, j): lag of slice j relative to slice i
+    def xcorr_lags_at(self, captures: Sequence["Capture"], starts: Sequence[int], n_samples: int,
+                      pairs: Sequence[Sequence[int]], want_margins: bool = False):
+        """Lags between resident captures: slice a = n_samples I/Q pairs of captures[a] from
+        starts[a] (negative / out of range -> GJ_LAG_INVALID for its pairs).  No slice ever
+        leaves HBM."""
+        flat = np.asarray(pairs, np.int32).reshape(-1)
+        npairs = flat.size // 2
+        na = len(captures)
+        d = self._out(8 * na + 12 * npairs + 64)
+        off_l = 8 * na
+        d.upload(np.asarray(starts, np.int64))
+        self.timer_start()
+        self.xcorr_lags_dev(captures, [c.nbytes for c in captures], d.ptr, n_samples, pairs, d.ptr + off_l,
+                            d.ptr + off_l + 4 * npairs, d.ptr + off_l + 8 * npairs)
+        self.last_kernel_ms = self.timer_stop()
+        lags = d.download(np.int32, npairs, offset=off_l)
+        peaks = d.download(np.float32, npairs, offset=off_l + 4 * npairs)
+        if want_margins:
+            return lags, peaks, d.download(np.float32, npairs, offset=off_l + 8 * npairs)
+        return lags, peaks
+
+    def byte_histogram(self, cap: "Capture", chunk_samples: int = 2048000, nperseg: int = 1024,
+                       stride: int = 100) -> np.ndarray:
+        """256-bin histogram of raw_chunk[::stride] over the chunks the waterfall keeps
+        (widmo_plot.py:35,85)."""
+        d = self._out(8 * 256)
+        self.byte_histogram_dev(cap, cap.nbytes, chunk_samples, nperseg, stride, d)
+        self.synchronize()
+        return d.download(np.uint64, 256)
+
+    def xcorr_lags(self, slices: Sequence, pairs: Sequence[Sequence[int]], want_margins: bool = False):
+        """lags[p], peaks[p] (, margins[p]) for pairs (i, j): lag of slice j relative to slice i
         (= argmax|correlate(slice_j, slice_i, 'full')| - (N-1))."""
         arrs = [as_u8(s) for s in slices]
         n = arrs[0].size // 2
@@ -240,12 +420,15 @@ class Device:
         npairs = flat.size // 2
         lags = np.empty(npairs, np.int32)
         peaks = np.empty(npairs, np.float32)
+        margins = np.empty(npairs, np.float32)
         ms = C.c_float(0)
         self._check(self._lib.gj_xcorr_lags_u8(
             self._ctx, ptrs, len(arrs), n, flat.ctypes.data_as(C.POINTER(C.c_int32)), npairs,
             lags.ctypes.data_as(C.POINTER(C.c_int32)), peaks.ctypes.data_as(C.POINTER(C.c_float)),
-            C.byref(ms)))
+            margins.ctypes.data_as(C.POINTER(C.c_float)), C.byref(ms)))
         self.last_kernel_ms = ms.value
+        if want_margins:
+            return lags, peaks, margins
         return lags, peaks
 
     # ------------------------------------------------------------------ device pointers
@@ -292,14 +475,29 @@ class Device:
                                                  _ptr(d_power), rssi_threshold, _ptr(d_amp), noise_samples,
                                                  window, factor, _ptr(d_onset)))
 
-    def xcorr_lags_dev(self, d_iqs, nbytes_list, d_starts, n_samples, pairs, d_lags, d_peaks):
+    def tdoa_slot_bytes(self, n_samples: int) -> int:
+        return self._lib.gj_tdoa_slot_bytes(n_samples)
+
+    def tdoa_slot_dev(self, d_iq, nbytes, d_start, n_samples, d_slot):
+        """Cut the slice that starts at the DEVICE scalar *d_start into a TDOA slot."""
+        self._check(self._lib.gj_tdoa_slot_dev(self._ctx, _ptr(d_iq), nbytes, _ptr(d_start), n_samples, _ptr(d_slot)))
+
+    def xcorr_slots_dev(self, d_slots, slot_stride, n_ant, n_samples, pairs, d_lags, d_peaks, d_margins=None):
+        flat = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1))
+        self._check(self._lib.gj_xcorr_slots_dev(
+            self._ctx, _ptr(d_slots), slot_stride, n_ant, n_samples,
+            flat.ctypes.data_as(C.POINTER(C.c_int32)), flat.size // 2, _ptr(d_lags), _ptr(d_peaks),
+            _ptr(d_margins) or None))
+
+    def xcorr_lags_dev(self, d_iqs, nbytes_list, d_starts, n_samples, pairs, d_lags, d_peaks, d_margins=None):
         n_ant = len(d_iqs)
         ptrs = (C.c_void_p * n_ant)(*[_ptr(p) for p in d_iqs])
         sizes = (C.c_size_t * n_ant)(*[int(b) for b in nbytes_list])
         flat = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1))
         self._check(self._lib.gj_xcorr_lags_dev(
             self._ctx, ptrs, sizes, n_ant, _ptr(d_starts), n_samples,
-            flat.ctypes.data_as(C.POINTER(C.c_int32)), flat.size // 2, _ptr(d_lags), _ptr(d_peaks)))
+            flat.ctypes.data_as(C.POINTER(C.c_int32)), flat.size // 2, _ptr(d_lags), _ptr(d_peaks),
+            _ptr(d_margins) or None))
 
     def pack_result_dev(self, n_chunks, d_power, d_stats, d_amp, d_onset, d_lag, d_peak, d_psd, rows, nperseg, rank,
                         d_out):

@@ -30,7 +30,15 @@ class AmpStats(C.Structure):
 
 class Onset(C.Structure):
     _fields_ = [("start_index", C.c_int64), ("noise_power", C.c_float),
-                ("threshold", C.c_float)]
+                ("threshold", C.c_float), ("margin_hit", C.c_float),
+                ("margin_before", C.c_float), ("reserved", C.c_int64)]
+
+    @property
+    def margin(self) -> float:
+        """Smaller of the two decision margins (see include/gpsjam.h, gj_onset)."""
+        if self.start_index < 0:
+            return float(self.margin_before)
+        return float(min(self.margin_hit, self.margin_before))
 
 
 class SynthParams(C.Structure):
@@ -43,6 +51,9 @@ GJ_CP_ODD_CHUNK_ZERO = 1
 GJ_WELCH_SHIFT = 1
 GJ_MAX_ANTENNAS = 16
 GJ_LAG_INVALID = -(1 << 31)
+GJ_SLOT_HEADER = 16
+GJ_COMM_ID_BYTES = 128
+GJ_VERSION = 110
 
 _vp, _sz, _i, _f, _d = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double
 _pf, _psz = C.POINTER(C.c_float), C.POINTER(C.c_size_t)
@@ -63,6 +74,8 @@ SIGNATURES = {
     "gj_free": (_i, [_vp, _vp]),
     "gj_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "gj_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "gj_upload": (_i, [_vp, _vp, _sz, C.POINTER(_vp)]),
+    "gj_upload_file": (_i, [_vp, C.c_char_p, _sz, _sz, C.POINTER(_vp), _psz]),
     "gj_timer_start": (_i, [_vp]),
     "gj_timer_stop": (_i, [_vp, _pf]),
     "gj_chunk_count": (_sz, [_sz, _sz]),
@@ -80,9 +93,18 @@ SIGNATURES = {
     "gj_onset_u8": (_i, [_vp, _vp, _sz, _i, _i, _f, C.POINTER(Onset), _pf]),
     "gj_stream_scan_dev": (_i, [_vp, _vp, _sz, _sz, _f, _i, _vp, _f, _vp, _i, _i, _f, _vp]),
     "gj_xcorr_lags_dev": (_i, [_vp, C.POINTER(_vp), _psz, _i, _vp, _sz, C.POINTER(C.c_int32), _i,
-                               _vp, _vp]),
+                               _vp, _vp, _vp]),
     "gj_xcorr_lags_u8": (_i, [_vp, C.POINTER(_vp), _i, _sz, C.POINTER(C.c_int32), _i,
-                              C.POINTER(C.c_int32), _pf, _pf]),
+                              C.POINTER(C.c_int32), _pf, _pf, _pf]),
+    "gj_tdoa_slot_bytes": (_sz, [_sz]),
+    "gj_tdoa_slot_dev": (_i, [_vp, _vp, _sz, _vp, _sz, _vp]),
+    "gj_xcorr_slots_dev": (_i, [_vp, _vp, _sz, _i, _sz, C.POINTER(C.c_int32), _i, _vp, _vp, _vp]),
+    "gj_comm_unique_id": (_i, [_vp]),
+    "gj_comm_init_rank": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "gj_comm_rank": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "gj_comm_gather_dev": (_i, [_vp, _vp, _sz, _vp, _i]),
+    "gj_comm_bcast_dev": (_i, [_vp, _vp, _sz, _i]),
+    "gj_comm_destroy": (_i, [_vp]),
     "gj_xcorr_workspace": (_sz, [_vp, _i, _sz, _i]),
     "gj_pack_result_dev": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp]),
     "gj_synth_u8_dev": (_i, [_vp, C.POINTER(SynthParams), C.c_int64, _sz, _vp]),

@@ -1,23 +1,28 @@
-"""One antenna capture per GPU (one process per GPU, torch.distributed over RCCL/xGMI).
+"""One antenna capture per GPU (one process per GPU; RCCL over xGMI through torch.distributed
+or through the library's own gj_comm_* entry points).
 
-The per-capture kernels (K1 power scan, K2 Welch PSD, K3 amplitude statistics, K4 onset)
-are independent across captures, so captures are sharded one per rank with no data-path
-collective.  The only real exchange of the path is TDOA: every rank correlates its own
-onset-aligned slice against the reference antenna's slice (rank 0), which is broadcast
-(2 bytes x slice samples, 1 MiB for 2^19) -- then one gather of a small fixed-layout result
-vector (power map, noise floor, threshold, amplitude statistics, onset, lag, peak, mean
-spectrum) to rank 0, which runs the host-side solvers (grid search / bearing).
+The per-capture kernels (K1 power scan, K2 Welch PSD, K3 amplitude statistics, K4 onset) are
+independent across captures, so captures are sharded one per rank with no data-path
+collective.  The one real exchange of the path is TDOA (skrypty/triangulateTDOA.py:60-90
+generalised from two antennas to N): every rank cuts its onset-aligned slice into a *TDOA
+slot* (16-byte validity header + 2 bytes per sample: 1 MiB for 2^19 samples), ONE gather
+brings the slots to rank 0, and rank 0 solves EVERY antenna pair (i, j), i < j, with one
+multi-pair K5 launch (N forward + N(N-1)/2 inverse 2^20-point transforms, L2 / Infinity-Cache
+resident).  A second gather brings each rank's fixed-layout result vector (power map, noise
+floor, threshold, amplitude statistics, onset, mean spectrum) to rank 0, which runs the
+host-side solvers (grid search / bearing).  An un-found onset or a slice that runs off the end
+of a capture marks that slot invalid and every pair with that antenna comes back as
+GJ_LAG_INVALID (the reference aborts there, triangulateTDOA.py:67-77).
 
-``pack_results`` / ``unpack_results`` / ``exchange`` only touch torch tensors and
-torch.distributed, so they run unchanged on CPU tensors with the gloo backend (tests) and on
+``pack_results`` / ``unpack_results`` / ``make_slot`` / ``gather_rows`` only touch torch tensors
+and torch.distributed, so they run unchanged on CPU tensors with the gloo backend (tests) and on
 HIP tensors with the nccl (= RCCL) backend (bench.py).
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
-from typing import List, Optional
-
 import contextlib
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -26,10 +31,23 @@ HEADER = 16          # scalars in front of the vectors, see RESULT_FIELDS
 RESULT_FIELDS = ("n_chunks", "baseline", "threshold", "n_above", "amp_first", "amp_count",
                  "amp_mean", "onset", "lag", "peak", "noise_power", "n_rows", "nperseg",
                  "rank", "reserved0", "reserved1")
+SLOT_HEADER = 16     # GJ_SLOT_HEADER: int64 flag (0 valid / -1 invalid), int64 start sample
+LAG_INVALID = -(1 << 31)
 
 
 def result_len(n_chunks: int, nperseg: int) -> int:
     return HEADER + n_chunks + nperseg
+
+
+def slot_bytes(n_samples: int) -> int:
+    """gj_tdoa_slot_bytes: header + slice, padded to a multiple of 256 bytes."""
+    return (SLOT_HEADER + 2 * n_samples + 255) // 256 * 256
+
+
+def all_pairs(n_ant: int) -> List[Tuple[int, int]]:
+    """(i, j), i < j: lag of antenna j relative to antenna i, for every pair
+    (BASELINE configs[3]: 3 antennas -> (0,1), (0,2), (1,2))."""
+    return [(i, j) for i in range(n_ant) for j in range(i + 1, n_ant)]
 
 
 def pack_results(n_chunks: int, nperseg: int, power_map: torch.Tensor, stats: torch.Tensor,
@@ -67,7 +85,7 @@ class StreamResult:
     amp_count: int
     amp_mean: float
     onset: int
-    lag: int
+    lag: int               # lag of this antenna relative to antenna 0 (pair (0, rank)); 0 for rank 0
     peak: float
     noise_power: float
     mean_spectrum: np.ndarray
@@ -87,6 +105,19 @@ class StreamResult:
         return [(int(s) * chunk_bytes, int(e) * chunk_bytes) for s, e in zip(starts, ends)]
 
 
+@dataclass
+class TdoaResult:
+    """Every antenna pair solved on rank 0: lags[p] = lag of antenna pairs[p][1] relative to
+    antenna pairs[p][0] in samples (LAG_INVALID when one of the two slots was invalid)."""
+    pairs: List[Tuple[int, int]] = field(default_factory=list)
+    lags: List[int] = field(default_factory=list)
+    peaks: List[float] = field(default_factory=list)
+    margins: List[float] = field(default_factory=list)
+
+    def lag(self, i: int, j: int) -> int:
+        return self.lags[self.pairs.index((i, j))]
+
+
 def unpack_results(vec: torch.Tensor) -> StreamResult:
     v = vec.detach().to("cpu", torch.float64).numpy()
     n_chunks, nperseg = int(v[0]), int(v[12])
@@ -98,36 +129,115 @@ def unpack_results(vec: torch.Tensor) -> StreamResult:
                         noise_power=float(v[10]), mean_spectrum=spec)
 
 
-def broadcast_reference_slice(slice_i16: torch.Tensor, world_size: int, src: int = 0) -> torch.Tensor:
-    """Rank ``src``'s onset-aligned slice (int16 view of the I/Q byte pairs) to every rank."""
-    if world_size > 1:
-        import torch.distributed as dist
-        dist.broadcast(slice_i16.view(torch.uint8), src=src)   # neither gloo nor RCCL moves int16
-    return slice_i16
+def make_slot(capture_u8: torch.Tensor, start: int, n_samples: int) -> torch.Tensor:
+    """TDOA slot of one capture with torch ops only (the CPU twin of gj_tdoa_slot_dev for the
+    gloo rehearsal of the exchange; the GPU pipeline uses the kernel)."""
+    slot = torch.zeros(slot_bytes(n_samples), dtype=torch.uint8, device=capture_u8.device)
+    ok = start >= 0 and 2 * (start + n_samples) <= capture_u8.numel()
+    head = torch.tensor([0 if ok else -1, int(start)], dtype=torch.int64).view(torch.uint8)
+    slot[:SLOT_HEADER] = head.to(slot.device)
+    if ok:
+        slot[SLOT_HEADER:SLOT_HEADER + 2 * n_samples] = capture_u8[2 * start:2 * (start + n_samples)]
+    return slot
+
+
+def slot_fields(slot: torch.Tensor, n_samples: int):
+    """(valid, start, uint8 slice) of one slot (host side; tests)."""
+    raw = slot.detach().cpu().contiguous()
+    flag, start = raw[:SLOT_HEADER].view(torch.int64).tolist()
+    return flag == 0, start, raw[SLOT_HEADER:SLOT_HEADER + 2 * n_samples].numpy()
+
+
+def gather_rows(row: torch.Tensor, rank: int, world_size: int, dst: int = 0,
+                out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """Every rank's ``row`` on ``dst`` as one [world, len] tensor (rows in rank order); None on the
+    other ranks.  One collective (torch.distributed.gather: RCCL on HIP tensors, gloo on CPU)."""
+    if world_size == 1:
+        return row.unsqueeze(0)
+    import torch.distributed as dist
+    if rank == dst:
+        if out is None:
+            out = torch.empty((world_size, row.numel()), dtype=row.dtype, device=row.device)
+        dist.gather(row, gather_list=[out[r] for r in range(world_size)], dst=dst)
+        return out
+    dist.gather(row, gather_list=None, dst=dst)
+    return None
 
 
 def gather_results(vec: torch.Tensor, rank: int, world_size: int, dst: int = 0) -> Optional[List[torch.Tensor]]:
     """Gather every rank's result vector on ``dst``; returns the list there, None elsewhere."""
-    if world_size == 1:
-        return [vec]
-    import torch.distributed as dist
-    if rank == dst:
-        out = [torch.empty_like(vec) for _ in range(world_size)]
-        dist.gather(vec, gather_list=out, dst=dst)
-        return out
-    dist.gather(vec, gather_list=None, dst=dst)
-    return None
+    rows = gather_rows(vec, rank, world_size, dst)
+    return None if rows is None else [rows[r] for r in range(rows.shape[0])]
+
+
+class StepResults:
+    """What ``AntennaStream.exchange`` returns on the solving rank: the gathered result vectors
+    and the pair lags, still in HBM, plus the event that marks them complete.  The collectives
+    and K5 run on the pipeline's second stream; a consumer on any other stream must call
+    ``wait()`` (or go through ``unpack()`` / indexing, which do) before reading the tensors.
+    The buffers are reused two steps later."""
+
+    def __init__(self, vectors, pairs, lags, peaks, margins, event, n_ant):
+        self.vectors, self.pairs = vectors, pairs
+        self.lags, self.peaks, self.margins = lags, peaks, margins
+        self.event, self.n_ant = event, n_ant
+
+    def wait(self, stream=None):
+        """Make ``stream`` (default: torch's current stream) wait for the exchange."""
+        if self.event is not None:
+            stream = stream or torch.cuda.current_stream(self.vectors.device)
+            stream.wait_event(self.event)
+            for t in (self.vectors, self.lags, self.peaks, self.margins):
+                if t is not None and t.is_cuda:
+                    t.record_stream(stream)
+        return self
+
+    def __len__(self):
+        return self.vectors.shape[0]
+
+    def __getitem__(self, r):
+        self.wait()
+        return self.vectors[r]
+
+    def tdoa(self) -> TdoaResult:
+        self.wait()
+        if self.lags is None:
+            return TdoaResult()
+        return TdoaResult(list(self.pairs), [int(x) for x in self.lags.cpu().tolist()],
+                          [float(x) for x in self.peaks.cpu().tolist()],
+                          [float(x) for x in self.margins.cpu().tolist()])
+
+    def unpack(self) -> Tuple[List[StreamResult], TdoaResult]:
+        """Host-side view: one StreamResult per rank (lag / peak = pair (0, rank)) and every pair."""
+        self.wait()
+        res = [unpack_results(self.vectors[r]) for r in range(self.vectors.shape[0])]
+        td = self.tdoa()
+        for r in res:
+            if r.rank == 0:
+                r.lag, r.peak = 0, 0.0
+            elif (0, r.rank) in td.pairs:
+                k = td.pairs.index((0, r.rank))
+                r.lag, r.peak = td.lags[k], td.peaks[k]
+        return res, td
 
 
 class AntennaStream:
     """Device-resident pipeline of one capture on one GPU (uses torch only for device
-    memory and the stream; every kernel is a gpsjam C-ABI call)."""
+    memory, streams and -- with ``transport="torch"`` -- the collectives; every kernel is a
+    gpsjam C-ABI call).
+
+    ``aux_slots`` (single-rank use): pre-filled TDOA slots of further antennas, [n_aux, slot_bytes]
+    uint8; the rank then solves all pairs over 1 + n_aux antennas itself (BASELINE configs[3]:
+    three antennas, three pairs on one GPU).
+    ``transport``: "torch" = torch.distributed (nccl = RCCL on HIP tensors, gloo for rehearsal);
+    "rccl" = the library's own gj_comm_* entry points (gpsjam.comm), no torch.distributed."""
 
     def __init__(self, dev, capture: torch.Tensor, *, chunk_bytes: int = 65536,
                  chunk_samples: int = 2048000, nperseg: int = 4096, fs: float = 2.048e6,
                  slice_samples: int = 1 << 19, noise_samples: int = 200000, window: int = 1000,
                  factor: float = 50.0, rssi_threshold: float = 0.0, rank: int = 0, world_size: int = 1,
-                 overlap: Optional[bool] = None):
+                 overlap: Optional[bool] = None, aux_slots: Optional[torch.Tensor] = None,
+                 transport="torch"):
         assert capture.dtype == torch.uint8 and capture.is_contiguous()
         self.dev, self.cap = dev, capture
         # K2 is VALU/LDS bound and leaves ~90 % of the HBM bandwidth idle, the fused scan is HBM
@@ -137,6 +247,7 @@ class AntennaStream:
             overlap = capture.is_cuda and hasattr(dev, "_ctx")
         self.overlap = bool(overlap)
         self.dev_side = dev
+        self._main = None
         if capture.is_cuda and hasattr(dev, "_ctx"):
             # the pipeline's torch ops, its events and the gpsjam kernels must share one stream
             self._main = torch.cuda.current_stream(capture.device)
@@ -147,7 +258,10 @@ class AntennaStream:
             self.dev_side.set_stream(self._side.cuda_stream)
             self._ev_free = torch.cuda.Event()      # main: previous results consumed, buffers may be rewritten
             self._ev_side = torch.cuda.Event()      # side: scan / TDOA results ready
+            self._ev_packed = torch.cuda.Event()    # main: this step's result vector is packed
             self._ev_free.record(self._main)
+        else:
+            self._side = self._main
         self.nbytes = capture.numel()
         self.rank, self.world = rank, world_size
         self.chunk_bytes, self.chunk_samples, self.nperseg, self.fs = chunk_bytes, chunk_samples, nperseg, fs
@@ -161,21 +275,49 @@ class AntennaStream:
         self.mask = torch.empty(self.n_chunks, dtype=torch.uint8, device=d)
         self.psd = torch.empty((max(self.rows, 1), nperseg), dtype=torch.float32, device=d)
         self.amp = torch.zeros(4, dtype=torch.int64, device=d)        # gj_amp_stats (32 bytes)
-        self.onset = torch.zeros(2, dtype=torch.int64, device=d)      # gj_onset (16 bytes)
-        self.starts = torch.zeros(2, dtype=torch.int64, device=d)
-        self.lag = torch.zeros(1, dtype=torch.int32, device=d)
-        self.peak = torch.zeros(1, dtype=torch.float32, device=d)
-        self.ref_slice = torch.zeros(slice_samples, dtype=torch.int16, device=d)
-        self._ar = torch.arange(slice_samples, dtype=torch.int64, device=d)
-        # two result vectors, used alternately: the gather of step k (second stream) may still be
-        # reading one while step k + 1 packs into the other
-        self._results = [torch.zeros(result_len(self.n_chunks, nperseg), dtype=torch.float64, device=d) for _ in range(2)]
-        self._result_idx = 0
+        self.onset = torch.zeros(4, dtype=torch.int64, device=d)      # gj_onset (32 bytes)
+        # this rank's own entry in its result vector: rank 0 is the reference antenna (lag 0); the
+        # other ranks' lags only exist on rank 0, which fills them in when it unpacks
+        self.lag_self = torch.full((1,), 0 if rank == 0 else LAG_INVALID, dtype=torch.int32, device=d)
+        self.peak_self = torch.zeros(1, dtype=torch.float32, device=d)
+        # TDOA: slots of every antenna this rank solves for (rank 0: all ranks; one rank: self + aux)
+        self.slot_bytes = dev.tdoa_slot_bytes(slice_samples)
+        n_aux = 0 if aux_slots is None else int(aux_slots.shape[0])
+        assert not (n_aux and world_size > 1), "aux_slots is the single-rank form"
+        self.n_ant = world_size if world_size > 1 else 1 + n_aux
+        self.is_root = rank == 0
+        self.pairs = all_pairs(self.n_ant) if self.is_root else []
+        self.slots = (torch.zeros((self.n_ant, self.slot_bytes), dtype=torch.uint8, device=d)
+                      if (self.is_root or world_size == 1) else None)
+        if n_aux:
+            assert aux_slots.shape[1] == self.slot_bytes and aux_slots.dtype == torch.uint8
+            self.slots[1:].copy_(aux_slots)
+        # collectives
+        self.comm = None
+        if transport == "rccl" and world_size > 1:
+            from .comm import Communicator
+            self.comm = Communicator(self.dev_side, rank, world_size)
+        elif not isinstance(transport, str):
+            self.comm = transport                  # a ready gpsjam.comm.Communicator on dev_side's context
+        self._exchange = world_size > 1 or self.comm is not None   # a communicator is used even when alone
+        # no exchange: the slot is written in place; otherwise a send buffer of its own on every rank
+        self.my_slot = self.slots[0] if not self._exchange else torch.zeros(self.slot_bytes, dtype=torch.uint8, device=d)
+        npairs = max(len(self.pairs), 1)
+        # two sets, used alternately: step k's consumer may still be reading one while step k + 1 fills the other
+        self._lags = [torch.full((npairs,), LAG_INVALID, dtype=torch.int32, device=d) for _ in range(2)]
+        self._peaks = [torch.zeros(npairs, dtype=torch.float32, device=d) for _ in range(2)]
+        self._margins = [torch.zeros(npairs, dtype=torch.float32, device=d) for _ in range(2)]
+        rl = result_len(self.n_chunks, nperseg)
+        self._results = [torch.zeros(rl, dtype=torch.float64, device=d) for _ in range(2)]
+        self._gathered = ([torch.zeros((world_size, rl), dtype=torch.float64, device=d) for _ in range(2)]
+                          if (self.is_root and self._exchange) else [None, None])
+        self._done = [torch.cuda.Event() for _ in range(2)] if capture.is_cuda else [None, None]
+        self._idx = 0
         self.result = self._results[0]
-        if self.overlap:
-            self._ev_packed = torch.cuda.Event()
         self.cap16 = capture.view(torch.int16)
-        ws_side = max(dev.xcorr_workspace(2, slice_samples, 1), self.nbytes // 48 + (1 << 20))
+        # workspaces
+        ws_side = max(dev.xcorr_workspace(self.n_ant, slice_samples, max(len(self.pairs), 1)),
+                      self.nbytes // 48 + (1 << 20))
         ws_main = dev.welch_workspace(self.nbytes, chunk_samples, nperseg)
         if self.overlap:
             dev.reserve(ws_main)
@@ -187,6 +329,7 @@ class AntennaStream:
         """Context manager: torch's current stream = the side stream (no-op without overlap)."""
         return torch.cuda.stream(self._side) if self.overlap else contextlib.nullcontext()
 
+    # ---------------------------------------------------------------- per-capture kernels
     def stream_scan(self):
         """K1 + K3 + K4 in one pass over the capture, then the noise-floor threshold."""
         if self.overlap:
@@ -206,61 +349,77 @@ class AntennaStream:
         self.stream_scan()
         self.welch()
 
+    # ---------------------------------------------------------------- the TDOA exchange
+    def _gather(self, row: torch.Tensor, out: Optional[torch.Tensor]):
+        """One gather to rank 0 on the side stream: torch.distributed or gj_comm_gather_dev."""
+        if self.comm is not None:
+            self.comm.gather(row, row.numel() * row.element_size(), out if self.is_root else None, 0)
+            return out
+        return gather_rows(row, self.rank, self.world, 0, out=out)
+
     def tdoa(self):
-        """Reference slice from rank 0 (broadcast), lag of this capture against it."""
+        """Own slice -> TDOA slot; slots of all ranks -> rank 0 (one gather); rank 0 solves every
+        antenna pair with one multi-pair K5 launch.  All on the second stream, beside K2."""
         with self._on_side():
-            self._tdoa(self.dev_side)
+            dev = self.dev_side
+            nxt = self._idx ^ 1                    # the set this step writes (pack() flips _idx)
+            dev.tdoa_slot_dev(self.cap, self.nbytes, self.onset, self.slice_samples, self.my_slot)
+            if self._exchange:
+                self._gather(self.my_slot, self.slots[:self.world] if self.is_root else None)
+            if self.is_root and self.pairs:
+                dev.xcorr_slots_dev(self.slots, self.slot_bytes, self.n_ant, self.slice_samples, self.pairs,
+                                    self._lags[nxt], self._peaks[nxt], self._margins[nxt])
             if self.overlap:
                 self._ev_side.record(self._side)
-
-    def _tdoa(self, dev):
-        n = self.slice_samples
-        nsamp = self.nbytes // 2
-        if self.world > 1:
-            if self.rank == 0:
-                idx = (self.onset[0] + self._ar).clamp_(0, nsamp - 1)
-                torch.index_select(self.cap16, 0, idx, out=self.ref_slice)
-            broadcast_reference_slice(self.ref_slice, self.world, 0)
-            # rank 0's onset travels in the slice's validity: an un-found onset (-1) on rank 0
-            # makes idx start at the clamp and the lag meaningless; rank 0 reports it.
-            self.starts[1:2].copy_(self.onset[0:1])          # starts[0] stays 0: the slice is already aligned
-            dev.xcorr_lags_dev([self.ref_slice, self.cap], [2 * n, self.nbytes], self.starts, n,
-                                    [(0, 1)], self.lag, self.peak)
-        else:
-            self.starts.copy_(self.onset[0:1].expand(2))
-            dev.xcorr_lags_dev([self.cap, self.cap], [self.nbytes, self.nbytes], self.starts, n,
-                                    [(0, 1)], self.lag, self.peak)
 
     def pack(self) -> torch.Tensor:
         """Result vector of this stream, built by one kernel (layout = pack_results)."""
         if self.overlap:
             self._main.wait_event(self._ev_side)
-        self._result_idx ^= 1
-        self.result = self._results[self._result_idx]
-        self.dev.pack_result_dev(self.n_chunks, self.power, self.stats, self.amp, self.onset, self.lag, self.peak,
-                                 self.psd, self.rows, self.nperseg, self.rank, self.result)
+        self._idx ^= 1
+        self.result = self._results[self._idx]
+        self.dev.pack_result_dev(self.n_chunks, self.power, self.stats, self.amp, self.onset, self.lag_self,
+                                 self.peak_self, self.psd, self.rows, self.nperseg, self.rank, self.result)
         if self.overlap:
             self._ev_free.record(self._main)
             self._ev_packed.record(self._main)
         return self.result
 
-    def exchange(self, dst: int = 0) -> Optional[List[torch.Tensor]]:
-        """Pack this step's result vector and gather every rank's on ``dst``.  With two streams the
+    def exchange(self, dst: int = 0) -> Optional[StepResults]:
+        """Pack this step's result vector and gather every rank's on rank 0.  With two streams the
         collective is issued on the second one (after the packing kernel), so the main stream goes
         straight on to the next step's K2 instead of waiting for the gather; the next step's scan
-        follows the gather in stream order, and a result buffer is rewritten only two steps later,
-        after a join that lies behind it."""
+        follows the gather in stream order.  The returned StepResults carries the event a consumer
+        on any other stream has to wait for (``wait()`` / ``unpack()``); buffers are reused two
+        steps later."""
+        assert dst == 0, "rank 0 solves"
         vec = self.pack()
-        if self.world == 1:
-            return [vec]
-        if not self.overlap:
-            return gather_results(vec, self.rank, self.world, dst)
-        self._side.wait_event(self._ev_packed)
-        with torch.cuda.stream(self._side):
-            return gather_results(vec, self.rank, self.world, dst)
+        k = self._idx
+        if not self._exchange:
+            rows = vec.unsqueeze(0)
+            if self._done[k] is not None:
+                self._done[k].record(self._main)
+        else:
+            if self.overlap:
+                self._side.wait_event(self._ev_packed)
+            with self._on_side():
+                rows = self._gather(vec, self._gathered[k])
+                if self._done[k] is not None:
+                    self._done[k].record(self._side)
+        if not self.is_root:
+            return None
+        has = bool(self.pairs)
+        return StepResults(rows, self.pairs, self._lags[k] if has else None, self._peaks[k] if has else None,
+                           self._margins[k] if has else None, self._done[k], self.n_ant)
 
-    def step(self):
+    def step(self) -> Optional[StepResults]:
         """One pass of the hot path over this rank's capture + the exchange."""
         self.scan()
         self.tdoa()
         return self.exchange(0)
+
+    def close(self):
+        if self.comm is not None and hasattr(self.comm, "close"):
+            self.comm.close()
+        if self.overlap and self.dev_side is not self.dev:
+            self.dev_side.close()

@@ -71,13 +71,13 @@ def _amplitude_statistics(iq_filename, threshold):
     """('ok', first_index, np.float32 mean amplitude) from the GPU, or ('unreadable' |
     'below_threshold', None, None).  Raises if the HIP library / GPU is unavailable."""
     try:
-        raw = gpsjam.read_capture(iq_filename)
+        cap = gpsjam.resident_capture(iq_filename)       # uploaded once per file, shared with the power scan
     except FileNotFoundError:
         print(f"BŁĄD: Plik '{iq_filename}' nie został znaleziony.")
         return 'unreadable', None, None
-    if raw.size < 2:
+    if cap.nbytes < 2:
         return 'unreadable', None, None
-    st = gpsjam.default_device().amp_stats(raw, float(threshold))
+    st = cap.dev.amp_stats(cap, float(threshold))
     if st.first_index < 0:
         return 'below_threshold', None, None
     return 'ok', int(st.first_index), np.float32(st.mean)

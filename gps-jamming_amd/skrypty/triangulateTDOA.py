@@ -71,6 +71,46 @@ def _raw_of(iq_data):
     return iq_data.raw if isinstance(iq_data, IQCapture) else None
 
 
+# Decision margins below which the GPU's decision and the reference's may differ: the kernels sum
+# exact integers / run a radix-16 complex64 FFT, the reference sums float32 |z|^2 (pairwise mean,
+# float64 inside np.convolve) / runs pocketfft.  Either side carries ~1e-7 (onset threshold) and
+# ~1e-6 (correlation peak) of rounding, so inside these margins the reference's own expression is
+# evaluated on the host and decides -- outside them the index is the reference's by construction.
+ONSET_NEAR_TIE = 1e-6
+LAG_NEAR_TIE = 2e-5
+near_tie_events = []     # (what, margin): filled when the host re-evaluation ran (diagnostics / tests)
+
+
+def _onset_reference_expression(raw, noise_samples, window_size, threshold_factor, stop_after=None):
+    """The reference's own arithmetic (:37-49) on the raw bytes, block by block so that a long
+    capture never needs its 8x float expansion at once: float32 |z|^2, float32 mean of the noise
+    span, float64 moving average by np.convolve(..., 'valid'), first index above the threshold.
+    Only used inside ONSET_NEAR_TIE; ``stop_after``: no crossing can lie beyond this index."""
+    n = raw.size // 2
+
+    def power_of(a, b):
+        seg = raw[2 * a:2 * b]
+        z = (seg[0::2].astype(np.float32) - 127.5) + 1j * (seg[1::2].astype(np.float32) - 127.5)
+        return np.abs(z.astype(np.complex64)) ** 2
+
+    noise_power = np.mean(power_of(0, noise_samples))
+    if noise_power == 0:
+        noise_power = 1e-9
+    threshold = noise_power * threshold_factor
+    kernel = np.ones(window_size) / window_size
+    n_out = n - window_size + 1
+    if stop_after is not None:
+        n_out = min(n_out, int(stop_after) + 1)
+    block = 1 << 22
+    for o0 in range(0, n_out, block):
+        o1 = min(o0 + block, n_out)
+        ma = np.convolve(power_of(o0, o1 + window_size - 1), kernel, mode='valid')
+        hit = np.where(ma > threshold)[0]
+        if hit.size:
+            return int(o0 + hit[0] + window_size // 2)
+    return -1
+
+
 def find_interference_start(iq_data, noise_samples, window_size, threshold_factor):
     """Sample index where the moving-average power first exceeds threshold_factor x the
     noise power, + window_size // 2; -1 if none (reference :37-49)."""
@@ -80,7 +120,13 @@ def find_interference_start(iq_data, noise_samples, window_size, threshold_facto
     if len(iq_data) < noise_samples + window_size:
         return -1
     res = gpsjam.default_device().onset(raw, int(noise_samples), int(window_size), float(threshold_factor))
-    return int(res.start_index)
+    if res.margin >= ONSET_NEAR_TIE:
+        return int(res.start_index)
+    # a moving average within rounding of the threshold: let the reference's expression decide.  The
+    # exact crossing bounds the search: nothing later than it (+ one window of slack) can be first.
+    near_tie_events.append(("onset", float(res.margin)))
+    stop = None if res.start_index < 0 else int(res.start_index) + int(window_size)
+    return _onset_reference_expression(raw, int(noise_samples), int(window_size), float(threshold_factor), stop)
 
 
 def correlation_lag(signal1_slice, signal0_slice):
@@ -89,8 +135,16 @@ def correlation_lag(signal1_slice, signal0_slice):
     r1, r0 = _raw_of(signal1_slice), _raw_of(signal0_slice)
     if r1 is None or r0 is None or r1.size != r0.size:
         raise TypeError("correlation_lag expects two equal-length slices of load_iq_data captures")
-    lags, peaks = gpsjam.default_device().xcorr_lags([r0, r1], [(0, 1)])
-    return int(lags[0]), float(peaks[0])
+    lags, peaks, margins = gpsjam.default_device().xcorr_lags([r0, r1], [(0, 1)], want_margins=True)
+    if margins[0] >= LAG_NEAR_TIE:
+        return int(lags[0]), float(peaks[0])
+    # two lags within FFT rounding of each other: the reference's choice depends on ITS rounding,
+    # so its own call (:86-89) decides
+    near_tie_events.append(("lag", float(margins[0])))
+    from scipy import signal
+    corr = signal.correlate(np.asarray(signal1_slice), np.asarray(signal0_slice), mode='full')
+    k = int(np.argmax(np.abs(corr)))
+    return k - (len(signal0_slice) - 1), float(np.abs(corr[k]))
 
 
 def bearing_from_lag(lag_samples, ant0_pos=ANT0_POS, ant1_pos=ANT1_POS, sample_rate=SAMPLE_RATE):

@@ -40,25 +40,11 @@ def analyze_full_file(filename, fft_size=FFT_SIZE, sample_rate=SAMPLE_RATE, chun
     print(f"Czas trwania: {duration_sec:.2f} sekund")
     print("Przetwarzanie... to może chwilę potrwać.")
 
-    dev = gpsjam.default_device()
-    raw = gpsjam.read_capture(filename)
-    rows = dev.welch_rows(raw.size, chunk_size, fft_size)
     # one upload; K2 and the byte histogram both run on the device-resident capture
-    buf = dev.alloc(max(raw.size, 16))
-    d_psd = dev.alloc(4 * max(rows, 1) * fft_size)
-    d_db = dev.alloc(4 * max(rows, 1) * fft_size)
-    d_hist = dev.alloc(8 * 256)
-    try:
-        if raw.size:
-            buf.upload(np.ascontiguousarray(raw))
-        dev.welch_dev(buf, raw.size, chunk_size, fft_size, sample_rate, d_psd, d_db, shift=True)
-        dev.byte_histogram_dev(buf, raw.size, chunk_size, fft_size, 100, d_hist)   # raw_chunk[::100], :35
-        dev.synchronize()
-        psd_db = d_db.download(np.float32, rows * fft_size).reshape(rows, fft_size)
-        histogram = d_hist.download(np.uint64)
-    finally:
-        for b_ in (buf, d_psd, d_db, d_hist):
-            b_.free()
+    cap = gpsjam.resident_capture(filename)
+    dev = cap.dev
+    _, psd_db = dev.welch(cap, chunk_samples=chunk_size, nperseg=fft_size, fs=sample_rate, shift=True, want_db=True)
+    histogram = dev.byte_histogram(cap, chunk_size, fft_size, 100)                   # raw_chunk[::100], :35
     return {
         'spectrogram': psd_db,
         'mean_spectrum': psd_db.mean(axis=0) if psd_db.shape[0] else np.zeros(fft_size, np.float32),

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GJ_VERSION 100 /* 0.1.0 */
+#define GJ_VERSION 110 /* 0.1.1: gj_onset grew to 32 bytes, K5 margins, TDOA slots, gj_comm_*, captures, acquisition */
 
 typedef struct gj_ctx gj_ctx;
 
@@ -69,6 +69,16 @@ int gj_free(gj_ctx* ctx, void* dptr);
 int gj_memcpy_h2d(gj_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int gj_memcpy_d2h(gj_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 
+/* Resident captures: one upload, then any number of *_dev calls on the returned device pointer
+ * (free with gj_free).  The "*_u8" entry points below stage their input on EVERY call; a caller
+ * that runs scan + PSD + RSSI on one file uploads it once with these.  gj_upload_file is the
+ * reference's ingest (np.fromfile / f.read: GpsJammerApp/app/worker.py:209-217,
+ * skrypty/triangulateRSSI.py:29, skrypty/triangulateTDOA.py:33) as file -> pinned bounce buffers
+ * -> HBM; max_bytes = 0 reads to the end of the file. */
+int gj_upload(gj_ctx* ctx, const uint8_t* host, size_t nbytes, void** dptr);
+int gj_upload_file(gj_ctx* ctx, const char* path, size_t offset, size_t max_bytes, void** dptr,
+                   size_t* nbytes_out);
+
 /* HIP-event stopwatch on the context's stream (what bench.py's roofline uses) */
 int gj_timer_start(gj_ctx* ctx);
 int gj_timer_stop(gj_ctx* ctx, float* elapsed_ms); /* synchronises on the stop event */
@@ -101,7 +111,9 @@ int gj_power_threshold_dev(gj_ctx* ctx, const float* d_power, size_t n, float pc
  * per chunk of chunk_samples I/Q pairs: x = ((I-127.5) + j(Q-127.5))/127.5, periodic Hann,
  * 50 % overlap, per-segment mean removal, |FFT|^2 averaged over the segments,
  * scale 1/(fs*sum(w^2)); a trailing partial chunk is kept when it holds at least
- * nperseg samples (widmo_plot.py:31).  nperseg: power of two, 16..4096.
+ * nperseg samples (widmo_plot.py:31).  nperseg: power of two, 16..4096;
+ * chunk_samples >= nperseg and chunk_samples + nperseg < 2^31 (a chunk is addressed with 32-bit
+ * byte offsets; GJ_ERR_UNSUPPORTED otherwise -- the capture itself may be any length).
  * Output rows are float32[nperseg]; GJ_WELCH_SHIFT applies numpy.fft.fftshift (:51);
  * d_psd_db (optional) receives 10*log10(psd + 1e-15) (:52). */
 #define GJ_WELCH_SHIFT 1
@@ -146,6 +158,18 @@ typedef struct gj_onset {
     int64_t start_index; /* -1 = not found */
     float noise_power;
     float threshold;
+    /* Decision margins, relative to the threshold.  The window sums here are exact integers and
+     * the noise mean is rounded once; the reference sums float32 |z|^2 (pairwise for the noise
+     * mean, float64 inside np.convolve), so its threshold and moving averages differ from these in
+     * the last ulps (~1e-7 relative).  When both margins are >= 1e-6 the index is the reference's
+     * index by construction; below that a caller that needs the reference's exact decision
+     * re-evaluates the reference's expression (skrypty/triangulateTDOA.py does, on the host). */
+    float margin_hit;    /* (moving average at the crossing - threshold) / threshold; 0 if not found */
+    float margin_before; /* (threshold - largest moving average in front of the crossing) / threshold;
+                          * positions the screening pass proved quiet enter with their upper bound, so
+                          * this can under-state the true gap, never over-state it.  Not found: over the
+                          * whole capture. */
+    int64_t reserved;
 } gj_onset;
 int gj_onset_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, int noise_samples, int window,
                  float factor, gj_onset* d_out);
@@ -174,13 +198,33 @@ int gj_stream_scan_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes,
  * lags[p] (INT32_MIN if an antenna of the pair is invalid), peaks[p] = max |c|. */
 #define GJ_MAX_ANTENNAS 16
 #define GJ_LAG_INVALID INT32_MIN
+/* margins[p] (optional, may be NULL) = 1 - |c|_runner-up / |c|_peak, the relative gap between the
+ * peak and the largest |c| at any other lag: the arg-max is taken over values that carry the
+ * rounding of a complex64 FFT (~1e-6 of the peak, here as in scipy), so a margin of that order
+ * means the reference's own choice between the two lags is decided by its rounding. */
 int gj_xcorr_lags_dev(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, int n_ant,
                       const int64_t* d_starts, size_t n_samples, const int32_t* pairs,
-                      int n_pairs, int32_t* d_lags, float* d_peaks);
+                      int n_pairs, int32_t* d_lags, float* d_peaks, float* d_margins);
 int gj_xcorr_lags_u8(gj_ctx* ctx, const uint8_t* const* slices, int n_ant, size_t n_samples,
-                     const int32_t* pairs, int n_pairs, int32_t* lags, float* peaks,
+                     const int32_t* pairs, int n_pairs, int32_t* lags, float* peaks, float* margins,
                      float* kernel_ms);
 size_t gj_xcorr_workspace(gj_ctx* ctx, int n_ant, size_t n_samples, int n_pairs);
+
+/* TDOA slot = what one capture contributes to a multi-antenna solve, as ONE message:
+ *   [int64 flag: 0 valid / -1 invalid][int64 start sample][2*n_samples bytes of I/Q], padded to a
+ * multiple of 256 bytes (gj_tdoa_slot_bytes).  gj_tdoa_slot_dev cuts the n_samples I/Q pairs that
+ * start at *d_start (DEVICE scalar, e.g. &gj_onset.start_index) out of a capture; an un-found
+ * onset or a slice that runs off the end marks the slot invalid (the reference aborts there,
+ * skrypty/triangulateTDOA.py:67-77).  gj_xcorr_slots_dev solves pairs over an array of slots
+ * (slot a at d_slots + a*slot_stride), e.g. the receive buffer of gj_comm_gather_dev: every pair
+ * (i, j) of skrypty/triangulateTDOA.py:80-89 generalised to n_ant antennas on one GPU. */
+#define GJ_SLOT_HEADER 16
+size_t gj_tdoa_slot_bytes(size_t n_samples);
+int gj_tdoa_slot_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, const int64_t* d_start,
+                     size_t n_samples, uint8_t* d_slot);
+int gj_xcorr_slots_dev(gj_ctx* ctx, const uint8_t* d_slots, size_t slot_stride, int n_ant,
+                       size_t n_samples, const int32_t* pairs, int n_pairs, int32_t* d_lags,
+                       float* d_peaks, float* d_margins);
 
 /* ------------------------------------------------- per-stream result vector ---------- */
 /* What one rank sends to rank 0 (gpsjam/sharded.py): double[16 + n_chunks + nperseg] =
@@ -193,6 +237,27 @@ int gj_pack_result_dev(gj_ctx* ctx, size_t n_chunks, const float* d_power, const
                        const gj_amp_stats* d_amp, const gj_onset* d_onset, const int32_t* d_lag,
                        const float* d_peak, const float* d_psd, size_t rows, int nperseg, int rank,
                        double* d_out);
+
+/* ------------------------------------------------- collectives (RCCL over xGMI) ------- */
+/* One communicator rank per GPU / process, for hosts without torch.distributed.  The path
+ * shards by capture (file k -> GPU k) and has ONE exchange: TDOA slots and per-stream result
+ * vectors travel to the solving rank (ncclGather, rccl.h:745).  The reference has no
+ * equivalent (one process, numpy).  Rank 0 calls gj_comm_unique_id and ships the 128 bytes to
+ * the other ranks by whatever means the host has (gpsjam/comm.py: one TCP socket on
+ * MASTER_ADDR:MASTER_PORT); every rank then calls gj_comm_init_rank on ITS context.
+ * Collectives are enqueued on the context's current stream (gj_set_stream) and do not
+ * synchronise the host; buffers are device memory.  librccl is bound at run time
+ * (GJ_ERR_UNSUPPORTED when it cannot be loaded). */
+typedef struct gj_comm gj_comm;
+#define GJ_COMM_ID_BYTES 128
+int gj_comm_unique_id(void* id /* [GJ_COMM_ID_BYTES] */);
+int gj_comm_init_rank(gj_ctx* ctx, const void* id, int rank, int n_ranks, gj_comm** out);
+int gj_comm_rank(gj_comm* comm, int* rank, int* n_ranks);
+/* every rank sends `bytes` bytes; root receives n_ranks*bytes in rank order (d_recv may be NULL
+ * elsewhere) */
+int gj_comm_gather_dev(gj_comm* comm, const void* d_send, size_t bytes, void* d_recv, int root);
+int gj_comm_bcast_dev(gj_comm* comm, void* d_buf, size_t bytes, int root);
+int gj_comm_destroy(gj_comm* comm); /* idempotent on NULL; synchronises the context's stream */
 
 /* ------------------------------------------------- synthetic captures --------------- */
 /* Bit-identical to gpsjam/synth.py (integer-only counter-based generator that mirrors

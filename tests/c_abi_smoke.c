@@ -73,6 +73,10 @@ int main(void) {
         fprintf(stderr, "K4 onset %lld not near 260000\n", (long long)on.start_index);
         return 1;
     }
+    if (sizeof(gj_onset) != 32 || !(on.margin_hit > 0.f) || !(on.margin_before > 0.f)) {
+        fprintf(stderr, "K4 margins %g %g (struct %zu bytes)\n", on.margin_hit, on.margin_before, sizeof(gj_onset));
+        return 1;
+    }
 
     /* error path: a too-small output buffer is reported, not overrun */
     if (gj_chunk_power_u8(ctx, iq, nbytes, chunk_bytes, 0.f, 0, power, nchunks - 1, &n_out, &ms) != GJ_ERR_CAPACITY) {

@@ -36,6 +36,9 @@ def test_bad_parameters_are_reported_and_context_survives(dev):
     with pytest.raises(gpsjam.GpsJamError) as e:                     # chunk shorter than one segment
         dev.welch_dev(dev.alloc(raw.size).upload(raw), raw.size, 1000, 4096, 2.048e6, d_psd)
     assert e.value.status == GJ_ERR_UNSUPPORTED
+    with pytest.raises(gpsjam.GpsJamError) as e:                     # one chunk = 2^31 samples: 32-bit chunk offsets
+        dev.welch_dev(dev.alloc(raw.size).upload(raw), raw.size, 1 << 31, 4096, 2.048e6, d_psd)
+    assert e.value.status == GJ_ERR_UNSUPPORTED
     # and the context still works
     pm = dev.chunk_power(raw)
     assert pm.shape == (2,) and np.isfinite(pm).all()

@@ -284,7 +284,7 @@ def test_k5_device_starts_and_invalid(dev, golden_meta, g4_raws):
     g4 = golden_meta["g4"]
     n = 50000
     bufs = [dev.alloc(r.size).upload(r) for r in g4_raws]
-    d_on = [dev.alloc(16) for _ in bufs]
+    d_on = [dev.alloc(32) for _ in bufs]
     d_starts = dev.alloc(8 * 3)
     for b, r, o in zip(bufs, g4_raws, d_on):
         dev.onset_dev(b, r.size, 200000, 1000, 50.0, o)
@@ -382,7 +382,7 @@ def test_stream_scan_equals_separate_kernels(dev, nbytes, chunk, thr):
     nch = dev.chunk_count(nbytes, chunk)
     out = {}
     for mode in ("fused", "separate"):
-        d_pow, d_amp, d_on = dev.alloc(4 * max(nch, 1)), dev.alloc(32), dev.alloc(16)
+        d_pow, d_amp, d_on = dev.alloc(4 * max(nch, 1)), dev.alloc(32), dev.alloc(32)
         if mode == "fused":
             dev.stream_scan_dev(buf, nbytes, chunk, d_pow, thr, d_amp, 200000, 1000, 50.0, d_on)
         else:
@@ -405,3 +405,27 @@ def test_stream_scan_equals_separate_kernels(dev, nbytes, chunk, thr):
         np.testing.assert_allclose(out["fused"][1]["m"], avg, rtol=1e-6)
     z = orc.tdoa_unpack(even)
     assert out["fused"][2] == orc.tdoa_onset(z)
+
+
+@pytest.mark.parametrize("tail_bytes,back", [(40000 + 346, 2500), (13 * 1024 + 712, 6000), (65536 - 1024 + 40, 3100),
+                                             (50 * 1024 + 1000, 7000), (20 * 1024 + 16, 2048)])
+def test_stream_scan_burst_in_partial_last_tile(dev, tail_bytes, back):
+    """Capture whose length is not a multiple of 1 KiB, last 64-KiB tile partly filled (> 12 KiB),
+    burst starting a few thousand samples before the end: the 512-sample screening sums of the last
+    tile must be complete (a wave that splits at the end of the stream used to leave three of them
+    under-counted), so the fused pass must find the same onset as K4 alone and the oracle."""
+    nbytes = 9 * 65536 + tail_bytes
+    ns = nbytes // 2
+    start = ns - back
+    raw = generate(StreamSpec(seed=77 + back, jam_start=start, jam_end=1 << 40, jam_sigma=90.0), ns)[:nbytes]
+    buf = dev.alloc(nbytes).upload(raw)
+    nch = dev.chunk_count(nbytes, 65536)
+    d_pow, d_amp, d_on, d_on2 = dev.alloc(4 * nch), dev.alloc(32), dev.alloc(32), dev.alloc(32)
+    dev.stream_scan_dev(buf, nbytes, 65536, d_pow, 0.0, d_amp, 200000, 1000, 50.0, d_on)
+    dev.onset_dev(buf, nbytes, 200000, 1000, 50.0, d_on2)
+    dev.synchronize()
+    want = orc.tdoa_onset(orc.tdoa_unpack(raw[:2 * ns]))
+    assert want > 0, "the test input must contain a detectable onset"
+    assert int(d_on2.download(np.int64, 1)[0]) == want
+    assert int(d_on.download(np.int64, 1)[0]) == want
+    np.testing.assert_array_equal(d_pow.download(np.float32, nch), exact_chunk_power(raw, 65536))

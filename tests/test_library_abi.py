@@ -25,7 +25,7 @@ def header_symbols():
 def test_library_exists_and_loads():
     assert os.path.exists(_ffi.LIB_PATH), "build with __graft_entry__.build()"
     lib = _ffi.load()
-    assert lib.gj_version() == 100
+    assert lib.gj_version() == _ffi.GJ_VERSION == 110
 
 
 def test_every_declared_symbol_is_exported_and_bound():
@@ -44,7 +44,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_struct_layouts_match_header():
     assert C.sizeof(_ffi.AmpStats) == 32
-    assert C.sizeof(_ffi.Onset) == 16
+    assert C.sizeof(_ffi.Onset) == 32
     assert C.sizeof(_ffi.SynthParams) == 56
 
 

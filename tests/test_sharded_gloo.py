@@ -1,7 +1,8 @@
-"""The N > 1 exchange (reference-slice broadcast + result gather + rank-0 unpacking) with two
-gloo ranks on the CPU.  The per-capture numbers that the GPU kernels would produce are
-supplied by the oracle here (this is a test of the distributed plumbing, which is
-backend-agnostic torch.distributed code shared with bench.py's RCCL run)."""
+"""The N > 1 exchange (TDOA-slot gather + all-pairs solve on rank 0 + result gather + rank-0
+unpacking) with gloo ranks on the CPU.  The per-capture numbers that the GPU kernels would
+produce are supplied by the oracle here (this is a test of the distributed plumbing, which is
+backend-agnostic torch.distributed code shared with bench.py's RCCL run; the same exchange with
+the real kernels on both ranks is tests/test_sharded_two_rank_gpu.py)."""
 import os
 import socket
 import sys
@@ -36,7 +37,7 @@ def _worker(rank, world, port, q):
         from gpsjam.synth import StreamSpec, generate
         from oracle import gpsjam_oracle as orc
 
-        delays = (0, 5)
+        delays = (0, 5, -3)
         n, sl, nperseg = 320000, 32768, 256
         raw = generate(StreamSpec(seed=11, antenna=rank, delay=delays[rank], jam_start=250000,
                                   jam_end=1 << 40, jam_sigma=60.0), n)
@@ -46,30 +47,43 @@ def _worker(rank, world, port, q):
         z = orc.tdoa_unpack(raw)
         onset = orc.tdoa_onset(z)
         lin, _, _ = orc.widmo_waterfall(raw, nperseg=nperseg, chunk_samples=100000)
-        cap16 = torch.from_numpy(raw.copy()).view(torch.int16)
-        ref = torch.zeros(sl, dtype=torch.int16)
+        # TDOA slot of this rank -> one gather to rank 0 -> every pair solved there
+        bad_rank = world - 1 if world == 3 else -1           # its slice is made to run off the end
+        slot = sharded.make_slot(torch.from_numpy(raw.copy()), onset if rank != bad_rank else n - 100, sl)
+        assert slot.numel() == sharded.slot_bytes(sl)
+        slots = sharded.gather_rows(slot, rank, world, 0)
+        pair_lags = {}
         if rank == 0:
-            ref.copy_(cap16[onset:onset + sl])
-        sharded.broadcast_reference_slice(ref, world, 0)
-        ref_raw = ref.view(torch.uint8).numpy()
-        lag, peak = orc.xcorr_lag(z[onset:onset + sl], orc.tdoa_unpack(ref_raw))
+            assert slots.shape == (world, sharded.slot_bytes(sl))
+            fields = [sharded.slot_fields(slots[r], sl) for r in range(world)]
+            for i, j in sharded.all_pairs(world):
+                if fields[i][0] and fields[j][0]:
+                    pair_lags[(i, j)] = int(orc.xcorr_lag(orc.tdoa_unpack(fields[j][2]), orc.tdoa_unpack(fields[i][2]))[0])
+                else:
+                    pair_lags[(i, j)] = sharded.LAG_INVALID
+        else:
+            assert slots is None
+        lag_self = 0 if rank == 0 else sharded.LAG_INVALID      # the other ranks' lags only exist on rank 0
         vec = sharded.pack_results(
             pm.size, nperseg, torch.from_numpy(pm), torch.tensor([base, thr, float((pm > thr).sum())]),
             torch.tensor(k), torch.tensor(n - k), torch.tensor(float(avg)), torch.tensor(onset),
-            torch.tensor(lag), torch.tensor(float(peak)), torch.tensor(1.0),
+            torch.tensor(lag_self), torch.tensor(0.0), torch.tensor(1.0),
             torch.from_numpy(lin.mean(axis=0)), lin.shape[0], rank)
         assert vec.numel() == sharded.result_len(pm.size, nperseg)
-        got = sharded.gather_results(vec, rank, world, 0)
+        rows = sharded.gather_rows(vec, rank, world, 0)
         if rank == 0:
-            res = [sharded.unpack_results(v) for v in got]
-            assert [r.rank for r in res] == [0, 1]
+            pairs = sharded.all_pairs(world)
+            step = sharded.StepResults(rows, pairs, torch.tensor([pair_lags[p] for p in pairs], dtype=torch.int32),
+                                       torch.ones(len(pairs)), torch.ones(len(pairs)), None, world)
+            res, td = step.unpack()
+            assert [r.rank for r in res] == list(range(world))
             np.testing.assert_array_equal(res[0].power_map, pm)
             assert res[0].jamming_byte_ranges() == [(int(a), int(b)) for a, b in ranges]
             assert res[0].lag == 0 and res[0].onset == onset
-            q.put(("ok", [r.lag for r in res], [r.onset for r in res], [r.amp_mean for r in res]))
+            q.put(("ok", td.pairs, td.lags, [r.onset for r in res], [r.lag for r in res], [r.amp_mean for r in res]))
         else:
-            assert got is None
-            q.put(("ok1", lag, onset))
+            assert rows is None
+            q.put(("ok1", rank, onset))
         dist.barrier()
     except Exception as e:                      # surface the failure in the parent
         q.put(("fail", rank, repr(e)))
@@ -78,23 +92,32 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(180)
-def test_two_rank_exchange_gloo():
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    msgs = [q.get(timeout=150) for _ in range(2)]
+    msgs = [q.get(timeout=200) for _ in range(world)]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     assert all(m[0] != "fail" for m in msgs), msgs
-    root = [m for m in msgs if m[0] == "ok"][0]
-    other = [m for m in msgs if m[0] == "ok1"][0]
-    # antenna 1 sees the burst 5 samples late; its own onset detection moves with it, and the
-    # lag of its onset-aligned slice against the reference slice is what rank 0 receives
-    assert root[1][1] == other[1]
-    assert root[2][1] == other[2]
-    assert root[2][1] - root[2][0] + root[1][1] == 5
+    _, pairs, lags, onsets, lag_vs_0, _ = [m for m in msgs if m[0] == "ok"][0]
+    others = {m[1]: m[2] for m in msgs if m[0] == "ok1"}
+    delays = (0, 5, -3)
+    assert pairs == [(i, j) for i in range(world) for j in range(i + 1, world)]
+    for r, o in others.items():
+        assert onsets[r] == o
+    # antenna a sees the burst delays[a] samples late; its own onset detection moves with it, and the
+    # lag of its onset-aligned slice against antenna i's is what rank 0 solves for every pair
+    bad = 2 if world == 3 else -1
+    for (i, j), lag in zip(pairs, lags):
+        if bad in (i, j):
+            assert lag == -(1 << 31)                          # the slice ran off the end: pair invalid
+        else:
+            assert lag + onsets[j] - onsets[i] == delays[j] - delays[i]
+    assert lag_vs_0[0] == 0 and lag_vs_0[1] == lags[pairs.index((0, 1))]

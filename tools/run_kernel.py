@@ -35,7 +35,7 @@ def main():
     nch = dev.chunk_count(nbytes, 65536)
     d_psd = dev.alloc(4 * max(rows, 1) * args.nperseg)
     d_pow, d_stats, d_mask = dev.alloc(4 * nch), dev.alloc(12), dev.alloc(nch)
-    d_amp, d_on = dev.alloc(32), dev.alloc(16)
+    d_amp, d_on = dev.alloc(32), dev.alloc(32)
     d_starts, d_lags, d_peaks = dev.alloc(16), dev.alloc(4), dev.alloc(4)
     d_starts.upload(np.array([int(0.4 * ns), int(0.4 * ns) + 3], np.int64))
     d_starts3, d_lags3, d_peaks3 = dev.alloc(24), dev.alloc(12), dev.alloc(12)
