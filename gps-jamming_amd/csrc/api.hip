@@ -366,15 +366,16 @@ int gj_synth_u8_dev(gj_ctx* ctx, const gj_synth_params* params, int64_t first_sa
 // ---------------------------------------------------------------- host-buffer entry points
 // Stage the capture into HBM (grow-only staging arena), run the same kernels, copy the small
 // results back.  kernel_ms excludes the copies.
-// Large captures go through two pinned 32 MiB bounce buffers (host memcpy of piece k+1 overlaps
-// the DMA of piece k: 29 GB/s against 21 GB/s for a pageable hipMemcpy of 1 GiB on the MI355X
-// box, tools/h2d_bench.hip); small ones take the plain path.
-constexpr size_t kPinBytes = 32u << 20;
+// Large captures go through pinned 16 MiB bounce buffers (the host copy of piece k+1 overlaps
+// the DMA of piece k: 29 GB/s with one fill thread against 21 GB/s for a pageable hipMemcpy of
+// 1 GiB on the MI355X box, tools/h2d_bench.hip); small ones take the plain path.
+constexpr size_t kPinBytes = 16u << 20;
 constexpr size_t kPinThreshold = 64u << 20;
 
 // Host buffer -> ctx->stage.  Large pageable buffers go through pinned bounce buffers: kFillThreads
-// host threads each copy their share of 32-MiB pieces into their own pair of pinned buffers and
-// queue the DMA (one memcpy thread tops out at ~31 GB/s end to end, below what the link carries).
+// host threads (8) each copy their share of 16-MiB pieces into their own pair of pinned buffers and
+// queue the DMA (one memcpy thread tops out at ~31 GB/s end to end, below what the link carries;
+// pread out of the page cache needs the extra threads more than memcpy does).
 constexpr int kFillThreads = gj_ctx::kPinBufs / 2;
 
 // `fill(dst, off, len)` puts bytes [off, off+len) of the source into a pinned buffer: memcpy from a
@@ -461,7 +462,7 @@ int gj_upload(gj_ctx* ctx, const uint8_t* host, size_t nbytes, void** dptr) {
 }
 
 // The reference's ingest (np.fromfile / f.read, worker.py:209-217, triangulateRSSI.py:29) as file ->
-// pinned bounce buffers (pread, four threads) -> HBM.  max_bytes = 0: to the end of the file.
+// pinned bounce buffers (pread, eight threads) -> HBM.  max_bytes = 0: to the end of the file.
 int gj_upload_file(gj_ctx* ctx, const char* path, size_t offset, size_t max_bytes, void** dptr, size_t* nbytes_out) {
     GJ_ENTER(ctx);
     if (!path || !dptr || !nbytes_out) return fail(ctx, GJ_ERR_INVALID, "null argument");

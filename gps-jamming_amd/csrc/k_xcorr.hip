@@ -370,6 +370,8 @@ int launch_xcorr(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, 
 
 // ---- TDOA slot: the onset-aligned slice of one capture + a validity header, as one message ----
 // [int64 flag: 0 = valid, -1 = invalid][int64 start sample in the sender's capture][2 n bytes of I/Q]
+__device__ __forceinline__ size_t align_up_dev(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
 __global__ __launch_bounds__(256) void tdoa_slot_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
                                                         const long long* __restrict__ start, size_t n,
                                                         uint8_t* __restrict__ slot) {
@@ -382,7 +384,9 @@ __global__ __launch_bounds__(256) void tdoa_slot_kernel(const uint8_t* __restric
     }
     const uint16_t* src = reinterpret_cast<const uint16_t*>(iq) + (ok ? s : 0);
     uint4* dst = reinterpret_cast<uint4*>(slot + GJ_SLOT_HEADER);
-    const size_t ngroups = (n + 7) / 8;   // the slot is padded to a multiple of 256 bytes
+    // the slot is padded to a multiple of 256 bytes: the padding is written too (zeros), so that a
+    // slot is a fully defined message
+    const size_t ngroups = (align_up_dev(GJ_SLOT_HEADER + 2 * n, 256) - GJ_SLOT_HEADER) / 16;
     for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < ngroups; g += (size_t)gridDim.x * blockDim.x) {
         unsigned w[4] = {0, 0, 0, 0};
         if (ok) {
@@ -402,7 +406,7 @@ int launch_tdoa_slot(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, const int6
     if (n_samples < 1) return fail(ctx, GJ_ERR_INVALID, "n_samples must be >= 1");
     if ((reinterpret_cast<uintptr_t>(d_iq) & 1) != 0) return fail(ctx, GJ_ERR_INVALID, "capture must be 2-byte aligned");
     if ((reinterpret_cast<uintptr_t>(d_slot) & 15) != 0) return fail(ctx, GJ_ERR_INVALID, "slot must be 16-byte aligned");
-    size_t blocks = ((n_samples + 7) / 8 + 255) / 256;
+    size_t blocks = ((n_samples + 7) / 8 + 16 + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(tdoa_slot_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_iq, nbytes / 2,
                        (const long long*)d_start, n_samples, d_slot);

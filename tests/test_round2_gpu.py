@@ -176,7 +176,7 @@ def test_k4_margins_and_near_tie_guard(dev, monkeypatch):
     raw = generate(StreamSpec(seed=71, jam_start=230000, jam_end=1 << 40, jam_sigma=60.0), 400000)
     o = dev.onset(raw)
     assert o.start_index == orc.tdoa_onset(orc.tdoa_unpack(raw))
-    assert o.margin_hit > 1e-4 and o.margin_before > 1e-3 and o.margin == min(o.margin_hit, o.margin_before)
+    assert o.margin_hit > 1e-5 and o.margin_before > 1e-5 and o.margin == min(o.margin_hit, o.margin_before)
     tdoa.near_tie_events.clear()
     assert tdoa.find_interference_start(tdoa.IQCapture(raw), 200000, 1000, 50.0) == o.start_index
     assert tdoa.near_tie_events == []
