@@ -351,6 +351,20 @@ int gj_pack_result_dev(gj_ctx* ctx, size_t n_chunks, const float* d_power, const
                               d_out);
 }
 
+int gj_acq_search_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t first_sample, int nsamp, int intg,
+                      const int16_t* d_codes, int n_prn, const uint8_t* d_phase, int n_freq, int nsampchip, double ctime,
+                      float threshold, gj_acq_result* d_out, double* d_power) {
+    GJ_ENTER(ctx);
+    if (!d_iq || !d_codes || !d_phase || !d_out) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    return launch_acq_search(ctx, d_iq, nbytes, first_sample, nsamp, intg, d_codes, n_prn, d_phase, n_freq, nsampchip, ctime,
+                             threshold, d_out, d_power);
+}
+
+size_t gj_acq_workspace(gj_ctx*, int nsamp, int n_freq, int n_prn, int intg, int with_power) {
+    if (nsamp <= 0 || n_freq <= 0 || n_prn <= 0 || intg <= 0) return 0;
+    return acq_workspace(nsamp, n_freq, n_prn, intg, with_power == 0);
+}
+
 int gj_synth_u8_dev(gj_ctx* ctx, const gj_synth_params* params, int64_t first_sample, size_t n_samples, uint8_t* d_out) {
     GJ_ENTER(ctx);
     if (!params || (n_samples && !d_out)) return fail(ctx, GJ_ERR_INVALID, "null buffer");

@@ -1,0 +1,289 @@
+// GNSS acquisition search as a batched FFT cross-correlation (gfx950) -- SURVEY section 8(f)-4.
+// Replaces, for all PRNs and Doppler bins at once, the reference receiver's per-channel loop
+//   sdraqcuisition      GpsJammerApp/backend/sdracq.c:3-50    (up to `intg` non-coherent steps, early stop)
+//   pcorrelator         GpsJammerApp/backend/sdrcmn.c:742-773 (per Doppler bin: mixcarr -> cpxcpx -> cpxconv)
+//   mixcarr (SSE2 form) sdrcmn.c:618-705                      (16-entry int8 cos/sin table, phase index per sample)
+//   cpxconv             sdrcmn.c:124-147                      (FFT . conj(code FFT) . IFFT -> |.|^2 / m^2, summed)
+//   checkacquisition    sdracq.c:52-84                        (peak, +-2 chip exclusion, peak ratio > 3)
+// on the block FFT of fft_core.h (the machinery of K2 / K5):
+//   acq_code_kernel : C_p   = FFT(resampled code of PRN p, zero-padded to nfft)            once per search
+//   acq_fwd_kernel  : X_s,f = FFT(mix(data window s, Doppler bin f) * CSCALE/m)            n_freq x intg transforms
+//   acq_inv_kernel  : P_p,f += |IFFT(-X_s,f conj(C_p))|^2 / m^2 over the first nsamp lags   n_freq x n_prn per step
+//   acq_check_kernel: per PRN the reference's peak test; a PRN that passes stops integrating (device flag)
+// The data FFT does not depend on the PRN, so it is computed once per (step, bin) and reused by all PRNs
+// (the reference recomputes it in every channel thread).  The mixer's phase index per sample comes as a table
+// built on the host exactly like the reference builds it (doubles accumulated in its order, truncation toward
+// zero): the integer mixer is bit-exact, everything behind the first FFT is float32 like FFTW's.
+#include "gj_common.h"
+
+namespace gj {
+
+struct AcqParams {
+    const uint8_t* iq;
+    unsigned long long first_sample;
+    int nsamp, nfft, n_freq, n_prn, intg, offset;
+    float scale;   // CSCALE / m
+    float inv_m2;  // 1 / m^2
+};
+
+template <int N, int PASS>
+__device__ __forceinline__ void acq_passes(c2 (&v)[16], cf* lds, int base, int jl, const cf* twtab) {
+    constexpr int NP = fft_npass(N);
+    c2 tw[15];
+    if constexpr (PASS > 0) load_twiddles<N, PASS>(tw, twtab, jl);
+    fft_pass<N, PASS, false, true>(v, tw, inner_twiddles());
+    if constexpr (PASS + 1 < NP) {
+        lds_scatter<N, PASS>(v, lds, base, jl);
+        __syncthreads();
+        lds_gather<N>(v, lds, base, jl);
+        __syncthreads();
+        acq_passes<N, PASS + 1>(v, lds, base, jl, twtab);
+    }
+}
+
+// 16-entry mixer tables of the reference's SSE2 path: (char)floor(cos(2 pi i / 16) / CSCALE + 0.5), CSCALE = 1/32
+__constant__ signed char kAcqCos[16] = {32, 30, 23, 12, 0, -12, -23, -30, -32, -30, -23, -12, 0, 12, 23, 30};
+__constant__ signed char kAcqSin[16] = {0, 12, 23, 30, 32, 30, 23, 12, 0, -12, -23, -30, -32, -30, -23, -12};
+
+// one transform per workgroup (N = 4096) or 4096 / N of them (smaller N): `which` = transform index
+template <int N>
+__global__ __launch_bounds__(kBlockThreads) void acq_code_kernel(const short* __restrict__ codes, int nsamp, int n_prn,
+                                                                 const cf* __restrict__ twtab, cf* __restrict__ cspec) {
+    constexpr int TF = N / 16, B = kBlockPoints / N;
+    __shared__ cf lds[B * lds_span(N)];
+    const int tid = threadIdx.x, b = tid / TF, jl = tid % TF;
+    const int p = blockIdx.x * B + b;
+    const bool live = p < n_prn;
+    c2 v[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int n = jl + TF * s;
+        v[s] = make_c2((live && n < nsamp) ? (float)codes[(size_t)p * nsamp + n] : 0.f, 0.f);   // cpxcpx(rcode, NULL, 1.0)
+    }
+    acq_passes<N, 0>(v, lds, b * lds_span(N), jl, twtab);
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) cspec[(size_t)p * N + jl + TF * s] = to_cf(v[s]);
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(kBlockThreads) void acq_fwd_kernel(AcqParams P, const uint8_t* __restrict__ phase,
+                                                                const cf* __restrict__ twtab, cf* __restrict__ xspec) {
+    constexpr int TF = N / 16, B = kBlockPoints / N;
+    __shared__ cf lds[B * lds_span(N)];
+    const int tid = threadIdx.x, b = tid / TF, jl = tid % TF;
+    const int t = blockIdx.x * B + b;          // transform = step * n_freq + bin
+    const bool live = t < P.intg * P.n_freq;
+    const int s_idx = live ? t / P.n_freq : 0, f = live ? t % P.n_freq : 0;
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(P.iq) + P.first_sample + (size_t)s_idx * P.nsamp;
+    const uint8_t* ph = phase + (size_t)f * N;
+    c2 v[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int n = jl + TF * s;
+        const unsigned w = src[n];
+        const int di = (int)(w & 255u) - P.offset, dq = (int)(w >> 8) - P.offset;   // (char)(u - 128), sdrrcv.c:104-106
+        const int k = ph[n] & 15;
+        const int co = kAcqCos[k], si = kAcqSin[k];
+        const int ii = co * di - si * dq, qq = si * di + co * dq;                    // int16 in the reference: |.| <= 8192
+        v[s] = make_c2((float)ii * P.scale, (float)qq * P.scale);                    // cpxcpx(dataI, dataQ, CSCALE / m)
+    }
+    acq_passes<N, 0>(v, lds, b * lds_span(N), jl, twtab);
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) xspec[(size_t)t * N + jl + TF * s] = to_cf(v[s]);
+    }
+}
+
+// grid.x = ceil(n_freq / B), grid.y = PRN.  |IFFT(Y)|^2 = |FFT(conj Y)|^2, Y = -X conj(C)  (cpxconv's product).
+template <int N>
+__global__ __launch_bounds__(kBlockThreads) void acq_inv_kernel(AcqParams P, int step, const int* __restrict__ done,
+                                                                const cf* __restrict__ twtab,
+                                                                const cf* __restrict__ xspec,
+                                                                const cf* __restrict__ cspec, double* __restrict__ power) {
+    constexpr int TF = N / 16, B = kBlockPoints / N;
+    __shared__ cf lds[B * lds_span(N)];
+    const int p = blockIdx.y;
+    if (done[p]) return;                       // this PRN has been acquired at an earlier step (sdracq.c:24-27)
+    const int tid = threadIdx.x, b = tid / TF, jl = tid % TF;
+    const int f = blockIdx.x * B + b;
+    const bool live = f < P.n_freq;
+    const cf* x = xspec + ((size_t)step * P.n_freq + (live ? f : 0)) * N;
+    const cf* c = cspec + (size_t)p * N;
+    c2 v[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const cf a = x[jl + TF * s], q = c[jl + TF * s];
+        // sdrcmn.c:131-135: real = -p0 q0 - p1 q1, imag = p0 q1 - p1 q0; conjugated for the forward-FFT inverse
+        v[s] = make_c2(-a.x * q.x - a.y * q.y, -(a.x * q.y - a.y * q.x));
+    }
+    acq_passes<N, 0>(v, lds, b * lds_span(N), jl, twtab);
+    if (live) {
+        double* dst = power + ((size_t)p * P.n_freq + f) * P.nsamp;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int k = jl + TF * s;
+            if (k < P.nsamp) dst[k] += (double)((v[s].x * v[s].x + v[s].y * v[s].y) * P.inv_m2);   // flagsum = 1 (:141-143)
+        }
+    }
+}
+
+struct AcqBest {
+    double val;
+    int idx;
+};
+__device__ __forceinline__ AcqBest acq_better(AcqBest a, AcqBest b) {   // larger value, first index on a tie (maxvd)
+    return (b.val > a.val || (b.val == a.val && b.idx < a.idx)) ? b : a;
+}
+__device__ AcqBest acq_block_best(AcqBest v, AcqBest* sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        AcqBest o;
+        o.val = __shfl_xor(v.val, off, 64);
+        o.idx = __shfl_xor(v.idx, off, 64);
+        v = acq_better(v, o);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    AcqBest r = sh[0];
+    for (unsigned k = 1; k < blockDim.x / 64; ++k) r = acq_better(r, sh[k]);
+    return r;
+}
+
+// checkacquisition (sdracq.c:52-84) for one PRN per workgroup, with maxvd / meanvd / ind2sub as written
+// (sdrcmn.c:411-440,512-515): strict '>' keeps the FIRST maximum; index 0 of a row seeds maxvd even when it lies in
+// the exclusion zone; a wrapped exclusion zone (exinds > exinde) keeps only the indices strictly between.
+__global__ __launch_bounds__(1024) void acq_check_kernel(AcqParams P, int step, int nsampchip, double ctime, float threshold,
+                                                         const double* __restrict__ power, int* __restrict__ done,
+                                                         gj_acq_result* __restrict__ out) {
+    __shared__ AcqBest sh[16];
+    __shared__ double shs[16];
+    __shared__ int shn[16];
+    const int p = blockIdx.x;
+    if (done[p]) return;
+    const double* pw = power + (size_t)p * P.n_freq * P.nsamp;
+    const int total = P.n_freq * P.nsamp;
+    AcqBest b{-1.0, 0x7fffffff};
+    for (int i = threadIdx.x; i < total; i += blockDim.x) b = acq_better(b, AcqBest{pw[i], i});
+    b = acq_block_best(b, sh);
+    const int codei = b.idx % P.nsamp, freqi = b.idx / P.nsamp;
+    int exinds = codei - 2 * nsampchip, exinde = codei + 2 * nsampchip;
+    if (exinds < 0) exinds += P.nsamp;
+    if (exinde >= P.nsamp) exinde -= P.nsamp;
+    const double* row = pw + (size_t)freqi * P.nsamp;
+    auto kept = [&](int i) {
+        return (exinds <= exinde) ? (i < exinds || i > exinde) : (i < exinds && i > exinde);
+    };
+    AcqBest b2{row[0], 0};                       // maxvd: max = data[0] whatever the exclusion zone says
+    double sum = 0.0;
+    int cnt = 0;
+    for (int i = threadIdx.x; i < P.nsamp; i += blockDim.x) {
+        if (kept(i)) {
+            if (i >= 1) b2 = acq_better(b2, AcqBest{row[i], i});
+            sum += row[i];
+            ++cnt;
+        }
+    }
+    b2 = acq_block_best(b2, sh);
+    sum = wave_sum_f64(sum);
+    cnt = (int)wave_sum_u32((unsigned)cnt);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { shs[threadIdx.x >> 6] = sum; shn[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        int n = 0;
+        for (unsigned k = 0; k < blockDim.x / 64; ++k) { tot += shs[k]; n += shn[k]; }
+        const double meanP = tot / (double)n;
+        gj_acq_result r;
+        r.max_power = b.val;
+        r.second_power = b2.val;
+        r.mean_power = meanP;
+        r.peak_ratio = b.val / b2.val;
+        r.cn0 = 10.0 * log10(b.val / meanP / ctime);
+        r.code_index = codei;
+        r.freq_index = freqi;
+        r.steps = step + 1;
+        r.acquired = r.peak_ratio > (double)threshold ? 1 : 0;
+        out[p] = r;
+        if (r.acquired) done[p] = 1;
+    }
+}
+
+size_t acq_workspace(int nsamp, int n_freq, int n_prn, int intg, bool own_power) {
+    const size_t nfft = 2 * (size_t)nsamp;
+    size_t b = 256;                                                        // done flags
+    b += align_up((size_t)n_prn * sizeof(int), 256);
+    b += align_up((size_t)n_prn * nfft * sizeof(cf), 256);                 // code spectra
+    b += align_up((size_t)intg * n_freq * nfft * sizeof(cf), 256);         // data spectra
+    if (own_power) b += align_up((size_t)n_prn * n_freq * nsamp * sizeof(double), 256);
+    return b;
+}
+
+template <int N>
+static int acq_run(gj_ctx* ctx, const AcqParams& P, const short* d_codes, const uint8_t* d_phase, int nsampchip,
+                   double ctime, float threshold, gj_acq_result* d_out, double* d_power) {
+    constexpr int B = kBlockPoints / N;
+    unsigned char* w = ctx->ws;
+    int* done = reinterpret_cast<int*>(w);
+    w += 256 + align_up((size_t)P.n_prn * sizeof(int), 256);
+    cf* cspec = reinterpret_cast<cf*>(w);
+    w += align_up((size_t)P.n_prn * N * sizeof(cf), 256);
+    cf* xspec = reinterpret_cast<cf*>(w);
+    w += align_up((size_t)P.intg * P.n_freq * N * sizeof(cf), 256);
+    double* power = d_power ? d_power : reinterpret_cast<double*>(w);
+    GJ_HIP(ctx, hipMemsetAsync(done, 0, (size_t)P.n_prn * sizeof(int), ctx->stream));
+    GJ_HIP(ctx, hipMemsetAsync(power, 0, (size_t)P.n_prn * P.n_freq * P.nsamp * sizeof(double), ctx->stream));   // calloc, sdrmain.c:346
+    GJ_HIP(ctx, hipMemsetAsync(d_out, 0, (size_t)P.n_prn * sizeof(gj_acq_result), ctx->stream));
+    hipLaunchKernelGGL((acq_code_kernel<N>), dim3((unsigned)((P.n_prn + B - 1) / B)), dim3(kBlockThreads), 0, ctx->stream,
+                       d_codes, P.nsamp, P.n_prn, ctx->d_twiddle, cspec);
+    GJ_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL((acq_fwd_kernel<N>), dim3((unsigned)((P.intg * P.n_freq + B - 1) / B)), dim3(kBlockThreads), 0,
+                       ctx->stream, P, d_phase, ctx->d_twiddle, xspec);
+    GJ_LAUNCH_CHECK(ctx);
+    for (int step = 0; step < P.intg; ++step) {
+        hipLaunchKernelGGL((acq_inv_kernel<N>), dim3((unsigned)((P.n_freq + B - 1) / B), (unsigned)P.n_prn),
+                           dim3(kBlockThreads), 0, ctx->stream, P, step, done, ctx->d_twiddle, xspec, cspec, power);
+        GJ_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(acq_check_kernel, dim3((unsigned)P.n_prn), dim3(1024), 0, ctx->stream, P, step, nsampchip,
+                           ctime, threshold, power, done, d_out);
+        GJ_LAUNCH_CHECK(ctx);
+    }
+    return GJ_OK;
+}
+
+int launch_acq_search(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t first_sample, int nsamp, int intg,
+                      const int16_t* d_codes, int n_prn, const uint8_t* d_phase, int n_freq, int nsampchip, double ctime,
+                      float threshold, gj_acq_result* d_out, double* d_power) {
+    if (nsamp != 2048 && nsamp != 1024 && nsamp != 512) return fail(ctx, GJ_ERR_UNSUPPORTED, "nsamp must be 512, 1024 or 2048");
+    if (intg < 1 || intg > 64 || n_prn < 1 || n_prn > 4096 || n_freq < 1 || n_freq > 4096)
+        return fail(ctx, GJ_ERR_INVALID, "intg 1..64, n_prn and n_freq 1..4096");
+    if (nsampchip < 0 || 4 * nsampchip >= nsamp || !(ctime > 0.0)) return fail(ctx, GJ_ERR_INVALID, "bad nsampchip / ctime");
+    if ((reinterpret_cast<uintptr_t>(d_iq) & 1) != 0) return fail(ctx, GJ_ERR_INVALID, "capture must be 2-byte aligned");
+    // step s reads samples [first + s nsamp, first + s nsamp + 2 nsamp)  (rcvgetbuff of 2*nsamp, then += nsamp)
+    const size_t need = first_sample + (size_t)(intg + 1) * nsamp;
+    if (need > nbytes / 2) return fail(ctx, GJ_ERR_INVALID, "search needs samples up to %zu, capture has %zu", need, nbytes / 2);
+    int rc = ensure_workspace(ctx, acq_workspace(nsamp, n_freq, n_prn, intg, d_power == nullptr));
+    if (rc) return rc;
+    AcqParams P;
+    P.iq = d_iq;
+    P.first_sample = first_sample;
+    P.nsamp = nsamp;
+    P.nfft = 2 * nsamp;
+    P.n_freq = n_freq;
+    P.n_prn = n_prn;
+    P.intg = intg;
+    P.offset = 128;
+    P.scale = (float)((1.0 / 32.0) / (double)P.nfft);   // CSCALE / m (sdrcmn.c:7,766)
+    P.inv_m2 = 1.0f / ((float)P.nfft * (float)P.nfft);
+    const short* codes = reinterpret_cast<const short*>(d_codes);
+    switch (P.nfft) {
+        case 4096: return acq_run<4096>(ctx, P, codes, d_phase, nsampchip, ctime, threshold, d_out, d_power);
+        case 2048: return acq_run<2048>(ctx, P, codes, d_phase, nsampchip, ctime, threshold, d_out, d_power);
+        default: return acq_run<1024>(ctx, P, codes, d_phase, nsampchip, ctime, threshold, d_out, d_power);
+    }
+}
+
+}   // namespace gj

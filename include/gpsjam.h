@@ -238,6 +238,39 @@ int gj_pack_result_dev(gj_ctx* ctx, size_t n_chunks, const float* d_power, const
                        const float* d_peak, const float* d_psd, size_t rows, int nperseg, int rank,
                        double* d_out);
 
+/* ------------------------------------------------- GNSS acquisition search ----------- */
+/* the reference receiver's parallel code-phase search, batched over every
+ * PRN and Doppler bin.  Replaces, per call, what each of its channel threads does on its own:
+ *   sdraqcuisition    GpsJammerApp/backend/sdracq.c:3-50    loop over `intg` steps, early stop
+ *   pcorrelator       GpsJammerApp/backend/sdrcmn.c:742-773 per bin: mixcarr -> cpxcpx -> cpxconv
+ *   mixcarr           sdrcmn.c:618-705 (the SSE2 form the reference's makefile builds)
+ *   cpxconv           sdrcmn.c:124-147 FFT . conj(code FFT) . IFFT -> |.|^2 / m^2, accumulated
+ *   checkacquisition  sdracq.c:52-84   peak, +-2 chip exclusion zone, peak ratio > threshold
+ * Inputs (device memory): the capture as int8 = u8 - 128 (sdrrcv.c:104-106); step s of the search
+ * reads the 2*nsamp samples from first_sample + s*nsamp; d_codes[p][nsamp] = the code of PRN p
+ * resampled to the sampling rate (+-1, int16: rescode, sdrinit.c:439); d_phase[f][2*nsamp] = the
+ * mixer's 4-bit phase index per sample for Doppler bin f, built on the host the way mixcarr
+ * builds it (gpsjam/gnss.py).  nsamp: 512, 1024 or 2048 (FFT length 2*nsamp, sdrinit.c:402).
+ * A PRN stops integrating at the first step whose peak ratio passes (results of that step are
+ * kept); the others run all `intg` steps.  d_power (optional) receives the accumulated
+ * correlation power double[n_prn][n_freq][nsamp] (the reference's `power` array). */
+typedef struct gj_acq_result {
+    double max_power;    /* maxP */
+    double second_power; /* maxP2: largest power of the peak's Doppler row outside the exclusion zone */
+    double mean_power;   /* meanP of that row outside the exclusion zone */
+    double peak_ratio;   /* maxP / maxP2 (acq.peakr) */
+    double cn0;          /* 10 log10(maxP / meanP / ctime) */
+    int32_t code_index;  /* acq.acqcodei */
+    int32_t freq_index;  /* acq.freqi */
+    int32_t steps;       /* integration steps used, 1..intg */
+    int32_t acquired;    /* peak_ratio > threshold */
+} gj_acq_result;
+int gj_acq_search_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t first_sample, int nsamp,
+                      int intg, const int16_t* d_codes, int n_prn, const uint8_t* d_phase, int n_freq,
+                      int nsampchip, double ctime, float threshold, gj_acq_result* d_out /* [n_prn] */,
+                      double* d_power /* [n_prn*n_freq*nsamp] or NULL */);
+size_t gj_acq_workspace(gj_ctx* ctx, int nsamp, int n_freq, int n_prn, int intg, int with_power);
+
 /* ------------------------------------------------- collectives (RCCL over xGMI) ------- */
 /* One communicator rank per GPU / process, for hosts without torch.distributed.  The path
  * shards by capture (file k -> GPU k) and has ONE exchange: TDOA slots and per-stream result

@@ -408,3 +408,170 @@ def tdoa_bearing(lag: int, ant0, ant1, fs: float = 2048000):
                 theta_deg=math.degrees(theta),
                 azimuth1_deg=math.degrees(base_ang + theta) % 360,
                 azimuth2_deg=math.degrees(base_ang - theta) % 360)
+
+
+# ----------------------------------------------------------------------------------
+# (6) GNSS acquisition search      GpsJammerApp/backend/sdracq.c, sdrcmn.c
+# ----------------------------------------------------------------------------------
+# PARITY UNPINNED for everything behind the first FFT: the reference's acquisition lives in
+# gnssdec (C + FFTW3f), which cannot be built here (fftw3.h / fec.h / libusb.h are absent)
+# and whose shipped binary is never run, and the reference holds no test vector for it.  What IS
+# pinned: the C/A codes, against the published first-ten-chips table of IS-GPS-200 (Table 3-Ia) in
+# tests/test_acq_host.py.  The functions below restate the C line by line in numpy (float32 where the
+# C uses float, the FFT by scipy.fft / pocketfft in complex64 where the C calls FFTW).
+ACQ_CSCALE = 1.0 / 32.0              # sdrcmn.c:7
+ACQ_TH = 3.0                         # sdr.h:66
+ACQ_G2_DELAY = (5, 6, 7, 8, 17, 18, 139, 140, 141, 251, 252, 254, 255, 256, 257, 258, 469, 470, 471,
+                472, 473, 474, 509, 512, 513, 514, 515, 516, 859, 860, 861, 862)   # sdrcode.c:104-106 (PRN 1..32)
+
+
+def acq_gencode_l1ca(prn: int) -> np.ndarray:
+    """gencode_L1CA (sdrcode.c:102-149): registers of -1, products for XOR."""
+    R1 = [-1] * 10
+    R2 = [-1] * 10
+    G1 = np.empty(1023, np.int16)
+    G2 = np.empty(1023, np.int16)
+    for i in range(1023):
+        G1[i] = R1[9]
+        G2[i] = R2[9]
+        C1 = R1[2] * R1[9]
+        C2 = R2[1] * R2[2] * R2[5] * R2[7] * R2[8] * R2[9]
+        for j in range(9, 0, -1):
+            R1[j] = R1[j - 1]
+            R2[j] = R2[j - 1]
+        R1[0] = C1
+        R2[0] = C2
+    code = np.empty(1023, np.int16)
+    j = 1023 - ACQ_G2_DELAY[prn - 1]
+    for i in range(1023):
+        code[i] = -G1[i] * G2[j % 1023]
+        j += 1
+    return code
+
+
+def acq_rescode(code: np.ndarray, ci: float, n: int) -> np.ndarray:
+    """rescode(code, len, 0, 0, ci, n, rcode), SSE2 form (sdrcmn.c:541-575), one sample at a time."""
+    ln = len(code)
+    i, nbit = ln, 31
+    while i:
+        i >>= 1
+        nbit -= 1
+    nbit -= 1
+    scale = 1 << nbit
+    coff = 0.0
+    x = []
+    for _ in range(4):
+        x.append(int(coff * scale + 0.5))
+        coff += ci
+    step = int(ci * 4 * scale + 0.5)
+    out = np.empty(n, np.int16)
+    for g in range(0, n, 4):
+        for k in range(4):
+            if x[k] > ln * scale - 1:
+                x[k] -= ln * scale
+            if g + k < n:
+                out[g + k] = code[x[k] >> nbit]
+            x[k] += step
+    return out
+
+
+def acq_mixcarr_sse2(data_i8: np.ndarray, ti: float, n: int, freq: float):
+    """mixcarr(data, DTYPEIQ, ti, n, freq, 0.0, II, QQ), SSE2 form (sdrcmn.c:618-684): 16-entry int8 table,
+    sixteen double phases advanced by 16 ps per block, cvttpd + mask."""
+    cost = np.array([math.floor(math.cos(2 * math.pi / 16 * i) / ACQ_CSCALE + 0.5) for i in range(16)], np.int32)
+    sint = np.array([math.floor(math.sin(2 * math.pi / 16 * i) / ACQ_CSCALE + 0.5) for i in range(16)], np.int32)
+    ps = freq * 16 * ti
+    phi = 0.0
+    regs = []
+    for _ in range(8):                                   # xmm1..xmm8 = (phi, phi + ps); phi += ps * 2
+        regs += [phi, phi + ps]
+        phi += ps * 2
+    regs = np.array(regs, np.float64)
+    inc = ps * 16
+    d = data_i8.astype(np.int32)
+    II = np.empty(n, np.int16)
+    QQ = np.empty(n, np.int16)
+    for b in range(0, n, 16):
+        idx = np.trunc(regs).astype(np.int64) & 15
+        di, dq = d[2 * b:2 * b + 32:2], d[2 * b + 1:2 * b + 32:2]
+        II[b:b + 16] = cost[idx] * di - sint[idx] * dq
+        QQ[b:b + 16] = sint[idx] * di + cost[idx] * dq
+        regs = regs + inc
+    return II, QQ
+
+
+def acq_code_fft(prn: int, nsamp: int, fs: float = SAMPLE_RATE) -> np.ndarray:
+    """xcode of a channel (sdrinit.c:436-441): resampled code, zero-padded to nfft, forward FFT."""
+    ci = (1.0 / fs) * 1.023e6
+    rcode = np.zeros(2 * nsamp, np.int16)
+    rcode[:nsamp] = acq_rescode(acq_gencode_l1ca(prn), ci, nsamp)
+    return _sfft.fft(rcode.astype(np.float32).astype(np.complex64))
+
+
+def acq_pcorrelator(data_i8: np.ndarray, ti: float, n: int, freqs, m: int, codex: np.ndarray, P: np.ndarray):
+    """pcorrelator (sdrcmn.c:742-773) + cpxconv (:124-147): P[i*n + k] += |IFFT(-FFT(x_i) conj-product)|^2 / m^2."""
+    m2 = np.float32(m) * np.float32(m)
+    for i, freq in enumerate(freqs):
+        II, QQ = acq_mixcarr_sse2(data_i8, ti, m, float(freq))
+        sc = np.float32(ACQ_CSCALE / m)
+        x = (II.astype(np.float32) * sc + 1j * (QQ.astype(np.float32) * sc)).astype(np.complex64)   # cpxcpx
+        X = _sfft.fft(x)
+        p0, p1, q0, q1 = X.real, X.imag, codex.real, codex.imag
+        Y = ((-p0 * q0 - p1 * q1) + 1j * (p0 * q1 - p1 * q0)).astype(np.complex64)
+        y = _sfft.ifft(Y) * np.float32(m)                    # FFTW's backward transform is unnormalised
+        y = y.astype(np.complex64)
+        term = (y.real[:n] * y.real[:n] + y.imag[:n] * y.imag[:n]) / m2
+        P[i * n:(i + 1) * n] += term.astype(np.float64)
+
+
+def _acq_kept(i, exinds, exinde):
+    return (i < exinds or i > exinde) if exinds <= exinde else (i < exinds and i > exinde)
+
+
+def acq_check(P: np.ndarray, nsamp: int, nfreq: int, nsampchip: int, ctime: float, th: float = ACQ_TH):
+    """checkacquisition (sdracq.c:52-84) with maxvd / meanvd / ind2sub as written (sdrcmn.c:411-440,512-515)."""
+    maxi = int(np.argmax(P))                              # maxvd without exclusion: first maximum
+    maxP = float(P[maxi])
+    codei, freqi = maxi % nsamp, (nfreq * maxi) // (nsamp * nfreq)
+    exinds = codei - 2 * nsampchip
+    if exinds < 0:
+        exinds += nsamp
+    exinde = codei + 2 * nsampchip
+    if exinde >= nsamp:
+        exinde -= nsamp
+    row = P[freqi * nsamp:(freqi + 1) * nsamp]
+    keep = np.array([_acq_kept(i, exinds, exinde) for i in range(nsamp)])
+    meanP = float(row[keep].sum() / keep.sum())
+    mx = float(row[0])                                    # maxvd seeds with data[0] whatever the exclusion zone
+    for i in range(1, nsamp):
+        if keep[i] and mx < row[i]:
+            mx = float(row[i])
+    return {"maxP": maxP, "maxP2": mx, "meanP": meanP, "peakr": maxP / mx,
+            "cn0": 10 * math.log10(maxP / meanP / ctime), "codei": codei, "freqi": freqi,
+            "acquired": (maxP / mx) > th}
+
+
+def acq_search(raw, first_sample: int, prn: int, fs: float = SAMPLE_RATE, f_if: float = 0.0, intg: int = 10,
+               hband: int = 7000, step: int = 200):
+    """sdraqcuisition for one channel (sdracq.c:3-50) on the uint8 capture: int8 = u8 - 128 (sdrrcv.c:104-106),
+    up to ``intg`` steps of 2*nsamp samples advancing by nsamp, stop at the first step that acquires.
+    Returns (check dict + 'steps', P[nfreq*nsamp])."""
+    raw = _as_u8(raw)
+    ctime = 1023 / 1.023e6
+    nsamp = int(fs * ctime)
+    nsampchip = int(nsamp / 1023)
+    nfreq = 2 * (hband // step) + 1
+    freqs = [f_if + (i - (nfreq - 1) // 2) * step for i in range(nfreq)]
+    codex = acq_code_fft(prn, nsamp, fs)
+    P = np.zeros(nfreq * nsamp, np.float64)               # calloc (sdrmain.c:346)
+    res = None
+    for i in range(intg):
+        loc = first_sample + i * nsamp
+        win = raw[2 * loc:2 * (loc + 2 * nsamp)]
+        data = (win.astype(np.int16) - 128).astype(np.int8)
+        acq_pcorrelator(data, 1.0 / fs, nsamp, freqs, 2 * nsamp, codex, P)
+        res = acq_check(P, nsamp, nfreq, nsampchip, ctime)
+        res["steps"] = i + 1
+        if res["acquired"]:
+            break
+    return res, P
