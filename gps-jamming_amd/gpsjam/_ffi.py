@@ -99,6 +99,8 @@ SIGNATURES = {
     "gj_tdoa_slot_bytes": (_sz, [_sz]),
     "gj_tdoa_slot_dev": (_i, [_vp, _vp, _sz, _vp, _sz, _vp]),
     "gj_xcorr_slots_dev": (_i, [_vp, _vp, _sz, _i, _sz, C.POINTER(C.c_int32), _i, _vp, _vp, _vp]),
+    "gj_acq_search_dev": (_i, [_vp, _vp, _sz, _sz, _i, _i, _vp, _i, _vp, _i, _i, _d, _f, _vp, _vp]),
+    "gj_acq_workspace": (_sz, [_vp, _i, _i, _i, _i, _i]),
     "gj_comm_unique_id": (_i, [_vp]),
     "gj_comm_init_rank": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
     "gj_comm_rank": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
