@@ -67,6 +67,12 @@ __device__ __forceinline__ float power_from_moments(unsigned long long s2, unsig
     return mean + eps;
 }
 
+// the same from S = sum over the pairs of (2I-255)^2 + (2Q-255)^2 (what the fused scan accumulates)
+__device__ __forceinline__ float power_from_msum(unsigned long long S, size_t npairs, float eps) {
+    const float mean = (float)((double)S / (4.0 * (double)npairs));
+    return mean + eps;
+}
+
 __global__ __launch_bounds__(kScanThreads) void chunk_power_kernel(const uint8_t* __restrict__ iq, size_t nbytes,
                                                                    size_t chunk_bytes, unsigned tiles_per_chunk,
                                                                    float eps, int flags, float* __restrict__ power,
@@ -101,8 +107,10 @@ __global__ __launch_bounds__(kScanThreads) void chunk_power_kernel(const uint8_t
     }
 }
 
+// msum: acc[2c] holds the sum of (2u-255)^2 itself (fused scan) instead of the byte moments
 __global__ void chunk_power_finalize_kernel(const unsigned long long* __restrict__ acc, size_t nchunks, size_t nbytes,
-                                            size_t chunk_bytes, float eps, int flags, float* __restrict__ power) {
+                                            size_t chunk_bytes, float eps, int flags, float* __restrict__ power,
+                                            bool msum = false) {
     const size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
     const size_t off = c * chunk_bytes;
@@ -110,7 +118,7 @@ __global__ void chunk_power_finalize_kernel(const unsigned long long* __restrict
     const size_t npairs = len >> 1;
     if ((flags & GJ_CP_ODD_CHUNK_ZERO) && ((len & 1) || len == 0)) return;   // already written
     if (npairs == 0) return;
-    power[c] = power_from_moments(acc[2 * c], acc[2 * c + 1], npairs, eps);
+    power[c] = msum ? power_from_msum(acc[2 * c], npairs, eps) : power_from_moments(acc[2 * c], acc[2 * c + 1], npairs, eps);
 }
 
 int launch_chunk_power(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
@@ -493,8 +501,8 @@ constexpr int kOnsetLds = kOnsetOut + kOnsetMaxWin;   // u32 words (64 KiB)
 struct OnsetScratch {
     unsigned long long first_inv;   // ~(min index whose moving average is above the threshold)
     unsigned long long cand_inv;    // ~(first sample of the first block that fails the screening proof)
-    unsigned long long noise_m2;    // sum u^2 / sum u over the bytes of the first noise_samples samples
-    unsigned long long noise_m1;
+    unsigned long long noise_S;     // sum of (2I-255)^2 + (2Q-255)^2 = 4 |z|^2 over the first noise_samples samples
+    unsigned long long reserved;
     float noise;
     float thr;
     // decision margin (gj_onset.margin_before): the largest window sum that stayed below the
@@ -507,8 +515,7 @@ struct OnsetScratch {
 };
 
 __device__ __forceinline__ float onset_threshold(const OnsetScratch* sc, int noise_samples, float factor, float* noise_out) {
-    const long long S = 4ll * (long long)sc->noise_m2 - 1020ll * (long long)sc->noise_m1 + 65025ll * (2ll * noise_samples);
-    float noise = (float)((double)S / (4.0 * (double)noise_samples));
+    float noise = (float)((double)sc->noise_S / (4.0 * (double)noise_samples));
     if (noise == 0.f) noise = 1e-9f;          // triangulateTDOA.py:42
     if (noise_out) *noise_out = noise;
     return noise * factor;
@@ -523,7 +530,8 @@ __global__ __launch_bounds__(kScanThreads) void onset_noise_kernel(const uint8_t
                                                                    OnsetScratch* __restrict__ sc) {
     unsigned long long s2 = 0, s1 = 0;
     block_byte_moments(iq, 0, (size_t)2 * noise_samples, s2, s1);
-    if (threadIdx.x == 0) { sc->noise_m2 = s2; sc->noise_m1 = s1; }
+    if (threadIdx.x == 0)
+        sc->noise_S = (unsigned long long)(4ll * (long long)s2 - 1020ll * (long long)s1 + 65025ll * (2ll * noise_samples));
 }
 
 __device__ __forceinline__ int onset_pad(int k) { return k + (k >> 5); }   // spreads stride-`per` accesses over banks
@@ -799,6 +807,31 @@ int launch_onset(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, int noise_samp
 // ---------------------------------------------------------------------------------------
 typedef short gj_short2 __attribute__((ext_vector_type(2)));
 
+// Sum of v over the 64 lanes, valid in LANE 63 only: four in-row DPP steps, then row_bcast:15 into rows 1 and 3
+// and row_bcast:31 into rows 2 and 3 -- six VALU adds, no readlane, no LDS (group_sum_dpp<64> needs eleven
+// instructions to make the total wave-uniform, which the block-sum store does not need).
+__device__ __forceinline__ int wave_sum_lane63(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);   // row_mirror: every lane holds its row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15, rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31, rows 2 and 3
+    return v;
+}
+
+// (2I-255)^2 + (2Q-255)^2 of sample HI (0: bytes 0-1, 1: bytes 2-3) of the dword w: v_perm_b32 spreads (I, Q)
+// into the two 16-bit halves, v_pk_mad_i16 forms (2I-255, 2Q-255), v_dot2_i32_i16 squares and adds
+template <int HI>
+__device__ __forceinline__ int msq_of_half(unsigned w, unsigned k2, unsigned km255) {
+    const unsigned spread = __builtin_amdgcn_perm(w, w, HI ? 0x0C030C02u : 0x0C010C00u);
+    unsigned h;
+    int m;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(h) : "v"(spread), "v"(k2), "v"(km255));
+    asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(m) : "v"(h));
+    return m;
+}
+
 __device__ __forceinline__ float amp_of_pair(unsigned iq16) {   // iq16 = I | Q << 8
     // (2I-255, 2Q-255) as packed int16 -> dot with itself = 4|z|^2
     const unsigned spread = (iq16 & 0xffu) | ((iq16 & 0xff00u) << 8);          // I in bits 0-7, Q in bits 16-23
@@ -827,8 +860,10 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
     const size_t b1 = (b0 + kScanTile < use_end) ? b0 + kScanTile : use_end;
     const size_t nvec = (b1 - b0) >> 4;                            // full 16-byte vectors
     const uint4* v = reinterpret_cast<const uint4*>(iq + b0);
-    unsigned s2 = 0, s1 = 0, n2 = 0, n1 = 0;
-    double sum = 0.0;
+    // Everything comes from the per-sample m = (2I-255)^2 + (2Q-255)^2 (exact integers, three instructions per
+    // sample): amplitudes are sqrt(m) / 255, chunk power is sum(m) / (4 n), the K4 sums are sums of m.
+    unsigned S = 0, nS = 0;                                        // per lane: <= 16 vectors x 8 x 130050 < 2^32
+    double sum = 0.0;                                              // sum of sqrt(m); scaled by 1/255 once per tile
     long long first = 0x7fffffffffffffffll;
     const bool in_noise = b0 < noise_bytes;                        // tile touches the K4 noise span
     unsigned k2 = 0x00020002u, km255 = 0xFF01FF01u;
@@ -836,28 +871,29 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
     // `live` is false only for the lanes past the end of a partial last tile (see below): they take
     // part in the wave-wide reductions with zero contributions
     auto body = [&](const uint4& q, size_t i, const bool live) {
-        unsigned v2 = 0, v1 = 0;
-        acc_moments(q, v2, v1);   // a dead lane carries a zero vector: v2 = v1 = 0
-        s2 += v2;
-        s1 += v1;
-        if (in_noise && b0 + (i << 4) < noise_bytes) { n2 += v2; n1 += v1; }   // noise_bytes % 16 == 0
-        // block sum of 4|z|^2 over the wave = one 512-sample block (wave-uniform after the reduction)
-        const unsigned m8 = 4u * v2 - 1020u * v1 + 16u * 65025u;
-        const int c512 = group_sum_dpp<64>((int)(live ? m8 : 0u));
-        if ((tid & 63) == 0) cblk[(b0 >> 10) + (i >> 6)] = (unsigned)c512;
         const unsigned ws[4] = {q.x, q.y, q.z, q.w};
-        float part = 0.f;
+        int m[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float a0 = amp_of_half<0>(ws[k], k2, km255), a1 = amp_of_half<1>(ws[k], k2, km255);
-            part += a0;
-            part += a1;
+            m[2 * k] = msq_of_half<0>(ws[k], k2, km255);
+            m[2 * k + 1] = msq_of_half<1>(ws[k], k2, km255);
+        }
+        float part = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float r = __fsqrt_rn((float)m[k]);
+            part += r;
             if constexpr (TRACK_FIRST) {
-                const long long base = (long long)((b0 >> 1) + i * 8 + 2 * k);
-                if (live && a0 > thr && base < first) first = base;
-                if (live && a1 > thr && base + 1 < first) first = base + 1;
+                const long long idx = (long long)((b0 >> 1) + i * 8 + k);
+                if (live && r * (1.0f / 255.0f) > thr && idx < first) first = idx;   // same expression as K3 alone
             }
         }
+        const unsigned m8 = live ? (unsigned)(((m[0] + m[1]) + (m[2] + m[3])) + ((m[4] + m[5]) + (m[6] + m[7]))) : 0u;
+        S += m8;
+        if (in_noise && b0 + (i << 4) < noise_bytes) nS += m8;      // noise_bytes % 16 == 0
+        // block sum of 4|z|^2 over the wave = one 512-sample block
+        const int c512 = wave_sum_lane63((int)m8);
+        if ((tid & 63) == 63) cblk[(b0 >> 10) + (i >> 6)] = (unsigned)c512;
         sum += (double)(live ? part : 0.f);
     };
     if (nvec == kScanTile / 16) {
@@ -886,12 +922,12 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
         unsigned c = 0;
         for (size_t n = (b0 >> 1) + nvec * 8; 2 * n < b1; ++n) {
             const unsigned ui = iq[2 * n], uq = iq[2 * n + 1];
-            s2 += ui * ui + uq * uq;
-            s1 += ui + uq;
-            c += m_of(ui, uq);
-            const float a = amp_of_pair(ui | (uq << 8));
-            sum += (double)a;
-            if (TRACK_FIRST && a > thr && (long long)n < first) first = (long long)n;
+            const unsigned mm = m_of(ui, uq);
+            S += mm;
+            c += mm;
+            const float r = __fsqrt_rn((float)mm);
+            sum += (double)r;
+            if (TRACK_FIRST && r * (1.0f / 255.0f) > thr && (long long)n < first) first = (long long)n;
         }
         (void)c;
     }
@@ -909,26 +945,25 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
         }
     }
     if (in_noise) {
-        const unsigned long long w2 = wave_sum_u64(n2), w1 = wave_sum_u64(n1);
-        if ((tid & 63) == 0) { atomicAdd(&sc->noise_m2, w2); atomicAdd(&sc->noise_m1, w1); }
+        const unsigned long long wn = wave_sum_u64(nS);
+        if ((tid & 63) == 0) atomicAdd(&sc->noise_S, wn);
     }
     if constexpr (!TRACK_FIRST) {
         if (tid == 0 && b1 > b0) first = (long long)(b0 >> 1);   // threshold below the smallest amplitude
     }
-    const unsigned long long m2 = wave_sum_u64(s2), m1 = wave_sum_u64(s1);
+    const unsigned long long mS = wave_sum_u64(S);
     sum = wave_sum_f64(sum);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const long long o = __shfl_xor(first, off, 64);
         first = o < first ? o : first;
     }
-    if ((tid & 63) == 0) { red_m[0][tid >> 6] = m2; red_m[1][tid >> 6] = m1; red_s[tid >> 6] = sum; red_f[tid >> 6] = first; }
+    if ((tid & 63) == 0) { red_m[0][tid >> 6] = mS; red_s[tid >> 6] = sum; red_f[tid >> 6] = first; }
     __syncthreads();
     if (tid == 0) {
-        const unsigned long long t2 = red_m[0][0] + red_m[0][1] + red_m[0][2] + red_m[0][3];
-        const unsigned long long t1 = red_m[1][0] + red_m[1][1] + red_m[1][2] + red_m[1][3];
+        const unsigned long long tS = red_m[0][0] + red_m[0][1] + red_m[0][2] + red_m[0][3];
         AmpTile at;
-        at.sum = (red_s[0] + red_s[1]) + (red_s[2] + red_s[3]);
+        at.sum = ((red_s[0] + red_s[1]) + (red_s[2] + red_s[3])) * (1.0 / 255.0);
         long long f = red_f[0];
         for (int k = 1; k < 4; ++k) f = red_f[k] < f ? red_f[k] : f;
         at.first = f;
@@ -938,10 +973,9 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
         const size_t len = (nbytes - off < chunk_bytes) ? nbytes - off : chunk_bytes;
         const bool zero_rule = (flags & GJ_CP_ODD_CHUNK_ZERO) && ((len & 1) || len == 0);
         if (tiles_per_chunk == 1) {
-            power[c] = zero_rule ? 0.0f : ((len >> 1) ? power_from_moments(t2, t1, len >> 1, eps) : __builtin_nanf(""));
+            power[c] = zero_rule ? 0.0f : ((len >> 1) ? power_from_msum(tS, len >> 1, eps) : __builtin_nanf(""));
         } else {
-            atomicAdd(&acc[2 * c], t2);
-            atomicAdd(&acc[2 * c + 1], t1);
+            atomicAdd(&acc[2 * c], tS);
         }
     }
 }
@@ -994,7 +1028,7 @@ int launch_stream_scan(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t c
     GJ_LAUNCH_CHECK(ctx);
     if (tpc > 1) {
         hipLaunchKernelGGL(chunk_power_finalize_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0,
-                           ctx->stream, acc, nchunks, nbytes, chunk_bytes, eps, flags, d_power);
+                           ctx->stream, acc, nchunks, nbytes, chunk_bytes, eps, flags, d_power, true);
         GJ_LAUNCH_CHECK(ctx);
     }
     // amplitude totals + the chunk-power edge cases (last chunk odd / without a complete pair)
