@@ -41,6 +41,20 @@ __device__ __forceinline__ void acq_passes(c2 (&v)[16], cf* lds, int base, int j
     }
 }
 
+// the same with the pass twiddles already in registers (loops that transform many times)
+template <int N, int PASS>
+__device__ __forceinline__ void acq_passes_tw(c2 (&v)[16], cf* lds, int base, int jl, const c2 (&tw)[3][15]) {
+    constexpr int NP = fft_npass(N);
+    fft_pass<N, PASS, false, true>(v, tw[PASS], inner_twiddles());
+    if constexpr (PASS + 1 < NP) {
+        lds_scatter<N, PASS>(v, lds, base, jl);
+        __syncthreads();
+        lds_gather<N>(v, lds, base, jl);
+        __syncthreads();
+        acq_passes_tw<N, PASS + 1>(v, lds, base, jl, tw);
+    }
+}
+
 // 16-entry mixer tables of the reference's SSE2 path: (char)floor(cos(2 pi i / 16) / CSCALE + 0.5), CSCALE = 1/32
 __constant__ signed char kAcqCos[16] = {32, 30, 23, 12, 0, -12, -23, -30, -32, -30, -23, -12, 0, 12, 23, 30};
 __constant__ signed char kAcqSin[16] = {0, 12, 23, 30, 32, 30, 23, 12, 0, -12, -23, -30, -32, -30, -23, -12};
@@ -212,13 +226,159 @@ __global__ __launch_bounds__(1024) void acq_check_kernel(AcqParams P, int step, 
     }
 }
 
+// ---- single-launch form (no d_power requested) ---------------------------------------------------
+// One workgroup per (PRN, Doppler bin) runs ALL integration steps: the code spectrum and the running power of
+// its row stay in registers, nothing of P goes through memory.  After every step it records what
+// checkacquisition would need from this row IF it turned out to hold the PRN's peak: the row's first maximum,
+// and -- with the exclusion zone centred on that maximum -- maxvd's second peak and meanvd's sum.  The
+// summary kernel then replays the reference's step loop per PRN on those 71 x intg records.
+struct AcqRow {
+    double maxv, max2, sum;
+    int argk, cnt;
+};
+
+template <int N, typename T, typename F>
+__device__ __forceinline__ T acq_group_reduce(T v, F&& op, T* sh /* [kBlockThreads / 64] */, int b) {
+    constexpr int TF = N / 16, WPF = TF / 64;   // waves per transform (N >= 1024)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        T o;
+        if constexpr (sizeof(T) == 16) {
+            o.val = __shfl_xor(v.val, off, 64);
+            o.idx = __shfl_xor(v.idx, off, 64);
+        } else {
+            o = __shfl_xor(v, off, 64);
+        }
+        v = op(v, o);
+    }
+    if constexpr (WPF == 1) return v;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    T r = sh[b * WPF];
+#pragma unroll
+    for (int k = 1; k < WPF; ++k) r = op(r, sh[b * WPF + k]);
+    return r;
+}
+
+template <int N>
+__global__ __launch_bounds__(kBlockThreads) void acq_inv_all_kernel(AcqParams P, int nsampchip, const cf* __restrict__ twtab,
+                                                                    const cf* __restrict__ xspec,
+                                                                    const cf* __restrict__ cspec,
+                                                                    AcqRow* __restrict__ rows /* [n_prn][intg][n_freq] */) {
+    constexpr int TF = N / 16, B = kBlockPoints / N;
+    __shared__ cf lds[B * lds_span(N)];
+    __shared__ AcqBest shb[kBlockThreads / 64];
+    __shared__ double shd[kBlockThreads / 64];
+    __shared__ int shi[kBlockThreads / 64];
+    const int p = blockIdx.y;
+    const int tid = threadIdx.x, b = tid / TF, jl = tid % TF;
+    const int f = blockIdx.x * B + b;
+    const bool live = f < P.n_freq;
+    const cf* c = cspec + (size_t)p * N;
+    cf cq[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) cq[s] = c[jl + TF * s];
+    c2 tw[3][15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) tw[0][k] = tw[1][k] = tw[2][k] = make_c2(1.f, 0.f);
+    if constexpr (fft_npass(N) > 1) load_twiddles<N, 1>(tw[1], twtab, jl);
+    if constexpr (fft_npass(N) > 2) load_twiddles<N, 2>(tw[2], twtab, jl);
+    double acc[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc[s] = 0.0;
+    for (int step = 0; step < P.intg; ++step) {
+        const cf* x = xspec + ((size_t)step * P.n_freq + (live ? f : 0)) * N;
+        c2 v[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const cf a = x[jl + TF * s], q = cq[s];
+            v[s] = make_c2(-a.x * q.x - a.y * q.y, -(a.x * q.y - a.y * q.x));   // as in acq_inv_kernel
+        }
+        acq_passes_tw<N, 0>(v, lds, b * lds_span(N), jl, tw);
+        AcqBest best{-1.0, 0x7fffffff};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            acc[s] += (double)((v[s].x * v[s].x + v[s].y * v[s].y) * P.inv_m2);
+            best = acq_better(best, AcqBest{acc[s], jl + TF * s});
+        }
+        best = acq_group_reduce<N>(best, [](AcqBest a, AcqBest o) { return acq_better(a, o); }, shb, b);
+        int exinds = best.idx - 2 * nsampchip, exinde = best.idx + 2 * nsampchip;
+        if (exinds < 0) exinds += P.nsamp;
+        if (exinde >= P.nsamp) exinde -= P.nsamp;
+        double sum = 0.0, mx2 = (jl == 0) ? acc[0] : -1.0;   // maxvd seeds with data[0] whatever the exclusion zone says
+        int cnt = 0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int i = jl + TF * s;
+            const bool kept = (exinds <= exinde) ? (i < exinds || i > exinde) : (i < exinds && i > exinde);
+            if (kept) {
+                sum += acc[s];
+                ++cnt;
+                if (i >= 1) mx2 = acc[s] > mx2 ? acc[s] : mx2;
+            }
+        }
+        sum = acq_group_reduce<N>(sum, [](double a, double o) { return a + o; }, shd, b);
+        mx2 = acq_group_reduce<N>(mx2, [](double a, double o) { return a > o ? a : o; }, shd, b);
+        cnt = acq_group_reduce<N>(cnt, [](int a, int o) { return a + o; }, shi, b);
+        if (live && jl == 0) {
+            AcqRow r;
+            r.maxv = best.val;
+            r.max2 = mx2;
+            r.sum = sum;
+            r.argk = best.idx;
+            r.cnt = cnt;
+            rows[((size_t)p * P.intg + step) * P.n_freq + f] = r;
+        }
+    }
+}
+
+// the reference's loop over the integration steps (sdracq.c:15-28), replayed on the row records
+__global__ __launch_bounds__(64) void acq_summary_kernel(AcqParams P, double ctime, float threshold,
+                                                         const AcqRow* __restrict__ rows, gj_acq_result* __restrict__ out) {
+    const int p = blockIdx.x;
+    for (int step = 0; step < P.intg; ++step) {
+        const AcqRow* rr = rows + ((size_t)p * P.intg + step) * P.n_freq;
+        AcqBest b{-1.0, 0x7fffffff};   // idx = Doppler row; equal maxima: the smaller flat index = the smaller row
+        for (int f = threadIdx.x; f < P.n_freq; f += 64) b = acq_better(b, AcqBest{rr[f].maxv, f});
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            AcqBest o;
+            o.val = __shfl_xor(b.val, off, 64);
+            o.idx = __shfl_xor(b.idx, off, 64);
+            b = acq_better(b, o);
+        }
+        const AcqRow w = rr[b.idx];
+        const double meanP = w.sum / (double)w.cnt;
+        const double peakr = w.maxv / w.max2;
+        const bool acquired = peakr > (double)threshold;
+        if (acquired || step + 1 == P.intg) {
+            if (threadIdx.x == 0) {
+                gj_acq_result r;
+                r.max_power = w.maxv;
+                r.second_power = w.max2;
+                r.mean_power = meanP;
+                r.peak_ratio = peakr;
+                r.cn0 = 10.0 * log10(w.maxv / meanP / ctime);
+                r.code_index = w.argk;
+                r.freq_index = b.idx;
+                r.steps = step + 1;
+                r.acquired = acquired ? 1 : 0;
+                out[p] = r;
+            }
+            return;
+        }
+    }
+}
+
 size_t acq_workspace(int nsamp, int n_freq, int n_prn, int intg, bool own_power) {
     const size_t nfft = 2 * (size_t)nsamp;
     size_t b = 256;                                                        // done flags
     b += align_up((size_t)n_prn * sizeof(int), 256);
     b += align_up((size_t)n_prn * nfft * sizeof(cf), 256);                 // code spectra
     b += align_up((size_t)intg * n_freq * nfft * sizeof(cf), 256);         // data spectra
-    if (own_power) b += align_up((size_t)n_prn * n_freq * nsamp * sizeof(double), 256);
+    // no power array requested: the single-launch form keeps P in registers and needs the row records only
+    if (own_power) b += align_up((size_t)n_prn * intg * n_freq * sizeof(AcqRow), 256);
     return b;
 }
 
@@ -233,9 +393,6 @@ static int acq_run(gj_ctx* ctx, const AcqParams& P, const short* d_codes, const 
     w += align_up((size_t)P.n_prn * N * sizeof(cf), 256);
     cf* xspec = reinterpret_cast<cf*>(w);
     w += align_up((size_t)P.intg * P.n_freq * N * sizeof(cf), 256);
-    double* power = d_power ? d_power : reinterpret_cast<double*>(w);
-    GJ_HIP(ctx, hipMemsetAsync(done, 0, (size_t)P.n_prn * sizeof(int), ctx->stream));
-    GJ_HIP(ctx, hipMemsetAsync(power, 0, (size_t)P.n_prn * P.n_freq * P.nsamp * sizeof(double), ctx->stream));   // calloc, sdrmain.c:346
     GJ_HIP(ctx, hipMemsetAsync(d_out, 0, (size_t)P.n_prn * sizeof(gj_acq_result), ctx->stream));
     hipLaunchKernelGGL((acq_code_kernel<N>), dim3((unsigned)((P.n_prn + B - 1) / B)), dim3(kBlockThreads), 0, ctx->stream,
                        d_codes, P.nsamp, P.n_prn, ctx->d_twiddle, cspec);
@@ -243,6 +400,20 @@ static int acq_run(gj_ctx* ctx, const AcqParams& P, const short* d_codes, const 
     hipLaunchKernelGGL((acq_fwd_kernel<N>), dim3((unsigned)((P.intg * P.n_freq + B - 1) / B)), dim3(kBlockThreads), 0,
                        ctx->stream, P, d_phase, ctx->d_twiddle, xspec);
     GJ_LAUNCH_CHECK(ctx);
+    if (!d_power) {
+        AcqRow* rows = reinterpret_cast<AcqRow*>(w);
+        hipLaunchKernelGGL((acq_inv_all_kernel<N>), dim3((unsigned)((P.n_freq + B - 1) / B), (unsigned)P.n_prn),
+                           dim3(kBlockThreads), 0, ctx->stream, P, nsampchip, ctx->d_twiddle, xspec, cspec, rows);
+        GJ_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(acq_summary_kernel, dim3((unsigned)P.n_prn), dim3(64), 0, ctx->stream, P, ctime, threshold, rows,
+                           d_out);
+        GJ_LAUNCH_CHECK(ctx);
+        return GJ_OK;
+    }
+    // the caller wants the power array: step by step, P in memory, a PRN's rows frozen when it acquires
+    double* power = d_power;
+    GJ_HIP(ctx, hipMemsetAsync(done, 0, (size_t)P.n_prn * sizeof(int), ctx->stream));
+    GJ_HIP(ctx, hipMemsetAsync(power, 0, (size_t)P.n_prn * P.n_freq * P.nsamp * sizeof(double), ctx->stream));   // calloc, sdrmain.c:346
     for (int step = 0; step < P.intg; ++step) {
         hipLaunchKernelGGL((acq_inv_kernel<N>), dim3((unsigned)((P.n_freq + B - 1) / B), (unsigned)P.n_prn),
                            dim3(kBlockThreads), 0, ctx->stream, P, step, done, ctx->d_twiddle, xspec, cspec, power);

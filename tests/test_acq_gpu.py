@@ -40,8 +40,12 @@ def test_acq_search_matches_oracle(dev):
     with dev.capture(raw) as cap:
         res, P = srch.search(cap, first_sample=first, want_power=True)
         again = srch.search(cap, first_sample=first)                 # second run: workspace state is reset
+    # the single-launch form (row records, P in registers) replays the same decisions as the step-by-step form
     assert [(r.acquired, r.code_index, r.freq_index, r.steps) for r in res] == \
            [(r.acquired, r.code_index, r.freq_index, r.steps) for r in again]
+    for a, b in zip(res, again):
+        np.testing.assert_allclose([a.max_power, a.second_power, a.mean_power, a.peak_ratio, a.cn0],
+                                   [b.max_power, b.second_power, b.mean_power, b.peak_ratio, b.cn0], rtol=1e-12)
     by_prn = {r.prn: r for r in res}
     for k, prn in enumerate(prns):
         want, Pw = orc.acq_search(raw, first, prn)

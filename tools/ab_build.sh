@@ -7,5 +7,5 @@ cd "$(dirname "$0")/../gps-jamming_amd/csrc"
 mkdir -p ../../build_ab
 make -s -j8
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -I. $2 -c k_welch.hip -o /tmp/kw_$1.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build_ab/libgpsjam_$1.so api.o k_scan.o /tmp/kw_$1.o k_xcorr.o k_synth.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build_ab/libgpsjam_$1.so api.o k_scan.o /tmp/kw_$1.o k_xcorr.o k_synth.o k_acq.o comm.o -ldl
 echo built build_ab/libgpsjam_$1.so

@@ -4,13 +4,27 @@ dispatch of welch_kernel) with the HBM byte counts corrected as MI355X_MICROARCH
 FETCH_SIZE is in KiB and, on gfx950, tallies 128-B requests at 64 B for wide streaming reads;
 the factor for K2's own 2-byte-per-lane pattern is calibrated by tools/calib_fetch (1 GiB read
 exactly once with each pattern) in the same session.
-    python tools/pmc_summarize.py gpurun_out/<dir> > profiles/r01_pmc_welch/summary_final.json"""
+    python tools/pmc_summarize.py gpurun_out/<dir> > profiles/r02_pmc_welch/summary.json
+The summary is stamped with the commit it was measured on and with a hash of the K2 sources
+(bench.py compares that hash with the sources it runs on)."""
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
+import subprocess
 import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def source_hash():
+    h = hashlib.sha256()
+    for name in ("k_welch.hip", "fft_core.h", "gj_common.h"):
+        with open(os.path.join(REPO, "gps-jamming_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def collect(root, kernel_substr):
@@ -42,6 +56,15 @@ def main():
     if "read_bytes" in corr and "write_bytes" in corr:
         corr["hbm_bytes_per_launch"] = corr["read_bytes"] + corr["write_bytes"]
     out["_hbm_bytes_corrected"] = corr
+    if k2.get("SQ_INSTS_VALU") is not None:
+        out["_valu"] = {"sq_insts_valu_per_launch": k2["SQ_INSTS_VALU"],
+                        "sq_insts_lds_per_launch": k2.get("SQ_INSTS_LDS"), "sq_waves": k2.get("SQ_WAVES")}
+    try:
+        out["_commit"] = subprocess.run(["git", "-C", REPO, "rev-parse", "--short=12", "HEAD"], capture_output=True,
+                                        text=True, check=True).stdout.strip()
+    except Exception:
+        out["_commit"] = "unknown"
+    out["_source_hash"] = source_hash()
     out["_note"] = ("rocprofv3 --pmc, separate passes (tools/pmc_welch.sh), welch_kernel<4096> on 2^30 bytes, "
                     "averages per dispatch")
     print(json.dumps(out, indent=1))
