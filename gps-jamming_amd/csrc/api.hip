@@ -148,6 +148,25 @@ int gj_set_stream(gj_ctx* ctx, void* hip_stream, int external) {
     return GJ_OK;
 }
 
+int gj_set_unpack(gj_ctx* ctx, double offset, double scale) {
+    if (!ctx) return GJ_ERR_INVALID;
+    Guard g(ctx);
+    const double o2 = 2.0 * offset;
+    if (!(o2 >= 0.0 && o2 <= 510.0) || o2 != (double)(int)o2) return fail(ctx, GJ_ERR_INVALID, "offset must be a multiple of 0.5 in [0, 255]");
+    if (!(scale > 0.0) || !(scale < 1e6)) return fail(ctx, GJ_ERR_INVALID, "scale must be positive");
+    ctx->off2 = (int)o2;
+    ctx->scale = scale;
+    return GJ_OK;
+}
+
+int gj_get_unpack(gj_ctx* ctx, double* offset, double* scale) {
+    if (!ctx) return GJ_ERR_INVALID;
+    Guard g(ctx);
+    if (offset) *offset = 0.5 * ctx->off2;
+    if (scale) *scale = ctx->scale;
+    return GJ_OK;
+}
+
 int gj_synchronize(gj_ctx* ctx) {
     if (!ctx) return GJ_ERR_INVALID;
     Guard g(ctx);

@@ -25,10 +25,27 @@ struct gj_ctx {
     static constexpr int kPinBufs = 16;   // pinned bounce buffers of the host-buffer entry points (2 per fill thread)
     void* pin[kPinBufs] = {};
     hipEvent_t pin_ev[kPinBufs] = {};
+    // unpack convention (gj_set_unpack): sample = (u8 - offset) * scale; off2 = 2 * offset is an integer
+    int off2 = 255;
+    double scale = 1.0 / 127.5;
     char last_error[512] = {0};
 };
 
 namespace gj {
+
+// what the kernels need of the unpack convention: v = 2 u - off2 (exact integer), |sample| = |v| * half_scale
+struct Unpack {
+    int off2;
+    float half_scale;
+};
+inline Unpack unpack_of(const gj_ctx* ctx) { return Unpack{ctx->off2, (float)(ctx->scale * 0.5)}; }
+// (2 / scale)^2, snapped to the integer it is meant to be (65025 for the default 1/127.5)
+inline double unpack_norm2(const gj_ctx* ctx) {
+    double n = 2.0 / ctx->scale;
+    const double r = (double)(long long)(n + 0.5);
+    if (n - r < 1e-9 && r - n < 1e-9) n = r;
+    return n * n;
+}
 
 inline int fail(gj_ctx* ctx, int code, const char* fmt, ...) {
     if (ctx) {

@@ -60,9 +60,9 @@ __device__ __forceinline__ void block_byte_moments(const uint8_t* __restrict__ p
 }
 
 __device__ __forceinline__ float power_from_moments(unsigned long long s2, unsigned long long s1, size_t npairs,
-                                                    float eps) {
-    // sum (2u-255)^2 over 2*npairs bytes
-    const long long S = 4ll * (long long)s2 - 1020ll * (long long)s1 + 65025ll * (long long)(2 * npairs);
+                                                    float eps, int o2) {
+    // sum (2u-off2)^2 over 2*npairs bytes
+    const long long S = 4ll * (long long)s2 - 4ll * o2 * (long long)s1 + (long long)o2 * o2 * (long long)(2 * npairs);
     const float mean = (float)((double)S / (4.0 * (double)npairs));
     return mean + eps;
 }
@@ -76,7 +76,7 @@ __device__ __forceinline__ float power_from_msum(unsigned long long S, size_t np
 __global__ __launch_bounds__(kScanThreads) void chunk_power_kernel(const uint8_t* __restrict__ iq, size_t nbytes,
                                                                    size_t chunk_bytes, unsigned tiles_per_chunk,
                                                                    float eps, int flags, float* __restrict__ power,
-                                                                   unsigned long long* __restrict__ acc) {
+                                                                   unsigned long long* __restrict__ acc, int o2) {
     const size_t c = blockIdx.x / tiles_per_chunk;
     const unsigned t = blockIdx.x % tiles_per_chunk;
     const size_t off = c * chunk_bytes;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kScanThreads) void chunk_power_kernel(const uint8_t
     block_byte_moments(iq, b, e, s2, s1);
     if (threadIdx.x == 0) {
         if (tiles_per_chunk == 1) {
-            power[c] = power_from_moments(s2, s1, npairs, eps);
+            power[c] = power_from_moments(s2, s1, npairs, eps, o2);
         } else {
             atomicAdd(&acc[2 * c], s2);
             atomicAdd(&acc[2 * c + 1], s1);
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kScanThreads) void chunk_power_kernel(const uint8_t
 // msum: acc[2c] holds the sum of (2u-255)^2 itself (fused scan) instead of the byte moments
 __global__ void chunk_power_finalize_kernel(const unsigned long long* __restrict__ acc, size_t nchunks, size_t nbytes,
                                             size_t chunk_bytes, float eps, int flags, float* __restrict__ power,
-                                            bool msum = false) {
+                                            int o2, bool msum = false) {
     const size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
     const size_t off = c * chunk_bytes;
@@ -118,7 +118,7 @@ __global__ void chunk_power_finalize_kernel(const unsigned long long* __restrict
     const size_t npairs = len >> 1;
     if ((flags & GJ_CP_ODD_CHUNK_ZERO) && ((len & 1) || len == 0)) return;   // already written
     if (npairs == 0) return;
-    power[c] = msum ? power_from_msum(acc[2 * c], npairs, eps) : power_from_moments(acc[2 * c], acc[2 * c + 1], npairs, eps);
+    power[c] = msum ? power_from_msum(acc[2 * c], npairs, eps) : power_from_moments(acc[2 * c], acc[2 * c + 1], npairs, eps, o2);
 }
 
 int launch_chunk_power(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
@@ -136,11 +136,11 @@ int launch_chunk_power(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t c
         GJ_HIP(ctx, hipMemsetAsync(acc, 0, nchunks * 16, ctx->stream));
     }
     hipLaunchKernelGGL(chunk_power_kernel, dim3((unsigned)(nchunks * tiles)), dim3(kScanThreads), 0, ctx->stream, d_iq,
-                       nbytes, chunk_bytes, (unsigned)tiles, eps, flags, d_power, acc);
+                       nbytes, chunk_bytes, (unsigned)tiles, eps, flags, d_power, acc, ctx->off2);
     GJ_LAUNCH_CHECK(ctx);
     if (tiles > 1) {
         hipLaunchKernelGGL(chunk_power_finalize_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0,
-                           ctx->stream, acc, nchunks, nbytes, chunk_bytes, eps, flags, d_power);
+                           ctx->stream, acc, nchunks, nbytes, chunk_bytes, eps, flags, d_power, ctx->off2);
         GJ_LAUNCH_CHECK(ctx);
     }
     return GJ_OK;
@@ -334,23 +334,25 @@ int launch_power_threshold(gj_ctx* ctx, const float* d_power, size_t n, float pc
 // ---------------------------------------------------------------------------------------
 // K3 amplitude statistics
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float amp_of(unsigned i8, unsigned q8) {
-    const int vi = 2 * (int)i8 - 255, vq = 2 * (int)q8 - 255;
-    return __fsqrt_rn((float)(vi * vi + vq * vq)) * (1.0f / 255.0f);
+__device__ __forceinline__ float amp_of(unsigned i8, unsigned q8, Unpack up) {
+    const int vi = 2 * (int)i8 - up.off2, vq = 2 * (int)q8 - up.off2;
+    return __fsqrt_rn((float)(vi * vi + vq * vq)) * up.half_scale;
 }
+// packed (-off2, -off2) for v_pk_mad_i16
+__device__ __forceinline__ unsigned pk_minus_off2(int o2) { return ((unsigned)(-o2) & 0xffffu) * 0x10001u; }
 
 // amp_of for sample `HI` (0: bytes 0-1, 1: bytes 2-3) of the dword w, in three integer
 // instructions instead of seven: v_perm_b32 spreads (I, Q) into the two 16-bit halves,
 // v_pk_mad_i16 forms (2I-255, 2Q-255), v_dot2_i32_i16 squares and adds.  k2 = 0x00020002,
 // km255 = 0xFF01FF01 (packed -255) are loop-invariant registers.
 template <int HI>
-__device__ __forceinline__ float amp_of_half(unsigned w, unsigned k2, unsigned km255) {
+__device__ __forceinline__ float amp_of_half(unsigned w, unsigned k2, unsigned km255, float hs) {
     const unsigned spread = __builtin_amdgcn_perm(w, w, HI ? 0x0C030C02u : 0x0C010C00u);
     unsigned h;
     int m;
     asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(h) : "v"(spread), "v"(k2), "v"(km255));
     asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(m) : "v"(h));
-    return __fsqrt_rn((float)m) * (1.0f / 255.0f);
+    return __fsqrt_rn((float)m) * hs;
 }
 
 constexpr size_t kAmpTileSamples = kScanTile / 2;
@@ -361,7 +363,7 @@ struct AmpTile {
 };
 
 __global__ __launch_bounds__(kScanThreads) void amp_tiles_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
-                                                                 float thr, AmpTile* __restrict__ tiles) {
+                                                                 float thr, AmpTile* __restrict__ tiles, Unpack up) {
     __shared__ double rs[kScanThreads / 64];
     __shared__ long long rf[kScanThreads / 64];
     const size_t s0 = (size_t)blockIdx.x * kAmpTileSamples;
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(kScanThreads) void amp_tiles_kernel(const uint8_t* 
     const bool aligned = ((reinterpret_cast<uintptr_t>(iq) & 15) == 0);
     const size_t nfull = aligned ? ((s1 - s0) >> 3) : 0;   // groups of 8 samples = 16 bytes
     const uint4* v = reinterpret_cast<const uint4*>(iq + 2 * s0);
-    unsigned k2 = 0x00020002u, km255 = 0xFF01FF01u;
+    unsigned k2 = 0x00020002u, km255 = pk_minus_off2(up.off2);
     asm volatile("" : "+v"(k2), "+v"(km255));   // both in VGPRs (one constant-bus slot per op)
     for (size_t gidx = tid; gidx < nfull; gidx += kScanThreads) {
         const uint4 w = v[gidx];
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(kScanThreads) void amp_tiles_kernel(const uint8_t* 
         const long long base = (long long)(s0 + gidx * 8);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float a0 = amp_of_half<0>(ws[k], k2, km255), a1 = amp_of_half<1>(ws[k], k2, km255);
+            const float a0 = amp_of_half<0>(ws[k], k2, km255, up.half_scale), a1 = amp_of_half<1>(ws[k], k2, km255, up.half_scale);
             part += a0;
             part += a1;
             if (a0 > thr && base + 2 * k < first) first = base + 2 * k;
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(kScanThreads) void amp_tiles_kernel(const uint8_t* 
         sum += (double)part;
     }
     for (size_t s = s0 + nfull * 8 + tid; s < s1; s += kScanThreads) {
-        const float a = amp_of(iq[2 * s], iq[2 * s + 1]);
+        const float a = amp_of(iq[2 * s], iq[2 * s + 1], up);
         sum += (double)a;
         if (a > thr && (long long)s < first) first = (long long)s;
     }
@@ -425,7 +427,7 @@ __device__ double block_sum_f64(double v, double* sh /* [blockDim/64] */) {
 
 __global__ __launch_bounds__(1024) void amp_finalize_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
                                                             const AmpTile* __restrict__ tiles, size_t ntiles,
-                                                            gj_amp_stats* __restrict__ out,
+                                                            gj_amp_stats* __restrict__ out, Unpack up,
                                                             float* __restrict__ power = nullptr, size_t nchunks = 0,
                                                             size_t nbytes = 0, size_t chunk_bytes = 1, int flags = 0) {
     // (fused scan only) the last chunk when no tile wrote it or the odd-chunk rule applies
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(1024) void amp_finalize_kernel(const uint8_t* __res
         // remainder of the tile that holds the first hit
         const size_t e0 = ((t0 + 1) * kAmpTileSamples < nsamples) ? (t0 + 1) * kAmpTileSamples : nsamples;
         for (size_t s = (size_t)first + threadIdx.x; s < e0; s += blockDim.x)
-            acc += (double)amp_of(iq[2 * s], iq[2 * s + 1]);
+            acc += (double)amp_of(iq[2 * s], iq[2 * s + 1], up);
     }
     const double total = block_sum_f64(acc, sh);
     if (threadIdx.x == 0) {
@@ -481,10 +483,11 @@ int launch_amp_stats(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, float thre
     AmpTile* tiles = reinterpret_cast<AmpTile*>(ctx->ws);
     if (ntiles) {
         hipLaunchKernelGGL(amp_tiles_kernel, dim3((unsigned)ntiles), dim3(kScanThreads), 0, ctx->stream, d_iq, nsamples,
-                           threshold, tiles);
+                           threshold, tiles, unpack_of(ctx));
         GJ_LAUNCH_CHECK(ctx);
     }
-    hipLaunchKernelGGL(amp_finalize_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_iq, nsamples, tiles, ntiles, d_out);
+    hipLaunchKernelGGL(amp_finalize_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_iq, nsamples, tiles, ntiles, d_out,
+                       unpack_of(ctx));
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
 }
@@ -521,17 +524,17 @@ __device__ __forceinline__ float onset_threshold(const OnsetScratch* sc, int noi
     return noise * factor;
 }
 
-__device__ __forceinline__ unsigned m_of(unsigned i8, unsigned q8) {
-    const int vi = 2 * (int)i8 - 255, vq = 2 * (int)q8 - 255;
+__device__ __forceinline__ unsigned m_of(unsigned i8, unsigned q8, int o2 = 255) {
+    const int vi = 2 * (int)i8 - o2, vq = 2 * (int)q8 - o2;
     return (unsigned)(vi * vi + vq * vq);   // = 4 |z|^2
 }
 
 __global__ __launch_bounds__(kScanThreads) void onset_noise_kernel(const uint8_t* __restrict__ iq, int noise_samples,
-                                                                   OnsetScratch* __restrict__ sc) {
+                                                                   OnsetScratch* __restrict__ sc, int o2) {
     unsigned long long s2 = 0, s1 = 0;
     block_byte_moments(iq, 0, (size_t)2 * noise_samples, s2, s1);
     if (threadIdx.x == 0)
-        sc->noise_S = (unsigned long long)(4ll * (long long)s2 - 1020ll * (long long)s1 + 65025ll * (2ll * noise_samples));
+        sc->noise_S = (unsigned long long)(4ll * (long long)s2 - 4ll * o2 * (long long)s1 + (long long)o2 * o2 * (2ll * noise_samples));
 }
 
 __device__ __forceinline__ int onset_pad(int k) { return k + (k >> 5); }   // spreads stride-`per` accesses over banks
@@ -550,7 +553,7 @@ template <int BS>
 __global__ __launch_bounds__(kScanThreads) void onset_coarse_kernel(const uint8_t* __restrict__ iq,
                                                                     const unsigned* __restrict__ cblk, size_t nsamples,
                                                                     int window, int noise_samples, float factor,
-                                                                    OnsetScratch* __restrict__ sc) {
+                                                                    OnsetScratch* __restrict__ sc, int o2) {
     __shared__ unsigned pre[kCoarseBlocks + kCoarseHalo + (kCoarseBlocks + kCoarseHalo) / 32 + 8];
     __shared__ unsigned thread_tot[kScanThreads];
     const size_t nout = nsamples - (size_t)window + 1;
@@ -577,9 +580,9 @@ __global__ __launch_bounds__(kScanThreads) void onset_coarse_kernel(const uint8_
                     const uint4 q = v[j];
                     unsigned s2 = 0, s1 = 0;
                     acc_moments(q, s2, s1);
-                    c = 4u * s2 - 1020u * s1 + 16u * 65025u;
+                    c = 4u * s2 - 4u * (unsigned)o2 * s1 + 16u * (unsigned)(o2 * o2);
                 } else {
-                    for (size_t n = 8 * j; n < nsamples; ++n) c += m_of(iq[2 * n], iq[2 * n + 1]);
+                    for (size_t n = 8 * j; n < nsamples; ++n) c += m_of(iq[2 * n], iq[2 * n + 1], o2);
                 }
             } else {
                 c = cblk[j];
@@ -644,7 +647,7 @@ __global__ __launch_bounds__(kScanThreads) void onset_coarse_kernel(const uint8_
 // as an earlier tile has reported a hit (or the stream ends), so the common case -- onset in the
 // first tile after the candidate -- costs one tile per workgroup.
 __global__ __launch_bounds__(kScanThreads) void onset_scan_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
-                                                                  int window, OnsetScratch* __restrict__ sc) {
+                                                                  int window, OnsetScratch* __restrict__ sc, int o2) {
     __shared__ unsigned pre[kOnsetLds + kOnsetLds / 32 + 2];
     __shared__ unsigned thread_tot[kScanThreads];
     const size_t nout = nsamples - (size_t)window + 1;   // valid positions
@@ -663,7 +666,7 @@ __global__ __launch_bounds__(kScanThreads) void onset_scan_kernel(const uint8_t*
         const uint16_t* iq16 = iq16_all + o0;
         for (int k = tid; k < need; k += kScanThreads) {
             const unsigned w = iq16[k];
-            pre[onset_pad(k + 1)] = m_of(w & 255u, w >> 8);
+            pre[onset_pad(k + 1)] = m_of(w & 255u, w >> 8, o2);
         }
         if (tid == 0) pre[0] = 0;
         __syncthreads();
@@ -735,7 +738,7 @@ __global__ void onset_set_cand_kernel(OnsetScratch* __restrict__ sc, int noise_s
 // One wave.  Besides the index: the two decision margins of gj_onset (exact window sum at the
 // crossing, recomputed here from the capture; largest sum that stayed below, from the scratch).
 __global__ __launch_bounds__(64) void onset_finalize_kernel(const uint8_t* __restrict__ iq, const OnsetScratch* __restrict__ sc,
-                                                            int window, int valid, gj_onset* __restrict__ out) {
+                                                            int window, int valid, gj_onset* __restrict__ out, int o2) {
     const int tid = threadIdx.x;
     if (!valid) {
         if (tid == 0) {
@@ -748,7 +751,7 @@ __global__ __launch_bounds__(64) void onset_finalize_kernel(const uint8_t* __res
     const unsigned long long i0 = ~sc->first_inv;
     unsigned long long S = 0;
     if (found)
-        for (int k = tid; k < window; k += 64) S += m_of(iq[2 * (i0 + k)], iq[2 * (i0 + k) + 1]);
+        for (int k = tid; k < window; k += 64) S += m_of(iq[2 * (i0 + k)], iq[2 * (i0 + k) + 1], o2);
     S = wave_sum_u64(S);
     if (tid == 0) {
         const double thr = (double)sc->thr, scale = 0.25 / (double)window;
@@ -775,7 +778,7 @@ int launch_onset(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, int noise_samp
     GJ_HIP(ctx, hipMemsetAsync(sc, 0, sizeof(OnsetScratch), ctx->stream));
     const int valid = nsamples >= (size_t)noise_samples + (size_t)window;   // triangulateTDOA.py:39
     if (valid) {
-        hipLaunchKernelGGL(onset_noise_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_iq, noise_samples, sc);
+        hipLaunchKernelGGL(onset_noise_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_iq, noise_samples, sc, ctx->off2);
         GJ_LAUNCH_CHECK(ctx);
         const size_t nout = nsamples - window + 1;
         const size_t ntiles = (nout + kOnsetOut - 1) / kOnsetOut;
@@ -783,16 +786,16 @@ int launch_onset(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, int noise_samp
         if ((reinterpret_cast<uintptr_t>(d_iq) & 15) == 0) {
             const size_t nct = ((nout + 7) / 8 + kCoarseBlocks - 1) / kCoarseBlocks;
             hipLaunchKernelGGL(onset_coarse_kernel<8>, dim3((unsigned)nct), dim3(kScanThreads), 0, ctx->stream, d_iq,
-                               (const unsigned*)nullptr, nsamples, window, noise_samples, factor, sc);
+                               (const unsigned*)nullptr, nsamples, window, noise_samples, factor, sc, ctx->off2);
         } else {
             hipLaunchKernelGGL(onset_set_cand_kernel, dim3(1), dim3(1), 0, ctx->stream, sc, noise_samples, factor);
         }
         GJ_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(onset_scan_kernel, dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(kScanThreads), 0,
-                           ctx->stream, d_iq, nsamples, window, sc);
+                           ctx->stream, d_iq, nsamples, window, sc, ctx->off2);
         GJ_LAUNCH_CHECK(ctx);
     }
-    hipLaunchKernelGGL(onset_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, d_iq, sc, window, valid, d_out);
+    hipLaunchKernelGGL(onset_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, d_iq, sc, window, valid, d_out, ctx->off2);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
 }
@@ -832,15 +835,6 @@ __device__ __forceinline__ int msq_of_half(unsigned w, unsigned k2, unsigned km2
     return m;
 }
 
-__device__ __forceinline__ float amp_of_pair(unsigned iq16) {   // iq16 = I | Q << 8
-    // (2I-255, 2Q-255) as packed int16 -> dot with itself = 4|z|^2
-    const unsigned spread = (iq16 & 0xffu) | ((iq16 & 0xff00u) << 8);          // I in bits 0-7, Q in bits 16-23
-    const gj_short2 u = __builtin_bit_cast(gj_short2, spread);
-    const gj_short2 h = u * (short)2 - (short)255;                             // packed 16-bit: no borrow across halves
-    const int m = __builtin_amdgcn_sdot2(h, h, 0, false);
-    return __fsqrt_rn((float)m) * (1.0f / 255.0f);
-}
-
 template <bool TRACK_FIRST>
 __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
                                                                    size_t nbytes, size_t chunk_bytes,
@@ -849,7 +843,7 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
                                                                    unsigned long long* __restrict__ acc, float thr,
                                                                    AmpTile* __restrict__ tiles,
                                                                    unsigned* __restrict__ cblk, size_t noise_bytes,
-                                                                   OnsetScratch* __restrict__ sc) {
+                                                                   OnsetScratch* __restrict__ sc, Unpack up) {
     __shared__ unsigned long long red_m[2][kScanThreads / 64];
     __shared__ double red_s[kScanThreads / 64];
     __shared__ long long red_f[kScanThreads / 64];
@@ -866,7 +860,7 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
     double sum = 0.0;                                              // sum of sqrt(m); scaled by 1/255 once per tile
     long long first = 0x7fffffffffffffffll;
     const bool in_noise = b0 < noise_bytes;                        // tile touches the K4 noise span
-    unsigned k2 = 0x00020002u, km255 = 0xFF01FF01u;
+    unsigned k2 = 0x00020002u, km255 = pk_minus_off2(up.off2);
     asm volatile("" : "+v"(k2), "+v"(km255));                      // keep both in VGPRs (one constant-bus slot per op)
     // `live` is false only for the lanes past the end of a partial last tile (see below): they take
     // part in the wave-wide reductions with zero contributions
@@ -885,7 +879,7 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
             part += r;
             if constexpr (TRACK_FIRST) {
                 const long long idx = (long long)((b0 >> 1) + i * 8 + k);
-                if (live && r * (1.0f / 255.0f) > thr && idx < first) first = idx;   // same expression as K3 alone
+                if (live && r * up.half_scale > thr && idx < first) first = idx;   // same expression as K3 alone
             }
         }
         const unsigned m8 = live ? (unsigned)(((m[0] + m[1]) + (m[2] + m[3])) + ((m[4] + m[5]) + (m[6] + m[7]))) : 0u;
@@ -922,12 +916,12 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
         unsigned c = 0;
         for (size_t n = (b0 >> 1) + nvec * 8; 2 * n < b1; ++n) {
             const unsigned ui = iq[2 * n], uq = iq[2 * n + 1];
-            const unsigned mm = m_of(ui, uq);
+            const unsigned mm = m_of(ui, uq, up.off2);
             S += mm;
             c += mm;
             const float r = __fsqrt_rn((float)mm);
             sum += (double)r;
-            if (TRACK_FIRST && r * (1.0f / 255.0f) > thr && (long long)n < first) first = (long long)n;
+            if (TRACK_FIRST && r * up.half_scale > thr && (long long)n < first) first = (long long)n;
         }
         (void)c;
     }
@@ -939,7 +933,7 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
         if (tid < 64) {
             const size_t jb = (b1 - 1) >> 10;
             int c = 0;
-            for (size_t n = jb * 512 + tid; n < nsamples; n += 64) c += (int)m_of(iq[2 * n], iq[2 * n + 1]);
+            for (size_t n = jb * 512 + tid; n < nsamples; n += 64) c += (int)m_of(iq[2 * n], iq[2 * n + 1], up.off2);
             c = group_sum_dpp<64>(c);
             if (tid == 0) cblk[jb] = (unsigned)c;
         }
@@ -963,7 +957,7 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
     if (tid == 0) {
         const unsigned long long tS = red_m[0][0] + red_m[0][1] + red_m[0][2] + red_m[0][3];
         AmpTile at;
-        at.sum = ((red_s[0] + red_s[1]) + (red_s[2] + red_s[3])) * (1.0 / 255.0);
+        at.sum = ((red_s[0] + red_s[1]) + (red_s[2] + red_s[3])) * (double)up.half_scale;
         long long f = red_f[0];
         for (int k = 1; k < 4; ++k) f = red_f[k] < f ? red_f[k] : f;
         at.first = f;
@@ -1020,37 +1014,37 @@ int launch_stream_scan(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t c
     if (track)
         hipLaunchKernelGGL(stream_scan_kernel<true>, dim3((unsigned)ntiles), dim3(kScanThreads), 0, ctx->stream, d_iq,
                            nsamples, nbytes, chunk_bytes, (unsigned)tpc, eps, flags, d_power, acc, rssi_threshold, tiles,
-                           cblk, noise_fused ? noise_bytes : (size_t)0, sc);
+                           cblk, noise_fused ? noise_bytes : (size_t)0, sc, unpack_of(ctx));
     else
         hipLaunchKernelGGL(stream_scan_kernel<false>, dim3((unsigned)ntiles), dim3(kScanThreads), 0, ctx->stream, d_iq,
                            nsamples, nbytes, chunk_bytes, (unsigned)tpc, eps, flags, d_power, acc, rssi_threshold, tiles,
-                           cblk, noise_fused ? noise_bytes : (size_t)0, sc);
+                           cblk, noise_fused ? noise_bytes : (size_t)0, sc, unpack_of(ctx));
     GJ_LAUNCH_CHECK(ctx);
     if (tpc > 1) {
         hipLaunchKernelGGL(chunk_power_finalize_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0,
-                           ctx->stream, acc, nchunks, nbytes, chunk_bytes, eps, flags, d_power, true);
+                           ctx->stream, acc, nchunks, nbytes, chunk_bytes, eps, flags, d_power, ctx->off2, true);
         GJ_LAUNCH_CHECK(ctx);
     }
     // amplitude totals + the chunk-power edge cases (last chunk odd / without a complete pair)
     hipLaunchKernelGGL(amp_finalize_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_iq, nsamples, tiles, ntiles, d_amp,
-                       d_power, nchunks, nbytes, chunk_bytes, flags);
+                       unpack_of(ctx), d_power, nchunks, nbytes, chunk_bytes, flags);
     GJ_LAUNCH_CHECK(ctx);
     if (valid) {
         if (!noise_fused) {
-            hipLaunchKernelGGL(onset_noise_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_iq, noise_samples, sc);
+            hipLaunchKernelGGL(onset_noise_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_iq, noise_samples, sc, ctx->off2);
             GJ_LAUNCH_CHECK(ctx);
         }
         const size_t nout = nsamples - window + 1;
         const size_t nct = ((nout + 511) / 512 + kCoarseBlocks - 1) / kCoarseBlocks;
         hipLaunchKernelGGL(onset_coarse_kernel<512>, dim3((unsigned)nct), dim3(kScanThreads), 0, ctx->stream, d_iq,
-                           (const unsigned*)cblk, nsamples, window, noise_samples, factor, sc);
+                           (const unsigned*)cblk, nsamples, window, noise_samples, factor, sc, ctx->off2);
         GJ_LAUNCH_CHECK(ctx);
         const size_t nt = (nout + kOnsetOut - 1) / kOnsetOut;
         hipLaunchKernelGGL(onset_scan_kernel, dim3((unsigned)(nt < 256 ? nt : 256)), dim3(kScanThreads), 0, ctx->stream,
-                           d_iq, nsamples, window, sc);
+                           d_iq, nsamples, window, sc, ctx->off2);
         GJ_LAUNCH_CHECK(ctx);
     }
-    hipLaunchKernelGGL(onset_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, d_iq, sc, window, valid, d_onset);
+    hipLaunchKernelGGL(onset_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, d_iq, sc, window, valid, d_onset, ctx->off2);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
 }

@@ -55,6 +55,12 @@
 #ifndef GJ_W_XPOSE
 #define GJ_W_XPOSE 1     // 1: N = 4096 uses the bank-conflict-free exchange schedule (fft_core.h X4096)
 #endif
+#ifndef GJ_W_PRIO
+// s_setprio level of K2's waves (0 = the hardware default).  The SIMD's instruction arbiter serves the
+// higher-priority wave first: K2 is bound by VALU issue, and the waves of the HBM-bound scan that the pipeline
+// runs beside it on the second stream otherwise take issue slots away from it one for one.
+#define GJ_W_PRIO 0
+#endif
 #define GJ_LOAD_RAW(x) (x)
 // GJ_STAMPS (diagnostic builds only, tools/ab_build.sh): s_memtime stamps around the phases of
 // a step, summed per wave and added to g_welch_stamps; read with gj_debug_welch_stamps().
@@ -88,6 +94,8 @@ __device__ unsigned long long g_welch_stamps[8];
 #endif
 
 struct WelchGeom {
+    float neg_off;        // -offset of the unpack convention (default -127.5)
+    float off2;           // 2 * offset
     unsigned long long chunk_samples;
     unsigned nchunks;     // rows kept
     unsigned splits;      // workgroups per chunk
@@ -184,6 +192,7 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
     __shared__ cf lds1[Cfg::dbuf ? SPAN : 1];
     // (sum I, sum Q) per wave; three slots when half-segment sums are carried over (see HS below)
     __shared__ float wsum[3][B][WPF][2];
+    if constexpr (GJ_W_PRIO != 0) __builtin_amdgcn_s_setprio(GJ_W_PRIO);
     const int tid = threadIdx.x;
     const int b = tid / TF, jl0 = tid % TF;   // jl0: butterfly of pass 0 (input index jl0 + TF s)
     const int jl = XP ? X4096::jl1(tid) : jl0;   // butterfly of the later passes = bins held at the end
@@ -214,9 +223,9 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
     for (int s = 0; s < 8; ++s) {
         const float wa = wintab[jl0 + TF * (2 * s)], wb = wintab[jl0 + TF * (2 * s + 1)];
         w2p[s] = make_c2(2.0f * wa, 2.0f * wb);
-        if constexpr (!Cfg::win16) wcp[s] = make_c2(-255.0f * wa, -255.0f * wb);
+        if constexpr (!Cfg::win16) wcp[s] = make_c2(-g.off2 * wa, -g.off2 * wb);
     }
-    [[maybe_unused]] const c2 khalf = make_c2(-127.5f, -127.5f);
+    [[maybe_unused]] const c2 khalf = make_c2(g.neg_off, g.neg_off);
     c2 accp[Cfg::pkacc ? 16 : 1];      // (sum re^2, sum im^2): one packed FMA per bin and step
     float accs[Cfg::pkacc ? 1 : 16];   // or scalar sums (two FMAs per bin and step, 16 VGPRs fewer)
 #pragma unroll
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
                 }
             }
         }
-        const float Sx = fmaf(2.0f, si, -255.0f * N), Sy = fmaf(2.0f, sq, -255.0f * N);   // sum of (2u - 255)
+        const float Sx = fmaf(2.0f, si, -g.off2 * N), Sy = fmaf(2.0f, sq, -g.off2 * N);   // sum of (2u - off2)
         if (jl == WelchBins<N>::jl(0)) {
             v[WelchBins<N>::slot(0)].x -= 0.5f * Sx;
             v[WelchBins<N>::slot(0)].y -= 0.5f * Sy;
@@ -403,6 +412,8 @@ static bool welch_plan(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int npe
     pl.rows = gj_welch_rows(nbytes, chunk_samples, nperseg);
     pl.batch = kBlockPoints / nperseg;
     pl.g.chunk_samples = chunk_samples;
+    pl.g.neg_off = -0.5f * (float)ctx->off2;
+    pl.g.off2 = (float)ctx->off2;
     pl.g.nchunks = (unsigned)pl.rows;
     const size_t step = nperseg / 2;
     pl.g.nseg_full = (unsigned)((chunk_samples - nperseg) / step + 1);
@@ -432,8 +443,9 @@ static bool welch_plan(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int npe
     pl.g.splits = (unsigned)want;
     pl.ws_bytes = pl.rows * want * (size_t)kBlockPoints * sizeof(float);
     const double sw2 = 0.375 * nperseg;   // sum of the squared periodic Hann window
-    pl.scale_full = 1.0 / (fs * sw2 * 65025.0 * (double)pl.g.nseg_full);
-    pl.scale_last = 1.0 / (fs * sw2 * 65025.0 * (double)pl.g.nseg_last);
+    const double norm2 = unpack_norm2(ctx);   // the kernel works on 2u - off2 = sample * (2 / scale): 65025 by default
+    pl.scale_full = 1.0 / (fs * sw2 * norm2 * (double)pl.g.nseg_full);
+    pl.scale_last = 1.0 / (fs * sw2 * norm2 * (double)pl.g.nseg_last);
     return true;
 }
 

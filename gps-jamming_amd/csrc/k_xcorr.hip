@@ -19,6 +19,7 @@ namespace gj {
 constexpr int kRow = 4096;   // L2: contiguous row length
 
 struct XcParams {
+    int off2;   // unpack convention: 2 * offset (255)
     const uint8_t* iq[GJ_MAX_ANTENNAS];
     unsigned long long nsamples[GJ_MAX_ANTENNAS];
     int pair_i[GJ_MAX_ANTENNAS * GJ_MAX_ANTENNAS / 2 + 8];
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(kBlockThreads) void xc_cols_kernel(XcParams P, cons
         for (int s = 0; s < 16; ++s) {
             const unsigned n = (unsigned)(jl + TF * s) * (unsigned)kRow + (unsigned)n2;
             const unsigned u = raw[s];
-            const c2 x = make_c2((float)(2 * (int)(u & 255u) - 255), (float)(2 * (int)(u >> 8) - 255));
+            const c2 x = make_c2((float)(2 * (int)(u & 255u) - P.off2), (float)(2 * (int)(u >> 8) - P.off2));
             v[s] = (n < nlim) ? x : make_c2(0.f, 0.f);
         }
     } else {
@@ -317,6 +318,7 @@ int launch_xcorr(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, 
     if (n_samples > (1ull << 23)) return fail(ctx, GJ_ERR_UNSUPPORTED, "slice longer than 2^23 samples");
     XcParams P;
     memset(&P, 0, sizeof(P));
+    P.off2 = ctx->off2;
     for (int a = 0; a < n_ant; ++a) {
         if (reinterpret_cast<uintptr_t>(d_iq[a]) & 1) return fail(ctx, GJ_ERR_INVALID, "capture must be 2-byte aligned");
         P.iq[a] = d_iq[a];

@@ -282,6 +282,16 @@ class Device:
     def synchronize(self):
         self._check(self._lib.gj_synchronize(self._ctx))
 
+    def set_unpack(self, offset: float = 127.5, scale: float = 1.0 / 127.5):
+        """sample = (u8 - offset) * scale for every later call on this context (gj_set_unpack):
+        (127.5, 1/127.5) is the Python reference's convention, (128, 1/128) gnssdec's."""
+        self._check(self._lib.gj_set_unpack(self._ctx, float(offset), float(scale)))
+
+    def get_unpack(self):
+        o, s = C.c_double(0), C.c_double(0)
+        self._check(self._lib.gj_get_unpack(self._ctx, C.byref(o), C.byref(s)))
+        return o.value, s.value
+
     def reserve(self, nbytes: int):
         self._check(self._lib.gj_reserve(self._ctx, int(nbytes)))
 

@@ -58,6 +58,17 @@ int gj_destroy(gj_ctx* ctx); /* idempotent on NULL */
  * external == 0: back to the context's own non-blocking stream. */
 int gj_set_stream(gj_ctx* ctx, void* hip_stream, int external);
 int gj_synchronize(gj_ctx* ctx);
+/* Unpack convention of the uint8 samples on this context: sample = (u8 - offset) * scale.  The
+ * reference uses three: u - 127.5 (worker.py:222, checkIfJamming.py:15,
+ * triangulateTDOA.py:34), (u - 127.5)/127.5 (triangulateRSSI.py:30, widmo_plot.py:39-40) and
+ * (int8)(u - 128) (GpsJammerApp/backend/sdrrcv.c:104-106).  The default (127.5, 1/127.5)
+ * reproduces the first two: `offset` is honoured by every kernel, `scale` by the kernels whose
+ * reference normalises (K2 Welch, K3 amplitude); K1, K4, K5 work in LSB units like their
+ * references.  offset must be a multiple of 0.5 in [0, 255] (sums stay exact integers).
+ * gj_set_unpack(ctx, 128, 1/128.) gives the gnssdec convention; the acquisition search always
+ * uses 128 as its reference does. */
+int gj_set_unpack(gj_ctx* ctx, double offset, double scale);
+int gj_get_unpack(gj_ctx* ctx, double* offset, double* scale);
 int gj_device_info(gj_ctx* ctx, char* name, size_t name_cap, int* compute_units,
                    uint64_t* hbm_bytes);
 /* Pre-size the internal workspace so that later *_dev calls allocate nothing. */

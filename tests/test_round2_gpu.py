@@ -280,3 +280,71 @@ def test_antenna_stream_over_native_transport(dev):
     b.close()
     torch.cuda.set_stream(torch.cuda.default_stream())
     d.close()
+
+
+# ----------------------------------------------------------------------------- unpack convention
+def test_unpack_convention_offset_128(dev):
+    """gj_set_unpack(128, 1/128): the gnssdec convention (sdrrcv.c:104-106) through K1..K5, against the
+    same numpy / scipy expressions the oracle uses with 127.5 (written out here for 128)."""
+    from scipy import signal
+    n = 700000
+    raw = generate(StreamSpec(seed=91, jam_start=300000, jam_end=1 << 40, jam_sigma=55.0, dc_i_q8=900), n)
+    assert dev.get_unpack() == (127.5, 1.0 / 127.5)
+    ref_default = dev.chunk_power(raw)
+    try:
+        dev.set_unpack(128.0, 1.0 / 128.0)
+        assert dev.get_unpack() == (128.0, 1.0 / 128.0)
+        i8 = raw.astype(np.int32) - 128
+        # K1: exact integer mean of (I-128)^2 + (Q-128)^2 per 64-KiB chunk, rounded once
+        pm = dev.chunk_power(raw, eps=0.0)
+        want = []
+        for o in range(0, raw.size, 65536):
+            p = i8[o:o + 65536]
+            want.append(np.float32(float((p[0::2] ** 2 + p[1::2] ** 2).sum()) / (p.size // 2)))
+        np.testing.assert_array_equal(pm, np.array(want, np.float32))
+        assert not np.array_equal(pm, ref_default)
+        # K3: |x|, x = (u - 128)/128
+        z = (i8[0::2] + 1j * i8[1::2]) / 128.0
+        amp = np.abs(z)
+        for thr in (0.0, 0.25):
+            st = dev.amp_stats(raw, thr)
+            k = int(np.argmax(amp > thr))
+            assert st.first_index == k and st.count == n - k
+            np.testing.assert_allclose(st.mean, amp[k:].mean(), rtol=1e-6)
+        # K4 (LSB units, like its reference): exact integer window sums against the float64 expression
+        zz = i8[0::2].astype(np.float64) + 1j * i8[1::2]
+        pw = np.abs(zz) ** 2
+        thr = np.float32(pw[:200000].mean()) * np.float32(50.0)
+        cs = np.concatenate([[0.0], np.cumsum(pw)])
+        ma = (cs[1000:] - cs[:-1000]) / 1000.0
+        want_on = int(np.argmax(ma > thr)) + 500
+        o = dev.onset(raw)
+        assert o.margin > 1e-6 and o.start_index == want_on
+        # K2: scipy.signal.welch on x = (u - 128)/128 with widmo_plot's chunk rule
+        psd, _ = dev.welch(raw, chunk_samples=300000, nperseg=4096, want_db=False)
+        x = z.astype(np.complex64)
+        for c in range(psd.shape[0]):
+            seg = x[c * 300000:(c + 1) * 300000]
+            seg = seg - np.mean(seg)
+            _, p = signal.welch(seg, 2.048e6, nperseg=4096, return_onesided=False)
+            p = np.fft.fftshift(p)
+            keep = p > 1e-12
+            assert np.max(np.abs(psd[c][keep] - p[keep]) / p[keep]) < 1e-4
+        # K5: a constant offset does not move the lag of a clean peak
+        sl = [raw[2 * want_on:2 * (want_on + 32768)], raw[2 * (want_on - 7):2 * (want_on - 7 + 32768)]]
+        lags, _ = dev.xcorr_lags(sl, [(0, 1)])
+        assert lags.tolist() == [7]
+        # the fused pass follows the same convention
+        buf = dev.alloc(raw.size).upload(raw)
+        d_pow, d_amp, d_on = dev.alloc(4 * dev.chunk_count(raw.size, 65536)), dev.alloc(32), dev.alloc(32)
+        dev.stream_scan_dev(buf, raw.size, 65536, d_pow, 0.0, d_amp, 200000, 1000, 50.0, d_on, eps=0.0)
+        dev.synchronize()
+        np.testing.assert_array_equal(d_pow.download(np.float32), pm)
+        a = _ffi.AmpStats.from_buffer_copy(d_amp.download(np.uint8, 32).tobytes())
+        np.testing.assert_allclose(a.mean, amp.mean(), rtol=1e-6)
+        assert int(d_on.download(np.int64, 1)[0]) == want_on
+        with pytest.raises(gpsjam.GpsJamError):
+            dev.set_unpack(127.3, 1.0)                        # not a multiple of 0.5
+    finally:
+        dev.set_unpack()                                      # back to the reference's convention
+    np.testing.assert_array_equal(dev.chunk_power(raw), ref_default)

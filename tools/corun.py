@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """How much does a kernel running beside K2 stretch it?  Two gpsjam contexts on two torch
 streams over the same capture: K2 x reps on one, `--side` kernel back-to-back on the other.
-    python tools/corun.py --side fscan|k1|k3|k4|none [--reps 20]"""
+    python tools/corun.py --side fscan|k1|k3|k4|copy|fill|none [--reps 20]
+copy / fill: a device-to-device copy / a fill of 1 GiB (torch, next to no VALU work) -- tells HBM traffic apart
+from VALU issue as the cause of the stretch."""
 import argparse
 import os
 import sys
@@ -35,10 +37,19 @@ def main():
     psd = torch.empty((rows, 4096), dtype=torch.float32, device="cuda")
     pw = torch.empty(nch, dtype=torch.float32, device="cuda")
     amp = torch.zeros(4, dtype=torch.int64, device="cuda")
-    on = torch.zeros(2, dtype=torch.int64, device="cuda")
+    on = torch.zeros(4, dtype=torch.int64, device="cuda")
+    dst = torch.empty(nbytes, dtype=torch.uint8, device="cuda") if args.side in ("copy", "fill") else None
     torch.cuda.synchronize()
 
     def side():
+        if args.side == "copy":
+            with torch.cuda.stream(s2):
+                dst.copy_(cap)
+            return
+        if args.side == "fill":
+            with torch.cuda.stream(s2):
+                dst.fill_(7)
+            return
         if args.side == "fscan":
             b.stream_scan_dev(cap, nbytes, 65536, pw, 0.0, amp, 200000, 1000, 50.0, on)
         elif args.side == "k1":
