@@ -9,9 +9,10 @@ One "step" = one pass of the hot path over one synthetic antenna capture per GPU
 (BASELINE.json configs[1]; one stream per rank = configs[4] for N > 1):
   one fused HBM pass for K1 per-chunk power (+ 5th-percentile/+6 dB threshold), K3 amplitude
   statistics and K4 onset; K2 fused unpack + 4096-pt Welch PSD (1-s chunks); the rank's
-  onset-aligned 2^19-sample slice cut into a TDOA slot; the slots gathered to rank 0 (RCCL),
-  which solves EVERY antenna pair with one multi-pair K5 launch (2^20-pt FFT
-  cross-correlations); a second RCCL gather of the per-stream result vectors to rank 0.
+  onset-aligned 2^19-sample slice cut into a TDOA slot; ONE RCCL all-gather of the slots; EVERY
+  antenna pair solved (2^20-pt FFT cross-correlations), the pairs dealt over the ranks so that
+  each rank runs one multi-pair K5 launch of constant size; an RCCL gather of the per-stream
+  result vectors (with the solved pairs inside) to rank 0.
   At N = 1 the K5 solve is BASELINE configs[3]: this capture's slot against the slots of two
   further antennas (prepared before the timed region, as if gathered) = 3 antennas, 3 pairs.
   K2 (VALU/LDS bound) runs on one HIP stream, the HBM-bound scan, the gathers and K5
@@ -159,7 +160,7 @@ def main():
         ev[k][0].record()
         stream.welch()                  # K2
         ev[k][1].record()
-        stream.tdoa()                   # slot, slot gather, all-pairs K5 on rank 0 (second stream)
+        stream.tdoa()                   # slot, slot all-gather, this rank's share of the pairs (second stream)
         gathered = stream.exchange(0)   # pack (after the join) + result gather, issued on the second stream
     torch.cuda.synchronize()
     barrier()
@@ -184,8 +185,8 @@ def main():
     solo_ms = timed(stream.welch, work_stream)
     scan_ms = timed(stream.stream_scan, side)
     k5_ms = None
-    if stream.is_root and stream.pairs:
-        scratch = [torch.empty_like(t) for t in (stream._lags[0], stream._peaks[0], stream._margins[0])]
+    if rank == 0 and stream.pairs:
+        scratch = [torch.empty_like(t) for t in (stream.lags, stream.peaks, stream.margins)]
 
         def k5():                       # the same launch as in the step, into scratch outputs
             stream.dev_side.xcorr_slots_dev(stream.slots, stream.slot_bytes, stream.n_ant, SLICE, stream.pairs, *scratch)
@@ -237,8 +238,8 @@ def main():
             "config": {"workload": "configs[1]: fused uint8->complex64 + 4096-pt Welch PSD + jamming power "
                                    "threshold on 1 GiB synthetic I/Q per GPU (+ K3 amp stats, K4 onset, TDOA slot; "
                                    + ("configs[3]: 3 antennas / 3 pairs 2^20-pt xcorr solve on this GPU)" if world == 1
-                                      else f"configs[4]: slots gathered over RCCL, all {len(tdoa.pairs)} pairs of "
-                                           f"{world} antennas solved on rank 0, result vectors gathered)"),
+                                      else f"configs[4]: slots all-gathered over RCCL, all {len(tdoa.pairs)} pairs of "
+                                           f"{world} antennas solved, dealt over the ranks; result vectors gathered to rank 0)"),
                        "capture_bytes_per_gpu": nbytes, "nperseg": NPERSEG, "chunk_samples": CHUNK_SAMPLES,
                        "xcorr_slice": SLICE, "xcorr_antennas": stream.n_ant, "xcorr_pairs": len(tdoa.pairs),
                        "streams": world, "sharding": "one capture per GPU", "backend": args.backend if world > 1 else None,
@@ -272,9 +273,10 @@ def main():
         }
         if k5_ms is not None:
             # ingest 2N B per antenna + 32 L B per transform (four-step floor), A + P transforms
-            L, A, P = 2 * SLICE, stream.n_ant, len(tdoa.pairs)
+            L, P = 2 * SLICE, len(stream.pairs)
+            A = len({a for p in stream.pairs for a in p})
             k5_bytes = 2 * SLICE * A + 32 * L * (A + P)
-            line["secondary"][f"K5 xcorr solve, {A} antennas / {P} pairs, L = 2^20, solo"] = {
+            line["secondary"][f"K5 xcorr solve on rank 0, {A} antennas / {P} pairs, L = 2^20, solo"] = {
                 "bound": "hbm", "algorithmic_bytes_per_launch": k5_bytes, "avg_launch_ms": k5_ms,
                 "achieved": (k5_bytes / 1e9) / (k5_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (k5_bytes / 1e9) / (k5_ms / 1e3) / HBM_PEAK_GBS,
@@ -343,7 +345,7 @@ def host_info():
 def source_hash():
     """sha256 over the K2 sources: ties a committed PMC summary to the kernel it was measured on."""
     h = hashlib.sha256()
-    for name in ("k_welch.hip", "fft_core.h", "gj_common.h"):
+    for name in ("k_welch.hip", "fft_core.h"):
         with open(os.path.join(REPO, "gps-jamming_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

@@ -329,7 +329,10 @@ int gj_xcorr_lags_dev(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nby
                       float* d_margins) {
     GJ_ENTER(ctx);
     if (!d_iq || !nbytes || !d_starts || !pairs || !d_lags || !d_peaks) return fail(ctx, GJ_ERR_INVALID, "null buffer");
-    return launch_xcorr(ctx, d_iq, nbytes, n_ant, d_starts, 1, n_samples, pairs, n_pairs, d_lags, d_peaks, d_margins);
+    if (n_ant < 1 || n_ant > GJ_MAX_ANTENNAS) return fail(ctx, GJ_ERR_INVALID, "n_ant must be 1..%d", GJ_MAX_ANTENNAS);
+    const int64_t* sp[GJ_MAX_ANTENNAS];
+    for (int a = 0; a < n_ant; ++a) sp[a] = d_starts + a;
+    return launch_xcorr(ctx, d_iq, nbytes, n_ant, sp, n_samples, pairs, n_pairs, d_lags, d_peaks, d_margins);
 }
 
 size_t gj_tdoa_slot_bytes(size_t n_samples) { return align_up(GJ_SLOT_HEADER + 2 * n_samples, 256); }
@@ -345,29 +348,46 @@ int gj_xcorr_slots_dev(gj_ctx* ctx, const uint8_t* d_slots, size_t slot_stride, 
                        const int32_t* pairs, int n_pairs, int32_t* d_lags, float* d_peaks, float* d_margins) {
     GJ_ENTER(ctx);
     if (!d_slots || !pairs || !d_lags || !d_peaks) return fail(ctx, GJ_ERR_INVALID, "null buffer");
-    if (n_ant < 1 || n_ant > GJ_MAX_ANTENNAS) return fail(ctx, GJ_ERR_INVALID, "n_ant must be 1..%d", GJ_MAX_ANTENNAS);
+    if (n_ant < 1 || n_ant > 4096) return fail(ctx, GJ_ERR_INVALID, "n_ant must be 1..4096 slots");
+    if (n_pairs < 1) return fail(ctx, GJ_ERR_INVALID, "n_pairs must be >= 1");
     if (slot_stride < GJ_SLOT_HEADER + 2 * n_samples || (slot_stride & 15) || (reinterpret_cast<uintptr_t>(d_slots) & 15))
         return fail(ctx, GJ_ERR_INVALID, "slot stride %zu too small for %zu samples or not 16-byte aligned", slot_stride,
                     n_samples);
+    // only the slots the pairs name are transformed: the pairs of one call may touch at most GJ_MAX_ANTENNAS of them
+    int local_of[4096];
+    for (int a = 0; a < n_ant; ++a) local_of[a] = -1;
     const uint8_t* ptrs[GJ_MAX_ANTENNAS];
+    const int64_t* starts[GJ_MAX_ANTENNAS];
     size_t sizes[GJ_MAX_ANTENNAS];
-    for (int a = 0; a < n_ant; ++a) {
-        ptrs[a] = d_slots + (size_t)a * slot_stride + GJ_SLOT_HEADER;
-        sizes[a] = 2 * n_samples;
+    std::vector<int32_t> local_pairs((size_t)2 * n_pairs);
+    int used = 0;
+    for (int k = 0; k < 2 * n_pairs; ++k) {
+        const int a = pairs[k];
+        if (a < 0 || a >= n_ant) return fail(ctx, GJ_ERR_INVALID, "pair %d names slot %d of %d", k / 2, a, n_ant);
+        if (local_of[a] < 0) {
+            if (used == GJ_MAX_ANTENNAS) return fail(ctx, GJ_ERR_UNSUPPORTED, "the pairs of one call touch more than %d slots", GJ_MAX_ANTENNAS);
+            const uint8_t* slot = d_slots + (size_t)a * slot_stride;
+            ptrs[used] = slot + GJ_SLOT_HEADER;
+            starts[used] = reinterpret_cast<const int64_t*>(slot);   // the flag word: 0 valid / -1 invalid
+            sizes[used] = 2 * n_samples;
+            local_of[a] = used++;
+        }
+        local_pairs[k] = local_of[a];
     }
-    // start words = the slots' flag words (0 valid / -1 invalid), slot_stride bytes apart
-    return launch_xcorr(ctx, ptrs, sizes, n_ant, reinterpret_cast<const int64_t*>(d_slots), slot_stride / 8, n_samples,
-                        pairs, n_pairs, d_lags, d_peaks, d_margins);
+    return launch_xcorr(ctx, ptrs, sizes, used, starts, n_samples, local_pairs.data(), n_pairs, d_lags, d_peaks, d_margins);
 }
 
 int gj_pack_result_dev(gj_ctx* ctx, size_t n_chunks, const float* d_power, const float* d_stats, const gj_amp_stats* d_amp,
-                       const gj_onset* d_onset, const int32_t* d_lag, const float* d_peak, const float* d_psd,
-                       size_t rows, int nperseg, int rank, double* d_out) {
+                       const gj_onset* d_onset, const float* d_psd, size_t rows, int nperseg, int rank, int n_pairs,
+                       int pair_capacity, const int32_t* d_pairs, const int32_t* d_lags, const float* d_peaks,
+                       const float* d_margins, double* d_out) {
     GJ_ENTER(ctx);
-    if (!d_power || !d_stats || !d_amp || !d_onset || !d_lag || !d_peak || !d_out || (rows && !d_psd))
+    if (!d_power || !d_stats || !d_amp || !d_onset || !d_out || (rows && !d_psd))
         return fail(ctx, GJ_ERR_INVALID, "null buffer");
-    return launch_pack_result(ctx, n_chunks, d_power, d_stats, d_amp, d_onset, d_lag, d_peak, d_psd, rows, nperseg, rank,
-                              d_out);
+    if (n_pairs < 0 || n_pairs > pair_capacity) return fail(ctx, GJ_ERR_INVALID, "n_pairs %d exceeds the capacity %d", n_pairs, pair_capacity);
+    if (n_pairs && (!d_pairs || !d_lags || !d_peaks || !d_margins)) return fail(ctx, GJ_ERR_INVALID, "null pair buffer");
+    return launch_pack_result(ctx, n_chunks, d_power, d_stats, d_amp, d_onset, d_psd, rows, nperseg, rank, n_pairs,
+                              pair_capacity, d_pairs, d_lags, d_peaks, d_margins, d_out);
 }
 
 int gj_acq_search_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t first_sample, int nsamp, int intg,
@@ -641,8 +661,10 @@ int gj_xcorr_lags_u8(gj_ctx* ctx, const uint8_t* const* slices, int n_ant, size_
     float* d_peaks = reinterpret_cast<float*>(sc + 128 + 4 * (size_t)n_pairs);
     float* d_margins = reinterpret_cast<float*>(sc + 128 + 8 * (size_t)n_pairs);
     GJ_HIP(ctx, hipMemsetAsync(d_starts, 0, 128, ctx->stream));
+    const int64_t* sp[GJ_MAX_ANTENNAS];
+    for (int a = 0; a < n_ant; ++a) sp[a] = d_starts + a;
     GJ_TIMED(ctx, kernel_ms,
-             launch_xcorr(ctx, d_ptrs, nbytes, n_ant, d_starts, 1, n_samples, pairs, n_pairs, d_lags, d_peaks, d_margins));
+             launch_xcorr(ctx, d_ptrs, nbytes, n_ant, sp, n_samples, pairs, n_pairs, d_lags, d_peaks, d_margins));
     GJ_HIP(ctx, hipMemcpyAsync(peaks, d_peaks, 4 * (size_t)n_pairs, hipMemcpyDeviceToHost, ctx->stream));
     if (margins) GJ_HIP(ctx, hipMemcpyAsync(margins, d_margins, 4 * (size_t)n_pairs, hipMemcpyDeviceToHost, ctx->stream));
     return fetch(ctx, lags, d_lags, 4 * (size_t)n_pairs);

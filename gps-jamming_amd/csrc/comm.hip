@@ -27,6 +27,7 @@ struct Rccl {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclGather) Gather = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     char why[256] = {0};
 };
@@ -55,6 +56,7 @@ static Rccl* rccl() {
         GJ_SYM(CommDestroy, "ncclCommDestroy");
         GJ_SYM(Gather, "ncclGather");   // RCCL extension (rccl.h:745)
         GJ_SYM(Broadcast, "ncclBroadcast");
+        GJ_SYM(AllGather, "ncclAllGather");
         GJ_SYM(GetErrorString, "ncclGetErrorString");
 #undef GJ_SYM
     });
@@ -121,6 +123,16 @@ int gj_comm_gather_dev(gj_comm* c, const void* d_send, size_t bytes, void* d_rec
     if (!d_send || (c->rank == root && !d_recv)) return fail(ctx, GJ_ERR_INVALID, "null buffer");
     const ncclResult_t rc = rccl()->Gather(d_send, d_recv, bytes, ncclUint8, root, c->comm, ctx->stream);
     if (rc != ncclSuccess) return rccl_fail(ctx, "ncclGather", rc);
+    return GJ_OK;
+}
+
+int gj_comm_allgather_dev(gj_comm* c, const void* d_send, size_t bytes, void* d_recv) {
+    if (!c) return GJ_ERR_INVALID;
+    gj_ctx* ctx = c->ctx;
+    Guard g(ctx);
+    if (!d_send || !d_recv) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    const ncclResult_t rc = rccl()->AllGather(d_send, d_recv, bytes, ncclUint8, c->comm, ctx->stream);
+    if (rc != ncclSuccess) return rccl_fail(ctx, "ncclAllGather", rc);
     return GJ_OK;
 }
 

@@ -153,7 +153,7 @@ int launch_stream_scan(gj_ctx*, const uint8_t*, size_t, size_t, float, int, floa
 int launch_histogram(gj_ctx*, const uint8_t*, size_t, size_t, int, int, unsigned long long*);
 int launch_welch(gj_ctx*, const uint8_t*, size_t, size_t, int, double, int, float*, float*);
 size_t welch_workspace(gj_ctx*, size_t, size_t, int);
-int launch_xcorr(gj_ctx*, const uint8_t* const*, const size_t*, int, const int64_t*, size_t, size_t,
+int launch_xcorr(gj_ctx*, const uint8_t* const*, const size_t*, int, const int64_t* const*, size_t,
                  const int32_t*, int, int32_t*, float*, float*);
 int launch_tdoa_slot(gj_ctx*, const uint8_t*, size_t, const int64_t*, size_t, uint8_t*);
 int launch_acq_search(gj_ctx*, const uint8_t*, size_t, size_t, int, int, const int16_t*, int, const uint8_t*, int, int, double,
@@ -161,6 +161,6 @@ int launch_acq_search(gj_ctx*, const uint8_t*, size_t, size_t, int, int, const i
 size_t acq_workspace(int, int, int, int, bool);
 size_t xcorr_workspace(gj_ctx*, int, size_t, int);
 int launch_synth(gj_ctx*, const gj_synth_params&, int64_t, size_t, uint8_t*);
-int launch_pack_result(gj_ctx*, size_t, const float*, const float*, const gj_amp_stats*, const gj_onset*, const int32_t*,
-                       const float*, const float*, size_t, int, int, double*);
+int launch_pack_result(gj_ctx*, size_t, const float*, const float*, const gj_amp_stats*, const gj_onset*, const float*, size_t,
+                       int, int, int, int, const int32_t*, const int32_t*, const float*, const float*, double*);
 }   // namespace gj

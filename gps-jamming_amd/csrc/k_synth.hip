@@ -66,13 +66,15 @@ __global__ __launch_bounds__(256) void synth_kernel(gj_synth_params p, long long
 // result vector of one stream (see gj_pack_result_dev in gpsjam.h)
 // ---------------------------------------------------------------------------------------
 // block = 64 bins x 16 row lanes; blocks [0, nperseg/64) reduce the waterfall to its mean
-// spectrum, the following blocks copy the header and the power map
+// spectrum, the following blocks copy the header, the power map and the pair block
 __global__ __launch_bounds__(1024) void pack_result_kernel(size_t n_chunks, const float* __restrict__ power,
                                                            const float* __restrict__ stats,
                                                            const gj_amp_stats* __restrict__ amp,
-                                                           const gj_onset* __restrict__ onset, const int* __restrict__ lag,
-                                                           const float* __restrict__ peak, const float* __restrict__ psd,
-                                                           size_t rows, int nperseg, int rank, double* __restrict__ out) {
+                                                           const gj_onset* __restrict__ onset, const float* __restrict__ psd,
+                                                           size_t rows, int nperseg, int rank, int n_pairs, int pair_cap,
+                                                           const int* __restrict__ pairs, const int* __restrict__ lags,
+                                                           const float* __restrict__ peaks, const float* __restrict__ margins,
+                                                           double* __restrict__ out) {
     __shared__ float part[16][64];
     const unsigned spec_blocks = (unsigned)((nperseg + 63) / 64);
     if (blockIdx.x < spec_blocks) {
@@ -91,10 +93,13 @@ __global__ __launch_bounds__(1024) void pack_result_kernel(size_t n_chunks, cons
         }
         return;
     }
-    const size_t total = GJ_RESULT_HEADER + n_chunks;
+    const size_t head = GJ_RESULT_HEADER + n_chunks;
+    const size_t pair0 = head + (size_t)nperseg;
+    const size_t total = head + (size_t)GJ_RESULT_PAIR_FIELDS * pair_cap;
     for (size_t i = (blockIdx.x - spec_blocks) * (size_t)blockDim.x + threadIdx.x; i < total;
          i += (size_t)(gridDim.x - spec_blocks) * blockDim.x) {
         double v = 0.0;
+        size_t dst = i;
         if (i < GJ_RESULT_HEADER) {
             switch (i) {
                 case 0: v = (double)n_chunks; break;
@@ -105,29 +110,46 @@ __global__ __launch_bounds__(1024) void pack_result_kernel(size_t n_chunks, cons
                 case 5: v = (double)amp->count; break;
                 case 6: v = amp->mean; break;
                 case 7: v = (double)onset->start_index; break;
-                case 8: v = (double)lag[0]; break;
-                case 9: v = peak[0]; break;
+                case 8: v = rank == 0 ? 0.0 : (double)GJ_LAG_INVALID; break;   // lag against antenna 0: filled in by the solver's owner
+                case 9: v = 0.0; break;
                 case 10: v = onset->noise_power; break;
                 case 11: v = (double)rows; break;
                 case 12: v = (double)nperseg; break;
                 case 13: v = (double)rank; break;
+                case 14: v = (double)n_pairs; break;
+                case 15: v = (double)pair_cap; break;
                 default: v = 0.0;
             }
-        } else {
+        } else if (i < head) {
             v = power[i - GJ_RESULT_HEADER];
+        } else {   // pair block: {i, j, lag, peak, margin} per pair this stream solved, zero-padded to the capacity
+            const size_t q = i - head;
+            const int pr = (int)(q / GJ_RESULT_PAIR_FIELDS), fld = (int)(q % GJ_RESULT_PAIR_FIELDS);
+            dst = pair0 + q;
+            if (pr < n_pairs) {
+                switch (fld) {
+                    case 0: v = (double)pairs[2 * pr]; break;
+                    case 1: v = (double)pairs[2 * pr + 1]; break;
+                    case 2: v = (double)lags[pr]; break;
+                    case 3: v = peaks[pr]; break;
+                    default: v = margins[pr];
+                }
+            }
         }
-        out[i] = v;
+        out[dst] = v;
     }
 }
 
 int launch_pack_result(gj_ctx* ctx, size_t n_chunks, const float* d_power, const float* d_stats, const gj_amp_stats* d_amp,
-                       const gj_onset* d_onset, const int32_t* d_lag, const float* d_peak, const float* d_psd,
-                       size_t rows, int nperseg, int rank, double* d_out) {
+                       const gj_onset* d_onset, const float* d_psd, size_t rows, int nperseg, int rank, int n_pairs,
+                       int pair_cap, const int32_t* d_pairs, const int32_t* d_lags, const float* d_peaks,
+                       const float* d_margins, double* d_out) {
     const unsigned spec_blocks = (unsigned)((nperseg + 63) / 64);
-    size_t copy_blocks = (GJ_RESULT_HEADER + n_chunks + 1023) / 1024;
+    size_t copy_blocks = (GJ_RESULT_HEADER + n_chunks + (size_t)GJ_RESULT_PAIR_FIELDS * pair_cap + 1023) / 1024;
     if (copy_blocks > 256) copy_blocks = 256;
     hipLaunchKernelGGL(pack_result_kernel, dim3(spec_blocks + (unsigned)copy_blocks), dim3(1024), 0, ctx->stream, n_chunks,
-                       d_power, d_stats, d_amp, d_onset, d_lag, d_peak, d_psd, rows, nperseg, rank, d_out);
+                       d_power, d_stats, d_amp, d_onset, d_psd, rows, nperseg, rank, n_pairs, pair_cap, d_pairs, d_lags,
+                       d_peaks, d_margins, d_out);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
 }

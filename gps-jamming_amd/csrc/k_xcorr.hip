@@ -21,6 +21,7 @@ constexpr int kRow = 4096;   // L2: contiguous row length
 struct XcParams {
     int off2;   // unpack convention: 2 * offset (255)
     const uint8_t* iq[GJ_MAX_ANTENNAS];
+    const long long* start_ptr[GJ_MAX_ANTENNAS];   // where antenna a's start sample (or slot flag word) lives
     unsigned long long nsamples[GJ_MAX_ANTENNAS];
     int pair_i[GJ_MAX_ANTENNAS * GJ_MAX_ANTENNAS / 2 + 8];
     int pair_j[GJ_MAX_ANTENNAS * GJ_MAX_ANTENNAS / 2 + 8];
@@ -69,12 +70,11 @@ __device__ __forceinline__ void xc_passes(c2 (&v)[16], cf* lds, int base, int jl
     }
 }
 
-// starts[a * stride]: contiguous array (stride 1) or the header words of TDOA slots
-__global__ void xc_prepare_kernel(XcParams P, const long long* __restrict__ starts, size_t stride,
-                                  long long* __restrict__ eff, int* __restrict__ valid) {
+// start word of antenna a: an element of the caller's start array, or the flag word of a TDOA slot
+__global__ void xc_prepare_kernel(XcParams P, long long* __restrict__ eff, int* __restrict__ valid) {
     const int a = threadIdx.x;
     if (a >= P.n_ant) return;
-    const long long s = starts[(size_t)a * stride];
+    const long long s = *P.start_ptr[a];
     const bool ok = s >= 0 && (unsigned long long)s + P.n <= P.nsamples[a];
     valid[a] = ok;
     eff[a] = ok ? s : 0;
@@ -309,8 +309,8 @@ static void xc_cols(gj_ctx* ctx, int mode, const XcParams& P, int count, const l
     }
 }
 
-int launch_xcorr(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, int n_ant, const int64_t* d_starts,
-                 size_t starts_stride, size_t n_samples, const int32_t* pairs, int n_pairs, int32_t* d_lags,
+int launch_xcorr(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, int n_ant,
+                 const int64_t* const* start_ptrs, size_t n_samples, const int32_t* pairs, int n_pairs, int32_t* d_lags,
                  float* d_peaks, float* d_margins) {
     if (n_ant < 1 || n_ant > GJ_MAX_ANTENNAS) return fail(ctx, GJ_ERR_INVALID, "n_ant must be 1..%d", GJ_MAX_ANTENNAS);
     if (n_pairs < 1 || n_pairs > kMaxPairs) return fail(ctx, GJ_ERR_INVALID, "n_pairs must be 1..%d", kMaxPairs);
@@ -323,6 +323,7 @@ int launch_xcorr(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, 
         if (reinterpret_cast<uintptr_t>(d_iq[a]) & 1) return fail(ctx, GJ_ERR_INVALID, "capture must be 2-byte aligned");
         P.iq[a] = d_iq[a];
         P.nsamples[a] = nbytes[a] / 2;
+        P.start_ptr[a] = reinterpret_cast<const long long*>(start_ptrs[a]);
     }
     for (int p = 0; p < n_pairs; ++p) {
         const int i = pairs[2 * p], j = pairs[2 * p + 1];
@@ -345,8 +346,7 @@ int launch_xcorr(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, 
     long long* eff = reinterpret_cast<long long*>(cand + (size_t)n_pairs * ncand);
     int* valid = reinterpret_cast<int*>(eff + GJ_MAX_ANTENNAS);
 
-    hipLaunchKernelGGL(xc_prepare_kernel, dim3(1), dim3(64), 0, ctx->stream, P, (const long long*)d_starts, starts_stride,
-                       eff, valid);
+    hipLaunchKernelGGL(xc_prepare_kernel, dim3(1), dim3(64), 0, ctx->stream, P, eff, valid);
     GJ_LAUNCH_CHECK(ctx);
     xc_cols(ctx, 0, P, n_ant, eff, valid, spec, nullptr);
     GJ_LAUNCH_CHECK(ctx);

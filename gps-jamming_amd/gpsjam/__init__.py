@@ -509,11 +509,12 @@ class Device:
             flat.ctypes.data_as(C.POINTER(C.c_int32)), flat.size // 2, _ptr(d_lags), _ptr(d_peaks),
             _ptr(d_margins) or None))
 
-    def pack_result_dev(self, n_chunks, d_power, d_stats, d_amp, d_onset, d_lag, d_peak, d_psd, rows, nperseg, rank,
-                        d_out):
+    def pack_result_dev(self, n_chunks, d_power, d_stats, d_amp, d_onset, d_psd, rows, nperseg, rank, n_pairs,
+                        pair_capacity, d_pairs, d_lags, d_peaks, d_margins, d_out):
         self._check(self._lib.gj_pack_result_dev(self._ctx, n_chunks, _ptr(d_power), _ptr(d_stats), _ptr(d_amp),
-                                                 _ptr(d_onset), _ptr(d_lag), _ptr(d_peak), _ptr(d_psd), rows, nperseg,
-                                                 rank, _ptr(d_out)))
+                                                 _ptr(d_onset), _ptr(d_psd), rows, nperseg, rank, n_pairs, pair_capacity,
+                                                 _ptr(d_pairs) or None, _ptr(d_lags) or None, _ptr(d_peaks) or None,
+                                                 _ptr(d_margins) or None, _ptr(d_out)))
 
     def synth_dev(self, spec, n_samples: int, d_out, first_sample: int = 0):
         """Fill d_out[2*n_samples] with the capture described by a synth.StreamSpec."""

@@ -107,10 +107,11 @@ SIGNATURES = {
     "gj_comm_init_rank": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
     "gj_comm_rank": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "gj_comm_gather_dev": (_i, [_vp, _vp, _sz, _vp, _i]),
+    "gj_comm_allgather_dev": (_i, [_vp, _vp, _sz, _vp]),
     "gj_comm_bcast_dev": (_i, [_vp, _vp, _sz, _i]),
     "gj_comm_destroy": (_i, [_vp]),
     "gj_xcorr_workspace": (_sz, [_vp, _i, _sz, _i]),
-    "gj_pack_result_dev": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp]),
+    "gj_pack_result_dev": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "gj_synth_u8_dev": (_i, [_vp, C.POINTER(SynthParams), C.c_int64, _sz, _vp]),
 }
 

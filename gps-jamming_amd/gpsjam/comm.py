@@ -80,6 +80,10 @@ class Communicator:
         """Every rank sends nbytes; ``root`` receives world * nbytes in rank order."""
         self.dev._check(self.dev._lib.gj_comm_gather_dev(self._h, _ptr(d_send), int(nbytes), _ptr(d_recv) or None, root))
 
+    def allgather(self, d_send, nbytes: int, d_recv):
+        """Every rank sends nbytes and receives world * nbytes in rank order."""
+        self.dev._check(self.dev._lib.gj_comm_allgather_dev(self._h, _ptr(d_send), int(nbytes), _ptr(d_recv)))
+
     def bcast(self, d_buf, nbytes: int, root: int = 0):
         self.dev._check(self.dev._lib.gj_comm_bcast_dev(self._h, _ptr(d_buf), int(nbytes), root))
 

@@ -5,18 +5,21 @@ The per-capture kernels (K1 power scan, K2 Welch PSD, K3 amplitude statistics, K
 independent across captures, so captures are sharded one per rank with no data-path
 collective.  The one real exchange of the path is TDOA (skrypty/triangulateTDOA.py:60-90
 generalised from two antennas to N): every rank cuts its onset-aligned slice into a *TDOA
-slot* (16-byte validity header + 2 bytes per sample: 1 MiB for 2^19 samples), ONE gather
-brings the slots to rank 0, and rank 0 solves EVERY antenna pair (i, j), i < j, with one
-multi-pair K5 launch (N forward + N(N-1)/2 inverse 2^20-point transforms, L2 / Infinity-Cache
-resident).  A second gather brings each rank's fixed-layout result vector (power map, noise
-floor, threshold, amplitude statistics, onset, mean spectrum) to rank 0, which runs the
+slot* (16-byte validity header + 2 bytes per sample: 1 MiB for 2^19 samples) and ONE all-gather
+puts all N slots on every rank.  EVERY antenna pair (i, j) is solved, and the N(N-1)/2 pairs are
+dealt over the ranks so that the per-rank work stays constant as N grows: rank r solves
+(r, r+d mod N) for d = 1 .. N/2 (``pairs_of_rank``: 3 pairs on one rank for N = 1 + 2 auxiliary
+slots = BASELINE configs[3]; 3-4 pairs per rank over 5 antennas for N = 8) with one multi-pair K5
+launch that transforms only the slots its pairs name.  One gather then brings each rank's
+fixed-layout result vector -- power map, noise floor, threshold, amplitude statistics, onset, mean
+spectrum and the {i, j, lag, peak, margin} of the pairs it solved -- to rank 0, which runs the
 host-side solvers (grid search / bearing).  An un-found onset or a slice that runs off the end
 of a capture marks that slot invalid and every pair with that antenna comes back as
 GJ_LAG_INVALID (the reference aborts there, triangulateTDOA.py:67-77).
 
-``pack_results`` / ``unpack_results`` / ``make_slot`` / ``gather_rows`` only touch torch tensors
-and torch.distributed, so they run unchanged on CPU tensors with the gloo backend (tests) and on
-HIP tensors with the nccl (= RCCL) backend (bench.py).
+``pack_results`` / ``unpack_results`` / ``make_slot`` / ``gather_rows`` / ``allgather_rows`` only
+touch torch tensors and torch.distributed, so they run unchanged on CPU tensors with the gloo
+backend (tests) and on HIP tensors with the nccl (= RCCL) backend (bench.py).
 """
 from __future__ import annotations
 
@@ -35,8 +38,11 @@ SLOT_HEADER = 16     # GJ_SLOT_HEADER: int64 flag (0 valid / -1 invalid), int64 
 LAG_INVALID = -(1 << 31)
 
 
-def result_len(n_chunks: int, nperseg: int) -> int:
-    return HEADER + n_chunks + nperseg
+PAIR_FIELDS = 5      # GJ_RESULT_PAIR_FIELDS: i, j, lag, peak, margin
+
+
+def result_len(n_chunks: int, nperseg: int, pair_capacity: int = 0) -> int:
+    return HEADER + n_chunks + nperseg + PAIR_FIELDS * pair_capacity
 
 
 def slot_bytes(n_samples: int) -> int:
@@ -50,13 +56,40 @@ def all_pairs(n_ant: int) -> List[Tuple[int, int]]:
     return [(i, j) for i in range(n_ant) for j in range(i + 1, n_ant)]
 
 
+def pairs_of_rank(rank: int, world: int) -> List[Tuple[int, int]]:
+    """The pairs rank ``rank`` of ``world`` solves: (rank, rank + d mod world) for d = 1 .. (world-1)//2, and for
+    even ``world`` the diameter d = world/2 on the lower half of the ranks.  Every unordered pair appears
+    exactly once over the ranks; a rank touches at most world//2 + 1 antennas.  The first index may be the
+    larger one: ``canonical_pair`` turns (j, i, lag) into (i, j, -lag)."""
+    out = []
+    for d in range(1, (world - 1) // 2 + 1):
+        out.append((rank, (rank + d) % world))
+    if world % 2 == 0 and world > 1 and rank < world // 2:
+        out.append((rank, rank + world // 2))
+    return out
+
+
+def pair_capacity(world: int, n_ant: int) -> int:
+    """Pair entries a result vector reserves: all pairs when one rank solves them, world//2 otherwise."""
+    return n_ant * (n_ant - 1) // 2 if world == 1 else max(world // 2, 1)
+
+
+def canonical_pair(i: int, j: int, lag: int):
+    """(i, j, lag) with i < j: correlate(s_i, s_j) peaks at minus the lag of correlate(s_j, s_i)."""
+    if i <= j:
+        return i, j, lag
+    return j, i, (lag if lag == LAG_INVALID else -lag)
+
+
 def pack_results(n_chunks: int, nperseg: int, power_map: torch.Tensor, stats: torch.Tensor,
                  amp_first: torch.Tensor, amp_count: torch.Tensor, amp_mean: torch.Tensor,
                  onset: torch.Tensor, lag: torch.Tensor, peak: torch.Tensor,
                  noise_power: torch.Tensor, mean_spectrum: torch.Tensor, n_rows: int,
-                 rank: int) -> torch.Tensor:
-    """float64 vector [HEADER + n_chunks + nperseg] built with device-side ops only (no
-    host synchronisation).  int64 scalars are exact in float64 up to 2^53."""
+                 rank: int, pairs: Sequence[Tuple[int, int]] = (), pair_lags: Optional[torch.Tensor] = None,
+                 pair_peaks: Optional[torch.Tensor] = None, pair_margins: Optional[torch.Tensor] = None,
+                 capacity: int = 0) -> torch.Tensor:
+    """float64 vector [HEADER + n_chunks + nperseg + 5 capacity] (the layout of gj_pack_result_dev) built
+    with device-side ops only (no host synchronisation).  int64 scalars are exact in float64 up to 2^53."""
     dev = power_map.device
     head = torch.zeros(HEADER, dtype=torch.float64, device=dev)
     head[0] = n_chunks
@@ -71,7 +104,15 @@ def pack_results(n_chunks: int, nperseg: int, power_map: torch.Tensor, stats: to
     head[11] = n_rows
     head[12] = nperseg
     head[13] = rank
-    return torch.cat([head, power_map.to(torch.float64), mean_spectrum.to(torch.float64)])
+    head[14] = len(pairs)
+    head[15] = capacity
+    block = torch.zeros((capacity, PAIR_FIELDS), dtype=torch.float64, device=dev)
+    if len(pairs):
+        block[:len(pairs), 0:2] = torch.tensor(list(pairs), dtype=torch.float64, device=dev)
+        block[:len(pairs), 2] = pair_lags.to(torch.float64)[:len(pairs)]
+        block[:len(pairs), 3] = pair_peaks.to(torch.float64)[:len(pairs)]
+        block[:len(pairs), 4] = pair_margins.to(torch.float64)[:len(pairs)]
+    return torch.cat([head, power_map.to(torch.float64), mean_spectrum.to(torch.float64), block.reshape(-1)])
 
 
 @dataclass
@@ -89,6 +130,7 @@ class StreamResult:
     peak: float
     noise_power: float
     mean_spectrum: np.ndarray
+    solved: List[Tuple[int, int, int, float, float]] = field(default_factory=list)   # (i, j, lag, peak, margin) this stream solved
 
     def jamming_byte_ranges(self, chunk_bytes: int = 65536):
         """(start_byte, end_byte) runs above the threshold (worker.py:248-264)."""
@@ -123,10 +165,13 @@ def unpack_results(vec: torch.Tensor) -> StreamResult:
     n_chunks, nperseg = int(v[0]), int(v[12])
     pm = v[HEADER:HEADER + n_chunks].astype(np.float32)
     spec = v[HEADER + n_chunks:HEADER + n_chunks + nperseg].astype(np.float32)
+    n_pairs = int(v[14])
+    blk = v[HEADER + n_chunks + nperseg:HEADER + n_chunks + nperseg + PAIR_FIELDS * n_pairs].reshape(n_pairs, PAIR_FIELDS)
+    solved = [(int(r[0]), int(r[1]), int(r[2]), float(r[3]), float(r[4])) for r in blk]
     return StreamResult(rank=int(v[13]), power_map=pm, baseline=float(v[1]), threshold=float(v[2]),
                         n_above=int(v[3]), amp_first=int(v[4]), amp_count=int(v[5]),
                         amp_mean=float(v[6]), onset=int(v[7]), lag=int(v[8]), peak=float(v[9]),
-                        noise_power=float(v[10]), mean_spectrum=spec)
+                        noise_power=float(v[10]), mean_spectrum=spec, solved=solved)
 
 
 def make_slot(capture_u8: torch.Tensor, start: int, n_samples: int) -> torch.Tensor:
@@ -164,6 +209,17 @@ def gather_rows(row: torch.Tensor, rank: int, world_size: int, dst: int = 0,
     return None
 
 
+def allgather_rows(row: torch.Tensor, world_size: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Every rank's ``row`` on EVERY rank as one [world, len] tensor (torch.distributed.all_gather)."""
+    if world_size == 1:
+        return row.unsqueeze(0)
+    import torch.distributed as dist
+    if out is None:
+        out = torch.empty((world_size, row.numel()), dtype=row.dtype, device=row.device)
+    dist.all_gather([out[r] for r in range(world_size)], row)
+    return out
+
+
 def gather_results(vec: torch.Tensor, rank: int, world_size: int, dst: int = 0) -> Optional[List[torch.Tensor]]:
     """Gather every rank's result vector on ``dst``; returns the list there, None elsewhere."""
     rows = gather_rows(vec, rank, world_size, dst)
@@ -171,25 +227,22 @@ def gather_results(vec: torch.Tensor, rank: int, world_size: int, dst: int = 0) 
 
 
 class StepResults:
-    """What ``AntennaStream.exchange`` returns on the solving rank: the gathered result vectors
-    and the pair lags, still in HBM, plus the event that marks them complete.  The collectives
-    and K5 run on the pipeline's second stream; a consumer on any other stream must call
-    ``wait()`` (or go through ``unpack()`` / indexing, which do) before reading the tensors.
-    The buffers are reused two steps later."""
+    """What ``AntennaStream.exchange`` returns on rank 0: the gathered result vectors (with the pair
+    tables inside), still in HBM, plus the event that marks them complete.  The collectives and K5 run
+    on the pipeline's second stream; a consumer on any other stream must call ``wait()`` (or go through
+    ``unpack()`` / indexing, which do) before reading the tensors.  The buffers are reused two steps
+    later."""
 
-    def __init__(self, vectors, pairs, lags, peaks, margins, event, n_ant):
-        self.vectors, self.pairs = vectors, pairs
-        self.lags, self.peaks, self.margins = lags, peaks, margins
-        self.event, self.n_ant = event, n_ant
+    def __init__(self, vectors, event, n_ant):
+        self.vectors, self.event, self.n_ant = vectors, event, n_ant
 
     def wait(self, stream=None):
         """Make ``stream`` (default: torch's current stream) wait for the exchange."""
         if self.event is not None:
             stream = stream or torch.cuda.current_stream(self.vectors.device)
             stream.wait_event(self.event)
-            for t in (self.vectors, self.lags, self.peaks, self.margins):
-                if t is not None and t.is_cuda:
-                    t.record_stream(stream)
+            if self.vectors.is_cuda:
+                self.vectors.record_stream(stream)
         return self
 
     def __len__(self):
@@ -199,26 +252,27 @@ class StepResults:
         self.wait()
         return self.vectors[r]
 
-    def tdoa(self) -> TdoaResult:
-        self.wait()
-        if self.lags is None:
-            return TdoaResult()
-        return TdoaResult(list(self.pairs), [int(x) for x in self.lags.cpu().tolist()],
-                          [float(x) for x in self.peaks.cpu().tolist()],
-                          [float(x) for x in self.margins.cpu().tolist()])
-
     def unpack(self) -> Tuple[List[StreamResult], TdoaResult]:
-        """Host-side view: one StreamResult per rank (lag / peak = pair (0, rank)) and every pair."""
+        """Host-side view: one StreamResult per rank (lag / peak = pair (0, rank)) and every solved pair,
+        in canonical order (i < j, sorted)."""
         self.wait()
         res = [unpack_results(self.vectors[r]) for r in range(self.vectors.shape[0])]
-        td = self.tdoa()
+        table = {}
+        for r in res:
+            for i, j, lag, peak, margin in r.solved:
+                ci, cj, clag = canonical_pair(i, j, lag)
+                table[(ci, cj)] = (clag, peak, margin)
+        keys = sorted(table)
+        td = TdoaResult(keys, [table[k][0] for k in keys], [table[k][1] for k in keys], [table[k][2] for k in keys])
         for r in res:
             if r.rank == 0:
                 r.lag, r.peak = 0, 0.0
-            elif (0, r.rank) in td.pairs:
-                k = td.pairs.index((0, r.rank))
-                r.lag, r.peak = td.lags[k], td.peaks[k]
+            elif (0, r.rank) in table:
+                r.lag, r.peak = table[(0, r.rank)][0], table[(0, r.rank)][1]
         return res, td
+
+    def tdoa(self) -> TdoaResult:
+        return self.unpack()[1]
 
 
 class AntennaStream:
@@ -230,7 +284,8 @@ class AntennaStream:
     uint8; the rank then solves all pairs over 1 + n_aux antennas itself (BASELINE configs[3]:
     three antennas, three pairs on one GPU).
     ``transport``: "torch" = torch.distributed (nccl = RCCL on HIP tensors, gloo for rehearsal);
-    "rccl" = the library's own gj_comm_* entry points (gpsjam.comm), no torch.distributed."""
+    "rccl" = the library's own gj_comm_* entry points (gpsjam.comm), no torch.distributed; or a
+    ready ``gpsjam.comm.Communicator`` on the context the side stream uses."""
 
     def __init__(self, dev, capture: torch.Tensor, *, chunk_bytes: int = 65536,
                  chunk_samples: int = 2048000, nperseg: int = 4096, fs: float = 2.048e6,
@@ -240,7 +295,7 @@ class AntennaStream:
                  transport="torch"):
         assert capture.dtype == torch.uint8 and capture.is_contiguous()
         self.dev, self.cap = dev, capture
-        # K2 is VALU/LDS bound and leaves ~90 % of the HBM bandwidth idle, the fused scan is HBM
+        # K2 is bound by VALU issue and leaves ~90 % of the HBM bandwidth idle, the fused scan is HBM
         # bound: with ``overlap`` the scan, threshold and TDOA kernels run on a second HIP
         # stream (own gpsjam context = own workspace) concurrently with K2 and join in pack().
         if overlap is None:
@@ -276,38 +331,35 @@ class AntennaStream:
         self.psd = torch.empty((max(self.rows, 1), nperseg), dtype=torch.float32, device=d)
         self.amp = torch.zeros(4, dtype=torch.int64, device=d)        # gj_amp_stats (32 bytes)
         self.onset = torch.zeros(4, dtype=torch.int64, device=d)      # gj_onset (32 bytes)
-        # this rank's own entry in its result vector: rank 0 is the reference antenna (lag 0); the
-        # other ranks' lags only exist on rank 0, which fills them in when it unpacks
-        self.lag_self = torch.full((1,), 0 if rank == 0 else LAG_INVALID, dtype=torch.int32, device=d)
-        self.peak_self = torch.zeros(1, dtype=torch.float32, device=d)
-        # TDOA: slots of every antenna this rank solves for (rank 0: all ranks; one rank: self + aux)
-        self.slot_bytes = dev.tdoa_slot_bytes(slice_samples)
-        n_aux = 0 if aux_slots is None else int(aux_slots.shape[0])
-        assert not (n_aux and world_size > 1), "aux_slots is the single-rank form"
-        self.n_ant = world_size if world_size > 1 else 1 + n_aux
-        self.is_root = rank == 0
-        self.pairs = all_pairs(self.n_ant) if self.is_root else []
-        self.slots = (torch.zeros((self.n_ant, self.slot_bytes), dtype=torch.uint8, device=d)
-                      if (self.is_root or world_size == 1) else None)
-        if n_aux:
-            assert aux_slots.shape[1] == self.slot_bytes and aux_slots.dtype == torch.uint8
-            self.slots[1:].copy_(aux_slots)
         # collectives
         self.comm = None
         if transport == "rccl" and world_size > 1:
             from .comm import Communicator
             self.comm = Communicator(self.dev_side, rank, world_size)
         elif not isinstance(transport, str):
-            self.comm = transport                  # a ready gpsjam.comm.Communicator on dev_side's context
+            self.comm = transport
         self._exchange = world_size > 1 or self.comm is not None   # a communicator is used even when alone
-        # no exchange: the slot is written in place; otherwise a send buffer of its own on every rank
+        # TDOA: the slots of every antenna (all-gathered: every rank holds them all), the pairs THIS rank solves
+        self.slot_bytes = dev.tdoa_slot_bytes(slice_samples)
+        n_aux = 0 if aux_slots is None else int(aux_slots.shape[0])
+        assert not (n_aux and world_size > 1), "aux_slots is the single-rank form"
+        self.n_ant = world_size if world_size > 1 else 1 + n_aux
+        self.is_root = rank == 0
+        self.pairs = all_pairs(self.n_ant) if world_size == 1 else pairs_of_rank(rank, world_size)
+        self.pair_cap = pair_capacity(world_size, self.n_ant)
+        self.slots = torch.zeros((self.n_ant, self.slot_bytes), dtype=torch.uint8, device=d)
+        if n_aux:
+            assert aux_slots.shape[1] == self.slot_bytes and aux_slots.dtype == torch.uint8
+            self.slots[1:].copy_(aux_slots)
+        # no exchange: the slot is written in place; otherwise a send buffer of its own
         self.my_slot = self.slots[0] if not self._exchange else torch.zeros(self.slot_bytes, dtype=torch.uint8, device=d)
         npairs = max(len(self.pairs), 1)
+        self.d_pairs = torch.tensor([x for p in self.pairs for x in p] or [0, 0], dtype=torch.int32, device=d)
+        self.lags = torch.full((npairs,), LAG_INVALID, dtype=torch.int32, device=d)
+        self.peaks = torch.zeros(npairs, dtype=torch.float32, device=d)
+        self.margins = torch.zeros(npairs, dtype=torch.float32, device=d)
         # two sets, used alternately: step k's consumer may still be reading one while step k + 1 fills the other
-        self._lags = [torch.full((npairs,), LAG_INVALID, dtype=torch.int32, device=d) for _ in range(2)]
-        self._peaks = [torch.zeros(npairs, dtype=torch.float32, device=d) for _ in range(2)]
-        self._margins = [torch.zeros(npairs, dtype=torch.float32, device=d) for _ in range(2)]
-        rl = result_len(self.n_chunks, nperseg)
+        rl = result_len(self.n_chunks, nperseg, self.pair_cap)
         self._results = [torch.zeros(rl, dtype=torch.float64, device=d) for _ in range(2)]
         self._gathered = ([torch.zeros((world_size, rl), dtype=torch.float64, device=d) for _ in range(2)]
                           if (self.is_root and self._exchange) else [None, None])
@@ -315,9 +367,9 @@ class AntennaStream:
         self._idx = 0
         self.result = self._results[0]
         self.cap16 = capture.view(torch.int16)
-        # workspaces
-        ws_side = max(dev.xcorr_workspace(self.n_ant, slice_samples, max(len(self.pairs), 1)),
-                      self.nbytes // 48 + (1 << 20))
+        # workspaces: K5 transforms at most the antennas this rank's pairs name
+        ants = len({a for p in self.pairs for a in p}) or 1
+        ws_side = max(dev.xcorr_workspace(ants, slice_samples, npairs), self.nbytes // 48 + (1 << 20))
         ws_main = dev.welch_workspace(self.nbytes, chunk_samples, nperseg)
         if self.overlap:
             dev.reserve(ws_main)
@@ -350,25 +402,20 @@ class AntennaStream:
         self.welch()
 
     # ---------------------------------------------------------------- the TDOA exchange
-    def _gather(self, row: torch.Tensor, out: Optional[torch.Tensor]):
-        """One gather to rank 0 on the side stream: torch.distributed or gj_comm_gather_dev."""
-        if self.comm is not None:
-            self.comm.gather(row, row.numel() * row.element_size(), out if self.is_root else None, 0)
-            return out
-        return gather_rows(row, self.rank, self.world, 0, out=out)
-
     def tdoa(self):
-        """Own slice -> TDOA slot; slots of all ranks -> rank 0 (one gather); rank 0 solves every
-        antenna pair with one multi-pair K5 launch.  All on the second stream, beside K2."""
+        """Own slice -> TDOA slot; ONE all-gather puts every rank's slot on every rank; this rank solves
+        its share of the antenna pairs with one multi-pair K5 launch.  All on the second stream, beside K2."""
         with self._on_side():
             dev = self.dev_side
-            nxt = self._idx ^ 1                    # the set this step writes (pack() flips _idx)
             dev.tdoa_slot_dev(self.cap, self.nbytes, self.onset, self.slice_samples, self.my_slot)
             if self._exchange:
-                self._gather(self.my_slot, self.slots[:self.world] if self.is_root else None)
-            if self.is_root and self.pairs:
+                if self.comm is not None:
+                    self.comm.allgather(self.my_slot, self.slot_bytes, self.slots)
+                else:
+                    allgather_rows(self.my_slot, self.world, out=self.slots[:self.world])
+            if self.pairs:
                 dev.xcorr_slots_dev(self.slots, self.slot_bytes, self.n_ant, self.slice_samples, self.pairs,
-                                    self._lags[nxt], self._peaks[nxt], self._margins[nxt])
+                                    self.lags, self.peaks, self.margins)
             if self.overlap:
                 self._ev_side.record(self._side)
 
@@ -378,10 +425,11 @@ class AntennaStream:
             self._main.wait_event(self._ev_side)
         self._idx ^= 1
         self.result = self._results[self._idx]
-        self.dev.pack_result_dev(self.n_chunks, self.power, self.stats, self.amp, self.onset, self.lag_self,
-                                 self.peak_self, self.psd, self.rows, self.nperseg, self.rank, self.result)
+        self.dev.pack_result_dev(self.n_chunks, self.power, self.stats, self.amp, self.onset, self.psd, self.rows,
+                                 self.nperseg, self.rank, len(self.pairs), self.pair_cap, self.d_pairs, self.lags,
+                                 self.peaks, self.margins, self.result)
         if self.overlap:
-            self._ev_free.record(self._main)
+            self._ev_free.record(self._main)       # the next step's scan / K5 may overwrite their outputs now
             self._ev_packed.record(self._main)
         return self.result
 
@@ -392,7 +440,7 @@ class AntennaStream:
         follows the gather in stream order.  The returned StepResults carries the event a consumer
         on any other stream has to wait for (``wait()`` / ``unpack()``); buffers are reused two
         steps later."""
-        assert dst == 0, "rank 0 solves"
+        assert dst == 0, "rank 0 collects"
         vec = self.pack()
         k = self._idx
         if not self._exchange:
@@ -403,14 +451,16 @@ class AntennaStream:
             if self.overlap:
                 self._side.wait_event(self._ev_packed)
             with self._on_side():
-                rows = self._gather(vec, self._gathered[k])
+                if self.comm is not None:
+                    rows = self._gathered[k]
+                    self.comm.gather(vec, vec.numel() * vec.element_size(), rows if self.is_root else None, 0)
+                else:
+                    rows = gather_rows(vec, self.rank, self.world, 0, out=self._gathered[k])
                 if self._done[k] is not None:
                     self._done[k].record(self._side)
         if not self.is_root:
             return None
-        has = bool(self.pairs)
-        return StepResults(rows, self.pairs, self._lags[k] if has else None, self._peaks[k] if has else None,
-                           self._margins[k] if has else None, self._done[k], self.n_ant)
+        return StepResults(rows, self._done[k], self.n_ant)
 
     def step(self) -> Optional[StepResults]:
         """One pass of the hot path over this rank's capture + the exchange."""

@@ -226,9 +226,11 @@ size_t gj_xcorr_workspace(gj_ctx* ctx, int n_ant, size_t n_samples, int n_pairs)
  * multiple of 256 bytes (gj_tdoa_slot_bytes).  gj_tdoa_slot_dev cuts the n_samples I/Q pairs that
  * start at *d_start (DEVICE scalar, e.g. &gj_onset.start_index) out of a capture; an un-found
  * onset or a slice that runs off the end marks the slot invalid (the reference aborts there,
- * skrypty/triangulateTDOA.py:67-77).  gj_xcorr_slots_dev solves pairs over an array of slots
- * (slot a at d_slots + a*slot_stride), e.g. the receive buffer of gj_comm_gather_dev: every pair
- * (i, j) of skrypty/triangulateTDOA.py:80-89 generalised to n_ant antennas on one GPU. */
+ * skrypty/triangulateTDOA.py:67-77).  gj_xcorr_slots_dev solves pairs over an array of n_ant
+ * slots (slot a at d_slots + a*slot_stride), e.g. the receive buffer of gj_comm_allgather_dev:
+ * pairs (i, j) of skrypty/triangulateTDOA.py:80-89 generalised to n_ant antennas.  Only the
+ * slots the pairs name are transformed (at most GJ_MAX_ANTENNAS per call), so the pairs of a
+ * many-antenna solve can be dealt over the ranks (gpsjam/sharded.py pairs_of_rank). */
 #define GJ_SLOT_HEADER 16
 size_t gj_tdoa_slot_bytes(size_t n_samples);
 int gj_tdoa_slot_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, const int64_t* d_start,
@@ -238,16 +240,21 @@ int gj_xcorr_slots_dev(gj_ctx* ctx, const uint8_t* d_slots, size_t slot_stride, 
                        float* d_peaks, float* d_margins);
 
 /* ------------------------------------------------- per-stream result vector ---------- */
-/* What one rank sends to rank 0 (gpsjam/sharded.py): double[16 + n_chunks + nperseg] =
+/* What one rank sends to rank 0 (gpsjam/sharded.py):
+ * double[16 + n_chunks + nperseg + 5*pair_capacity] =
  * { n_chunks, baseline, threshold, n_above, amp.first_index, amp.count, amp.mean,
- *   onset.start_index, lag, peak, onset.noise_power, rows, nperseg, rank, 0, 0 },
- * the float32 power map, the mean over the rows of the PSD waterfall -- packed by one
- * kernel from the device-resident outputs of the calls above (no host synchronisation). */
+ *   onset.start_index, lag vs antenna 0 (0 on rank 0, GJ_LAG_INVALID elsewhere: the receiver fills
+ *   it in from the pair table), 0, onset.noise_power, rows, nperseg, rank, n_pairs, pair_capacity },
+ * the float32 power map, the mean over the rows of the PSD waterfall, and the pairs THIS stream
+ * solved as {i, j, lag, peak, margin} each (d_pairs = {i0,j0,i1,j1,...} and the outputs of
+ * gj_xcorr_slots_dev, all DEVICE arrays), zero-padded to pair_capacity -- packed by one kernel
+ * from device-resident outputs (no host synchronisation). */
 #define GJ_RESULT_HEADER 16
+#define GJ_RESULT_PAIR_FIELDS 5
 int gj_pack_result_dev(gj_ctx* ctx, size_t n_chunks, const float* d_power, const float* d_stats,
-                       const gj_amp_stats* d_amp, const gj_onset* d_onset, const int32_t* d_lag,
-                       const float* d_peak, const float* d_psd, size_t rows, int nperseg, int rank,
-                       double* d_out);
+                       const gj_amp_stats* d_amp, const gj_onset* d_onset, const float* d_psd, size_t rows,
+                       int nperseg, int rank, int n_pairs, int pair_capacity, const int32_t* d_pairs,
+                       const int32_t* d_lags, const float* d_peaks, const float* d_margins, double* d_out);
 
 /* ------------------------------------------------- GNSS acquisition search ----------- */
 /* the reference receiver's parallel code-phase search, batched over every
@@ -300,6 +307,8 @@ int gj_comm_rank(gj_comm* comm, int* rank, int* n_ranks);
 /* every rank sends `bytes` bytes; root receives n_ranks*bytes in rank order (d_recv may be NULL
  * elsewhere) */
 int gj_comm_gather_dev(gj_comm* comm, const void* d_send, size_t bytes, void* d_recv, int root);
+/* every rank sends `bytes` bytes and receives all n_ranks*bytes in rank order (ncclAllGather) */
+int gj_comm_allgather_dev(gj_comm* comm, const void* d_send, size_t bytes, void* d_recv);
 int gj_comm_bcast_dev(gj_comm* comm, void* d_buf, size_t bytes, int root);
 int gj_comm_destroy(gj_comm* comm); /* idempotent on NULL; synchronises the context's stream */
 

@@ -1,5 +1,5 @@
-"""The N > 1 exchange (TDOA-slot gather + all-pairs solve on rank 0 + result gather + rank-0
-unpacking) with gloo ranks on the CPU.  The per-capture numbers that the GPU kernels would
+"""The N > 1 exchange (TDOA-slot all-gather + every antenna pair solved, dealt over the ranks + result
+gather + rank-0 unpacking) with 2, 3 and 8 gloo ranks on the CPU.  The per-capture numbers that the GPU kernels would
 produce are supplied by the oracle here (this is a test of the distributed plumbing, which is
 backend-agnostic torch.distributed code shared with bench.py's RCCL run; the same exchange with
 the real kernels on both ranks is tests/test_sharded_two_rank_gpu.py)."""
@@ -15,6 +15,9 @@ import torch.multiprocessing as mp
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
+
+
+DELAYS = (0, 5, -3, 2, -7, 4, 1, -2)
 
 
 def _free_port():
@@ -37,7 +40,7 @@ def _worker(rank, world, port, q):
         from gpsjam.synth import StreamSpec, generate
         from oracle import gpsjam_oracle as orc
 
-        delays = (0, 5, -3)
+        delays = DELAYS
         n, sl, nperseg = 320000, 32768, 256
         raw = generate(StreamSpec(seed=11, antenna=rank, delay=delays[rank], jam_start=250000,
                                   jam_end=1 << 40, jam_sigma=60.0), n)
@@ -47,35 +50,32 @@ def _worker(rank, world, port, q):
         z = orc.tdoa_unpack(raw)
         onset = orc.tdoa_onset(z)
         lin, _, _ = orc.widmo_waterfall(raw, nperseg=nperseg, chunk_samples=100000)
-        # TDOA slot of this rank -> one gather to rank 0 -> every pair solved there
+        # TDOA slot of this rank -> ONE all-gather -> this rank solves its share of the pairs
         bad_rank = world - 1 if world == 3 else -1           # its slice is made to run off the end
         slot = sharded.make_slot(torch.from_numpy(raw.copy()), onset if rank != bad_rank else n - 100, sl)
         assert slot.numel() == sharded.slot_bytes(sl)
-        slots = sharded.gather_rows(slot, rank, world, 0)
-        pair_lags = {}
-        if rank == 0:
-            assert slots.shape == (world, sharded.slot_bytes(sl))
-            fields = [sharded.slot_fields(slots[r], sl) for r in range(world)]
-            for i, j in sharded.all_pairs(world):
-                if fields[i][0] and fields[j][0]:
-                    pair_lags[(i, j)] = int(orc.xcorr_lag(orc.tdoa_unpack(fields[j][2]), orc.tdoa_unpack(fields[i][2]))[0])
-                else:
-                    pair_lags[(i, j)] = sharded.LAG_INVALID
-        else:
-            assert slots is None
-        lag_self = 0 if rank == 0 else sharded.LAG_INVALID      # the other ranks' lags only exist on rank 0
+        slots = sharded.allgather_rows(slot, world)
+        assert slots.shape == (world, sharded.slot_bytes(sl))
+        fields = [sharded.slot_fields(slots[r], sl) for r in range(world)]
+        mine = sharded.pairs_of_rank(rank, world)
+        lags = []
+        for i, j in mine:
+            if fields[i][0] and fields[j][0]:
+                lags.append(int(orc.xcorr_lag(orc.tdoa_unpack(fields[j][2]), orc.tdoa_unpack(fields[i][2]))[0]))
+            else:
+                lags.append(sharded.LAG_INVALID)
+        cap = sharded.pair_capacity(world, world)
         vec = sharded.pack_results(
             pm.size, nperseg, torch.from_numpy(pm), torch.tensor([base, thr, float((pm > thr).sum())]),
             torch.tensor(k), torch.tensor(n - k), torch.tensor(float(avg)), torch.tensor(onset),
-            torch.tensor(lag_self), torch.tensor(0.0), torch.tensor(1.0),
-            torch.from_numpy(lin.mean(axis=0)), lin.shape[0], rank)
-        assert vec.numel() == sharded.result_len(pm.size, nperseg)
+            torch.tensor(0 if rank == 0 else sharded.LAG_INVALID), torch.tensor(0.0), torch.tensor(1.0),
+            torch.from_numpy(lin.mean(axis=0)), lin.shape[0], rank, pairs=mine,
+            pair_lags=torch.tensor(lags or [0], dtype=torch.int32), pair_peaks=torch.ones(max(len(mine), 1)),
+            pair_margins=torch.ones(max(len(mine), 1)), capacity=cap)
+        assert vec.numel() == sharded.result_len(pm.size, nperseg, cap)
         rows = sharded.gather_rows(vec, rank, world, 0)
         if rank == 0:
-            pairs = sharded.all_pairs(world)
-            step = sharded.StepResults(rows, pairs, torch.tensor([pair_lags[p] for p in pairs], dtype=torch.int32),
-                                       torch.ones(len(pairs)), torch.ones(len(pairs)), None, world)
-            res, td = step.unpack()
+            res, td = sharded.StepResults(rows, None, world).unpack()
             assert [r.rank for r in res] == list(range(world))
             np.testing.assert_array_equal(res[0].power_map, pm)
             assert res[0].jamming_byte_ranges() == [(int(a), int(b)) for a, b in ranges]
@@ -92,8 +92,8 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(240)
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_exchange_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -101,15 +101,15 @@ def test_exchange_gloo(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    msgs = [q.get(timeout=200) for _ in range(world)]
+    msgs = [q.get(timeout=350) for _ in range(world)]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     assert all(m[0] != "fail" for m in msgs), msgs
     _, pairs, lags, onsets, lag_vs_0, _ = [m for m in msgs if m[0] == "ok"][0]
     others = {m[1]: m[2] for m in msgs if m[0] == "ok1"}
-    delays = (0, 5, -3)
-    assert pairs == [(i, j) for i in range(world) for j in range(i + 1, world)]
+    delays = DELAYS
+    assert pairs == [(i, j) for i in range(world) for j in range(i + 1, world)]    # every pair, each solved once
     for r, o in others.items():
         assert onsets[r] == o
     # antenna a sees the burst delays[a] samples late; its own onset detection moves with it, and the

@@ -30,7 +30,7 @@ def test_antenna_stream_single_gpu():
     amp_mean = st.amp[3:4].view(torch.float32)[0]
     noise = st.onset[1:2].view(torch.float32)[0]
     ref = sharded.pack_results(st.n_chunks, st.nperseg, st.power, st.stats, st.amp[0], st.amp[1], amp_mean,
-                               st.onset[0], st.lag_self[0], st.peak_self[0], noise, st.psd[:st.rows].mean(dim=0),
+                               st.onset[0], torch.tensor(0), torch.tensor(0.0), noise, st.psd[:st.rows].mean(dim=0),
                                st.rows, 0)
     np.testing.assert_allclose(got[0].cpu().numpy(), ref.cpu().numpy(), rtol=1e-6)
     np.testing.assert_array_equal(got[0][:sharded.HEADER + st.n_chunks].cpu().numpy(),
@@ -138,12 +138,22 @@ def test_antenna_stream_three_antennas_one_gpu(overlap):
         assert lag + onsets[j] - onsets[i] == delays[j] - delays[i]
     assert all(m > 0.5 for m in td.margins)                # one clean peak per pair
     assert results[0].onset == onsets[0] and results[0].lag == 0
+    # the kernel-packed vector (pair block included) equals the torch-packed one
+    amp_mean = st.amp[3:4].view(torch.float32)[0]
+    noise = st.onset[1:2].view(torch.float32)[0]
+    ref = sharded.pack_results(st.n_chunks, st.nperseg, st.power, st.stats, st.amp[0], st.amp[1], amp_mean, st.onset[0],
+                               torch.tensor(0), torch.tensor(0.0), noise, st.psd[:st.rows].mean(dim=0), st.rows, 0,
+                               pairs=st.pairs, pair_lags=st.lags, pair_peaks=st.peaks, pair_margins=st.margins,
+                               capacity=st.pair_cap)
+    got = outs[-1][0]
+    assert got.numel() == sharded.result_len(st.n_chunks, st.nperseg, 3) == ref.numel()
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-6)
     # an antenna whose slice would run off the end of its capture: its pairs come back invalid
     bad = torch.tensor([n - sl + 1, 0, 0, 0], dtype=torch.int64, device="cuda")
     dev.tdoa_slot_dev(caps[2], caps[2].numel(), bad, sl, st.slots[2])
     st.tdoa()
     torch.cuda.synchronize()
-    lags = st._lags[st._idx ^ 1].cpu().tolist()
+    lags = st.lags.cpu().tolist()
     assert lags[0] == want[0] and lags[1] == sharded.LAG_INVALID and lags[2] == sharded.LAG_INVALID
     torch.cuda.set_stream(torch.cuda.default_stream())
     st.close()

@@ -21,7 +21,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def source_hash():
     h = hashlib.sha256()
-    for name in ("k_welch.hip", "fft_core.h", "gj_common.h"):
+    for name in ("k_welch.hip", "fft_core.h"):
         with open(os.path.join(REPO, "gps-jamming_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
