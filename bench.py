@@ -171,6 +171,8 @@ def main():
     # which includes whatever the concurrently running scan/TDOA kernels cost it; the scan and the K5 solve
     def timed(fn, on, reps=5):
         out = []
+        for _ in range(3):              # clocks and caches as in a steady run
+            fn()
         for _ in range(reps):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()

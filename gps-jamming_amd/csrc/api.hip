@@ -413,6 +413,7 @@ int gj_synth_u8_dev(gj_ctx* ctx, const gj_synth_params* params, int64_t first_sa
 }   // extern "C"
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -535,15 +536,33 @@ int gj_upload_file(gj_ctx* ctx, const char* path, size_t offset, size_t max_byte
         close(fd);
         return fail(ctx, GJ_ERR_NOMEM, "hipMalloc(%zu)", nbytes);
     }
-    int rc = staged_copy(ctx, static_cast<unsigned char*>(p), nbytes, [fd, offset](unsigned char* dst, size_t off, size_t len) {
-        size_t done = 0;
-        while (done < len) {
-            const ssize_t k = pread(fd, dst + done, len - done, (off_t)(offset + off + done));
-            if (k <= 0) return false;
-            done += (size_t)k;
-        }
-        return true;
-    });
+    // Page-cache pages are mapped and copied in user space (the fill threads' memcpy runs at the host-buffer
+    // rate; pread's kernel-side copy reached 13-15 GB/s with eight threads on these hosts); pread remains the
+    // path for files that cannot be mapped.
+    int rc = GJ_OK;
+    const long page = sysconf(_SC_PAGESIZE);
+    const size_t map_off = offset / (size_t)page * (size_t)page, lead = offset - map_off;
+    void* m = nbytes ? mmap(nullptr, nbytes + lead, PROT_READ, MAP_PRIVATE, fd, (off_t)map_off) : MAP_FAILED;
+    if (m != MAP_FAILED) {
+        (void)madvise(m, nbytes + lead, MADV_SEQUENTIAL);
+        const unsigned char* src = static_cast<const unsigned char*>(m) + lead;
+        rc = staged_copy(ctx, static_cast<unsigned char*>(p), nbytes, [src](unsigned char* dst, size_t off, size_t len) {
+            memcpy(dst, src + off, len);
+            return true;
+        });
+        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, GJ_ERR_HIP, "upload failed");
+        (void)munmap(m, nbytes + lead);
+    } else {
+        rc = staged_copy(ctx, static_cast<unsigned char*>(p), nbytes, [fd, offset](unsigned char* dst, size_t off, size_t len) {
+            size_t done = 0;
+            while (done < len) {
+                const ssize_t k = pread(fd, dst + done, len - done, (off_t)(offset + off + done));
+                if (k <= 0) return false;
+                done += (size_t)k;
+            }
+            return true;
+        });
+    }
     close(fd);
     if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, GJ_ERR_HIP, "upload failed");
     if (rc) {

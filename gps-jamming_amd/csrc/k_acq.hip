@@ -262,7 +262,7 @@ __device__ __forceinline__ T acq_group_reduce(T v, F&& op, T* sh /* [kBlockThrea
 }
 
 template <int N>
-__global__ __launch_bounds__(kBlockThreads) void acq_inv_all_kernel(AcqParams P, int nsampchip, const cf* __restrict__ twtab,
+__global__ __launch_bounds__(kBlockThreads, 3) void acq_inv_all_kernel(AcqParams P, int nsampchip, const cf* __restrict__ twtab,
                                                                     const cf* __restrict__ xspec,
                                                                     const cf* __restrict__ cspec,
                                                                     AcqRow* __restrict__ rows /* [n_prn][intg][n_freq] */) {
@@ -275,10 +275,7 @@ __global__ __launch_bounds__(kBlockThreads) void acq_inv_all_kernel(AcqParams P,
     const int tid = threadIdx.x, b = tid / TF, jl = tid % TF;
     const int f = blockIdx.x * B + b;
     const bool live = f < P.n_freq;
-    const cf* c = cspec + (size_t)p * N;
-    cf cq[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) cq[s] = c[jl + TF * s];
+    const cf* c = cspec + (size_t)p * N;   // 32 KB per PRN, re-read every step: L2-resident, and 32 VGPRs cheaper than a copy
     c2 tw[3][15];
 #pragma unroll
     for (int k = 0; k < 15; ++k) tw[0][k] = tw[1][k] = tw[2][k] = make_c2(1.f, 0.f);
@@ -292,7 +289,7 @@ __global__ __launch_bounds__(kBlockThreads) void acq_inv_all_kernel(AcqParams P,
         c2 v[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const cf a = x[jl + TF * s], q = cq[s];
+            const cf a = x[jl + TF * s], q = c[jl + TF * s];
             v[s] = make_c2(-a.x * q.x - a.y * q.y, -(a.x * q.y - a.y * q.x));   // as in acq_inv_kernel
         }
         acq_passes_tw<N, 0>(v, lds, b * lds_span(N), jl, tw);
