@@ -4,7 +4,7 @@ dispatch of welch_kernel) with the HBM byte counts corrected as MI355X_MICROARCH
 FETCH_SIZE is in KiB and, on gfx950, tallies 128-B requests at 64 B for wide streaming reads;
 the factor for K2's own 2-byte-per-lane pattern is calibrated by tools/calib_fetch (1 GiB read
 exactly once with each pattern) in the same session.
-    python tools/pmc_summarize.py gpurun_out/<dir> > profiles/r02_pmc_welch/summary.json
+    python tools/pmc_summarize.py gpurun_out/<dir> [measured-on-commit] > profiles/r02_pmc_welch/summary.json
 The summary is stamped with the commit it was measured on and with a hash of the K2 sources
 (bench.py compares that hash with the sources it runs on)."""
 import collections
@@ -59,11 +59,15 @@ def main():
     if k2.get("SQ_INSTS_VALU") is not None:
         out["_valu"] = {"sq_insts_valu_per_launch": k2["SQ_INSTS_VALU"],
                         "sq_insts_lds_per_launch": k2.get("SQ_INSTS_LDS"), "sq_waves": k2.get("SQ_WAVES")}
-    try:
-        out["_commit"] = subprocess.run(["git", "-C", REPO, "rev-parse", "--short=12", "HEAD"], capture_output=True,
-                                        text=True, check=True).stdout.strip()
-    except Exception:
-        out["_commit"] = "unknown"
+    # the commit the passes were MEASURED on: second argument, else the current HEAD
+    if len(sys.argv) > 2:
+        out["_commit"] = sys.argv[2]
+    else:
+        try:
+            out["_commit"] = subprocess.run(["git", "-C", REPO, "rev-parse", "--short=12", "HEAD"], capture_output=True,
+                                            text=True, check=True).stdout.strip()
+        except Exception:
+            out["_commit"] = "unknown"
     out["_source_hash"] = source_hash()
     out["_note"] = ("rocprofv3 --pmc, separate passes (tools/pmc_welch.sh), welch_kernel<4096> on 2^30 bytes, "
                     "averages per dispatch")
