@@ -11,6 +11,9 @@
 
 namespace gj {
 
+#ifndef GJ_SCAN_PRIO
+#define GJ_SCAN_PRIO 0   // s_setprio level of the fused scan's waves (experiment knob)
+#endif
 constexpr int kScanThreads = 256;
 constexpr size_t kScanTile = 65536;   // bytes per workgroup step
 
@@ -847,6 +850,7 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
     __shared__ unsigned long long red_m[2][kScanThreads / 64];
     __shared__ double red_s[kScanThreads / 64];
     __shared__ long long red_f[kScanThreads / 64];
+    if constexpr (GJ_SCAN_PRIO != 0) __builtin_amdgcn_s_setprio(GJ_SCAN_PRIO);
     const int tid = threadIdx.x;
     const size_t t = blockIdx.x;
     const size_t b0 = t * kScanTile;                               // first byte of the tile
@@ -1011,12 +1015,14 @@ int launch_stream_scan(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t c
     const bool noise_fused = valid && (noise_bytes % 16 == 0);
     // amplitudes are >= sqrt(2)/255 > 0.0055: a threshold below that makes every sample a hit
     const bool track = !(rssi_threshold < 0.005f);
+    // experiment knob: dynamic LDS the scan workgroups declare but never touch (residency limiter)
+    static const unsigned lds_pad = getenv("GPSJAM_SCAN_LDS_PAD") ? (unsigned)atoi(getenv("GPSJAM_SCAN_LDS_PAD")) : 0u;
     if (track)
-        hipLaunchKernelGGL(stream_scan_kernel<true>, dim3((unsigned)ntiles), dim3(kScanThreads), 0, ctx->stream, d_iq,
+        hipLaunchKernelGGL(stream_scan_kernel<true>, dim3((unsigned)ntiles), dim3(kScanThreads), lds_pad, ctx->stream, d_iq,
                            nsamples, nbytes, chunk_bytes, (unsigned)tpc, eps, flags, d_power, acc, rssi_threshold, tiles,
                            cblk, noise_fused ? noise_bytes : (size_t)0, sc, unpack_of(ctx));
     else
-        hipLaunchKernelGGL(stream_scan_kernel<false>, dim3((unsigned)ntiles), dim3(kScanThreads), 0, ctx->stream, d_iq,
+        hipLaunchKernelGGL(stream_scan_kernel<false>, dim3((unsigned)ntiles), dim3(kScanThreads), lds_pad, ctx->stream, d_iq,
                            nsamples, nbytes, chunk_bytes, (unsigned)tpc, eps, flags, d_power, acc, rssi_threshold, tiles,
                            cblk, noise_fused ? noise_bytes : (size_t)0, sc, unpack_of(ctx));
     GJ_LAUNCH_CHECK(ctx);

@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--k2-priority", type=int, default=0, help="torch stream priority of the K2 stream (-1 = high)")
     ap.add_argument("--side-priority", type=int, default=0)
     ap.add_argument("--side-per-k2", type=int, default=1, help="side launches issued per K2 launch")
+    ap.add_argument("--side-cu-every", type=int, default=0,
+                    help="confine the side stream to every n-th CU (hipExtStreamCreateWithCUMask); 0 = no mask")
     args = ap.parse_args()
     import torch
     import gpsjam
@@ -26,6 +28,16 @@ def main():
     nbytes = 1 << 30
     ns = nbytes // 2
     s1, s2 = torch.cuda.Stream(priority=args.k2_priority), torch.cuda.Stream(priority=args.side_priority)
+    if args.side_cu_every:
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        words = (C.c_uint32 * 8)()
+        for cu in range(0, 256, args.side_cu_every):
+            words[cu // 32] |= 1 << (cu % 32)
+        h = C.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(C.byref(h), 8, words)
+        assert rc == 0, rc
+        s2 = torch.cuda.ExternalStream(h.value)
     a, b = gpsjam.Device(0), gpsjam.Device(0)
     a.set_stream(s1.cuda_stream)
     b.set_stream(s2.cuda_stream)
@@ -49,6 +61,14 @@ def main():
         if args.side == "fill":
             with torch.cuda.stream(s2):
                 dst.fill_(7)
+            return
+        if args.side == "k1small":      # the same bytes per K2 launch, but out of a 16-MiB window: L2 / Infinity Cache, no HBM
+            for _ in range(64):
+                b.chunk_power_dev(cap, 1 << 24, 65536, pw)
+            return
+        if args.side == "k1x8":         # 8 launches over consecutive 128-MiB windows: HBM, same launch count ballpark
+            for k in range(8):
+                b.chunk_power_dev(cap[k << 27:], 1 << 27, 65536, pw[k << 11:])
             return
         if args.side == "fscan":
             b.stream_scan_dev(cap, nbytes, 65536, pw, 0.0, amp, 200000, 1000, 50.0, on)
