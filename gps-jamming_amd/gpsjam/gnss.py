@@ -17,11 +17,9 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
-from typing import List, Optional, Sequence
+from typing import List, Sequence
 
 import numpy as np
-
-from . import _ffi
 
 CA_LEN = 1023                 # chips per C/A code period (LEN_L1CA)
 CA_RATE = 1.023e6             # chips per second (CRATE_L1CA)

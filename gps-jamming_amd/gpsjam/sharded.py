@@ -25,7 +25,7 @@ from __future__ import annotations
 
 import contextlib
 from dataclasses import dataclass, field
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple  # noqa: F401
 
 import numpy as np
 import torch
