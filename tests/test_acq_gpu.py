@@ -82,3 +82,38 @@ def test_acq_all_32_prns_and_errors(dev):
         with pytest.raises(gpsjam.GpsJamError):
             srch.search(cap, first_sample=2 * 2048)                  # the eleven milliseconds do not fit any more
     srch.close()
+
+
+@pytest.mark.parametrize("fs", [1.024e6, 0.512e6])
+def test_acq_other_sampling_rates(dev, fs):
+    """nsamp = 1024 / 512 (FFT length 2048 / 1024): two / four transforms per workgroup, other
+    reduction shapes.  Same checks against the oracle as at 2.048 MS/s."""
+    nsamp = int(fs * 1e-3)
+    rng = np.random.default_rng(int(fs) % 97)
+    n = 13 * nsamp
+    t = np.arange(n) / fs
+    z = rng.normal(0, 10.0, n) + 1j * rng.normal(0, 10.0, n)
+    sats = [(4, 1800.0, nsamp // 3, 7.0), (20, -4400.0, nsamp - 9, 2.0)]
+    for prn, dop, delay, amp in sats:
+        chip = ((np.arange(n) - delay) * 1.023e6 / fs) % 1023
+        z += amp * gnss.ca_code(prn)[chip.astype(np.int64)] * np.exp(-2j * np.pi * dop * t)
+    iq = np.empty(2 * n)
+    iq[0::2], iq[1::2] = z.real, z.imag
+    raw = (np.clip(np.round(iq), -128, 127) + 128).astype(np.uint8)
+    prns = [4, 9, 20]
+    srch = gnss.AcqSearch(dev, prns=prns, fs=fs)
+    assert srch.nsamp == nsamp
+    with dev.capture(raw) as cap:
+        res, P = srch.search(cap, first_sample=17, want_power=True)
+        fast = srch.search(cap, first_sample=17)
+    for k, prn in enumerate(prns):
+        want, Pw = orc.acq_search(raw, 17, prn, fs=fs)
+        Pw = Pw.reshape(71, nsamp)
+        np.testing.assert_allclose(P[k], Pw, rtol=0, atol=2e-4 * Pw.max())
+        for got in (res[k], fast[k]):
+            assert got.acquired == want["acquired"] and got.steps == want["steps"], (prn, got, want)
+            if want["peakr"] > 1.5:
+                assert (got.code_index, got.freq_index) == (want["codei"], want["freqi"]), (prn, got, want)
+                np.testing.assert_allclose(got.peak_ratio, want["peakr"], rtol=2e-3)
+    assert res[0].acquired and abs(res[0].doppler_hz - 1800.0) <= 200.0
+    srch.close()
