@@ -61,6 +61,11 @@
 // runs beside it on the second stream otherwise take issue slots away from it one for one.
 #define GJ_W_PRIO 0
 #endif
+#ifndef GJ_W_SCANSUMS
+// feasibility prototype (timing only, tools/ab_build.sh): per step also sum |z|^2 and |z| over the NEW half segment
+// (what K1 / K3 / K4 need), reduce per wave and store -- "K2 as the one reader of the capture", DESIGN section 4
+#define GJ_W_SCANSUMS 0
+#endif
 #define GJ_LOAD_RAW(x) (x)
 // GJ_STAMPS (diagnostic builds only, tools/ab_build.sh): s_memtime stamps around the phases of
 // a step, summed per wave and added to g_welch_stamps; read with gj_debug_welch_stamps().
@@ -271,10 +276,19 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
             }
         }
         c2 fsum = make_c2(0.f, 0.f);   // (sum I, sum Q) of the raw bytes: integers < 2^24, exact in f32
+        [[maybe_unused]] float scan_m = 0.f, scan_a = 0.f;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const unsigned u = raw[s];
             const c2 f = make_c2((float)(u & 255u), (float)((u >> 8) & 255u));
+            if constexpr (GJ_W_SCANSUMS != 0 && HS) {
+                if (s >= 8) {
+                    const c2 t = cadd(f, khalf);
+                    const float r2 = fmaf(t.x, t.x, t.y * t.y);   // |z|^2, exact
+                    scan_m += r2;
+                    scan_a += __fsqrt_rn(r2);
+                }
+            }
             if constexpr (Cfg::win16)   // w (2u - 255) = (u - 127.5) (2w)
                 v[s] = (s & 1) ? scale_hi(cadd(f, khalf), w2p[s >> 1]) : scale_lo(cadd(f, khalf), w2p[s >> 1]);
             else
@@ -295,6 +309,15 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
             sq = group_sum_dpp_f<TF>(fsum.y);
         }
 
+        if constexpr (GJ_W_SCANSUMS != 0 && HS) {
+            const int mi = group_sum_dpp<64>((int)(4.0f * scan_m));
+            const float ai = group_sum_dpp_f<64>(scan_a);
+            if ((tid & 63) == 0) {
+                float* dst = partial + (size_t)gridDim.x * N + ((size_t)blockIdx.x * 64 + (it & 63)) * 8 + (tid >> 6) * 2;
+                dst[0] = __int_as_float(mi);
+                dst[1] = ai;
+            }
+        }
         GJ_STAMP(t_it1);
         GJ_STAMP_ADD(4, t_it0, t_it1);   // unpack + window + sums (+ waiting for the prefetched loads)
         if constexpr (XP) welch_passes_x4096(v, lds0, lds1, tid, tw, ktw, stamps);
@@ -441,7 +464,7 @@ static bool welch_plan(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int npe
         if (cost < best * 0.999) { best = cost; want = sp; }
     }
     pl.g.splits = (unsigned)want;
-    pl.ws_bytes = pl.rows * want * (size_t)kBlockPoints * sizeof(float);
+    pl.ws_bytes = pl.rows * want * (size_t)kBlockPoints * sizeof(float) + (GJ_W_SCANSUMS ? pl.rows * want * 64 * 8 * sizeof(float) : 0);
     const double sw2 = 0.375 * nperseg;   // sum of the squared periodic Hann window
     const double norm2 = unpack_norm2(ctx);   // the kernel works on 2u - off2 = sample * (2 / scale): 65025 by default
     pl.scale_full = 1.0 / (fs * sw2 * norm2 * (double)pl.g.nseg_full);
