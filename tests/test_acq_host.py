@@ -69,3 +69,30 @@ def test_mixer_phase_table_matches_oracle_mixer():
     # -7 kHz: 0.0547 of a table step per sample, truncated toward zero: samples 0..18 stay at 0, then 15, 14 ...
     assert tab[0, 18] == 0 and tab[0, 19] == 15 and tab[0, 37] == 14
     assert tab[70, 18] == 0 and tab[70, 19] == 1
+
+
+def test_pcorrelator_restatement_against_the_definition():
+    """What pcorrelator + cpxconv compute, read off the C (sdrcmn.c:124-147,742-773) without any FFT:
+    P[k] = (CSCALE / m)^2 |sum_n (II + j QQ)[(n + k) mod m] code[n]|^2 -- exact integer arithmetic here.
+    The oracle's FFT form (complex64, like FFTW's) must agree to float32 accuracy: this pins the conjugation,
+    the sign and the m^2 normalisation of the restatement, though not the reference's own rounding."""
+    rng = np.random.default_rng(11)
+    nsamp, m = 2048, 4096
+    data = rng.integers(-40, 41, 2 * m).astype(np.int8)
+    freqs = [-3400.0, 0.0, 1200.0]
+    codex = orc.acq_code_fft(9, nsamp)
+    P = np.zeros(len(freqs) * nsamp)
+    orc.acq_pcorrelator(data, 1 / 2.048e6, nsamp, freqs, m, codex, P)
+    rcode = np.zeros(m, np.int64)
+    rcode[:nsamp] = orc.acq_rescode(orc.acq_gencode_l1ca(9), (1 / 2.048e6) * 1.023e6, nsamp)
+    for i, f in enumerate(freqs):
+        II, QQ = orc.acq_mixcarr_sse2(data, 1 / 2.048e6, m, f)
+        II, QQ = II.astype(np.int64), QQ.astype(np.int64)
+        want = np.empty(nsamp)
+        for k in range(0, nsamp, 97):                       # every 97th code phase: exact, a few dozen dot products
+            re = int(np.dot(np.roll(II, -k), rcode))
+            im = int(np.dot(np.roll(QQ, -k), rcode))
+            want[k] = (re * re + im * im) * (orc.ACQ_CSCALE / m) ** 2
+        got = P[i * nsamp:(i + 1) * nsamp]
+        ks = np.arange(0, nsamp, 97)
+        np.testing.assert_allclose(got[ks], want[ks], rtol=0, atol=2e-5 * want[ks].max())

@@ -111,3 +111,79 @@ def test_sweep_k5_xcorr(dev, case):
         want, wpk = orc.xcorr_lag(zs[b], zs[a])
         assert lag == want == delays[b] - delays[a]
         np.testing.assert_allclose(pk, wpk, rtol=1e-4)
+
+
+@pytest.mark.parametrize("case", CASES[:8])
+def test_sweep_slots_and_pair_dealing(dev, case):
+    """Round 2: TDOA slots cut on the device at random onsets, the antenna pairs dealt over 'ranks' as the
+    sharded pipeline deals them (sharded.pairs_of_rank), one gj_xcorr_slots_dev call per rank; the union must be
+    every pair exactly once with the oracle's lag, and an invalid slot must invalidate exactly its pairs."""
+    from gpsjam import sharded
+    r = _rng(case, 6)
+    n_ant = int(r.randint(2, 7))
+    sl = int(r.choice([4096, 12345, 50000, 65536]))
+    n = 260000 + sl + 5000
+    delays = [0] + [int(r.randint(-30, 31)) for _ in range(n_ant - 1)]
+    start = int(r.randint(215000, 250000))                   # the common burst, seen by antenna a `delays[a]` samples late
+    raws = [generate(StreamSpec(seed=1500 + case, antenna=a, delay=d, jam_start=start, jam_end=1 << 40,
+                                jam_sigma=float(60 + 3 * a)), n) for a, d in enumerate(delays)]
+    bad = int(r.randint(0, n_ant)) if case % 3 == 0 else -1
+    sb = dev.tdoa_slot_bytes(sl)
+    slots, d_on = dev.alloc(n_ant * sb), dev.alloc(32)
+    onsets = []
+    for a, raw in enumerate(raws):
+        with dev.capture(raw) as cap:
+            dev.onset_dev(cap, cap.nbytes, 200000, 1000, 50.0, d_on)
+            if a == bad:                                     # a slice that runs off the end of the capture
+                d_on.upload(np.array([n - sl + 1], np.int64))
+            dev.tdoa_slot_dev(cap, cap.nbytes, d_on, sl, slots.ptr + a * sb)
+            dev.synchronize()
+        onsets.append(orc.tdoa_onset(orc.tdoa_unpack(raw)))
+    z = [orc.tdoa_unpack(x) for x in raws]
+    table = {}
+    d_l, d_p, d_m = dev.alloc(64), dev.alloc(64), dev.alloc(64)
+    for rank in range(n_ant):
+        mine = sharded.pairs_of_rank(rank, n_ant)
+        if not mine:
+            continue
+        dev.xcorr_slots_dev(slots, sb, n_ant, sl, mine, d_l, d_p, d_m)
+        dev.synchronize()
+        for (i, j), lag in zip(mine, d_l.download(np.int32, len(mine)).tolist()):
+            ci, cj, cl = sharded.canonical_pair(i, j, lag)
+            assert (ci, cj) not in table
+            table[(ci, cj)] = cl
+    assert sorted(table) == sharded.all_pairs(n_ant)
+    for (i, j), lag in table.items():
+        if bad in (i, j):
+            assert lag == sharded.LAG_INVALID
+        else:
+            want = orc.xcorr_lag(z[j][onsets[j]:onsets[j] + sl], z[i][onsets[i]:onsets[i] + sl])[0]
+            assert lag == want and lag + onsets[j] - onsets[i] == delays[j] - delays[i]
+
+
+@pytest.mark.parametrize("case", CASES[:8])
+def test_sweep_unpack_convention(dev, case):
+    """gj_set_unpack with random half-integer offsets and scales: K1 and K3 against plain numpy."""
+    r = _rng(case, 7)
+    offset = float(r.randint(200, 312)) / 2.0                # 100.0 .. 155.5 in steps of 0.5
+    scale = float(r.choice([1.0, 1 / 127.5, 1 / 128.0, 0.01]))
+    nsamp = int(r.randint(5000, 300000))
+    raw = generate(StreamSpec(seed=1700 + case, jam_start=nsamp // 3, jam_end=1 << 40, jam_sigma=float(r.uniform(20, 80))), nsamp)
+    v = raw.astype(np.float64) - offset
+    try:
+        dev.set_unpack(offset, scale)
+        pm = dev.chunk_power(raw, chunk_bytes=65536, eps=0.0)
+        want = [np.float32((v[o:o + 65536] ** 2).sum() / (len(v[o:o + 65536]) // 2)) for o in range(0, raw.size, 65536)]
+        np.testing.assert_array_equal(pm, np.array(want, np.float32))
+        amp = np.sqrt(v[0::2] ** 2 + v[1::2] ** 2) * scale
+        thr = float(r.choice([0.0, 0.3])) * scale * 127.5
+        st = dev.amp_stats(raw, thr)
+        hits = np.nonzero(amp.astype(np.float32) > np.float32(thr))[0]
+        if hits.size:
+            k = int(hits[0])
+            assert abs(st.first_index - k) <= 0 or abs(amp[st.first_index] - thr) < 1e-6 * max(thr, 1e-9)
+            np.testing.assert_allclose(st.mean, amp[st.first_index:].mean(), rtol=2e-6)
+        else:
+            assert st.first_index == -1
+    finally:
+        dev.set_unpack()
