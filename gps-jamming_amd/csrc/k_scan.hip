@@ -428,7 +428,9 @@ __device__ double block_sum_f64(double v, double* sh /* [blockDim/64] */) {
     return t;
 }
 
-__global__ __launch_bounds__(1024) void amp_finalize_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
+// 256 threads: a workgroup this size fits into whatever a finishing K2 workgroup frees (a 1024-thread one needs four
+// waves on every SIMD of one CU at once and waited ~100 us for that beside K2)
+__global__ __launch_bounds__(256) void amp_finalize_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
                                                             const AmpTile* __restrict__ tiles, size_t ntiles,
                                                             gj_amp_stats* __restrict__ out, Unpack up,
                                                             float* __restrict__ power = nullptr, size_t nchunks = 0,
@@ -445,7 +447,18 @@ __global__ __launch_bounds__(1024) void amp_finalize_kernel(const uint8_t* __res
     if (threadIdx.x == 0) first_s = 0x7fffffffffffffffll;
     __syncthreads();
     long long f = 0x7fffffffffffffffll;
-    for (size_t t = threadIdx.x; t < ntiles; t += blockDim.x) f = tiles[t].first < f ? tiles[t].first : f;
+    // eight independent loads in flight per thread: this single workgroup is latency-bound, and beside K2 every
+    // round trip is slow
+    for (size_t t = threadIdx.x; t < ntiles; t += 8 * (size_t)blockDim.x) {
+        long long v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const size_t tt = t + (size_t)k * blockDim.x;
+            v[k] = tt < ntiles ? tiles[tt].first : 0x7fffffffffffffffll;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f = v[k] < f ? v[k] : f;
+    }
     if (f != 0x7fffffffffffffffll) atomicMin(&first_s, f);
     __syncthreads();
     const long long first = first_s;
@@ -457,7 +470,15 @@ __global__ __launch_bounds__(1024) void amp_finalize_kernel(const uint8_t* __res
     }
     const size_t t0 = (size_t)first / kAmpTileSamples;
     double acc = 0.0;
-    for (size_t t = t0 + 1 + threadIdx.x; t < ntiles; t += blockDim.x) acc += tiles[t].sum;
+    for (size_t t = t0 + 1 + threadIdx.x; t < ntiles; t += 8 * (size_t)blockDim.x) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const size_t tt = t + (size_t)k * blockDim.x;
+            v[k] = tt < ntiles ? tiles[tt].sum : 0.0;
+        }
+        acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
     if ((size_t)first == t0 * kAmpTileSamples) {
         if (threadIdx.x == 0) acc += tiles[t0].sum;   // hit on the tile's first sample: its sum is the remainder
     } else {
@@ -489,7 +510,7 @@ int launch_amp_stats(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, float thre
                            threshold, tiles, unpack_of(ctx));
         GJ_LAUNCH_CHECK(ctx);
     }
-    hipLaunchKernelGGL(amp_finalize_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_iq, nsamples, tiles, ntiles, d_out,
+    hipLaunchKernelGGL(amp_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, d_iq, nsamples, tiles, ntiles, d_out,
                        unpack_of(ctx));
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
@@ -1032,7 +1053,7 @@ int launch_stream_scan(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t c
         GJ_LAUNCH_CHECK(ctx);
     }
     // amplitude totals + the chunk-power edge cases (last chunk odd / without a complete pair)
-    hipLaunchKernelGGL(amp_finalize_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_iq, nsamples, tiles, ntiles, d_amp,
+    hipLaunchKernelGGL(amp_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, d_iq, nsamples, tiles, ntiles, d_amp,
                        unpack_of(ctx), d_power, nchunks, nbytes, chunk_bytes, flags);
     GJ_LAUNCH_CHECK(ctx);
     if (valid) {

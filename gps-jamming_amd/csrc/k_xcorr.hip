@@ -212,17 +212,20 @@ __global__ __launch_bounds__(kBlockThreads) void xc_rows_kernel(XcParams P, cons
     }
 }
 
-// One pair only (the per-stream pipeline: this capture against the reference slice): the two
-// forward row transforms, the product conj(Z_j) Z_i and the inverse row transform of row k1 in ONE
-// kernel -- the spectra never go back to memory, one launch less on the tail after K2.
+// Few pairs (the per-stream pipeline: a rank's share of the antenna pairs): per pair the two forward row
+// transforms, the product conj(Z_j) Z_i and the inverse row transform of row k1 in ONE kernel (grid.y = pair) --
+// the row spectra never go to memory and there is one launch less on the chain that runs beside K2, where
+// every kernel waits for K2 workgroups to leave.  An antenna in several pairs is transformed once per pair:
+// used while 3 P <= 2 (A + P), i.e. P <= 2 A.
 __global__ __launch_bounds__(kBlockThreads) void xc_rows_pair_kernel(XcParams P, const cf* __restrict__ twtab,
                                                                      const cf* __restrict__ spec, cf* __restrict__ dbuf) {
     constexpr int N = kRow, TF = N / 16;
     __shared__ cf lds[lds_span(kBlockPoints)];
     const int jl = threadIdx.x;
     const int r = blockIdx.x;   // k1
-    const cf* si = spec + (size_t)P.pair_i[0] * P.L + (size_t)r * N;
-    const cf* sj = spec + (size_t)P.pair_j[0] * P.L + (size_t)r * N;
+    const int p = blockIdx.y;   // pair
+    const cf* si = spec + (size_t)P.pair_i[p] * P.L + (size_t)r * N;
+    const cf* sj = spec + (size_t)P.pair_j[p] * P.L + (size_t)r * N;
     c2 vi[16], vj[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) vi[s] = to_c2(si[jl + TF * s]);
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(kBlockThreads) void xc_rows_pair_kernel(XcParams P,
         vi[s] = make_c2(a.x * bb.x + a.y * bb.y, a.x * bb.y - a.y * bb.x);
     }
     xc_passes<N, 0>(vi, lds, 0, jl, twtab);
-    cf* dst = dbuf + (size_t)r * N;
+    cf* dst = dbuf + (size_t)p * P.L + (size_t)r * N;
     c2 w = twiddle_big((unsigned long long)r * jl, P.L);
     const c2 step = twiddle_big(((unsigned long long)r * TF) & (P.L - 1), P.L);
 #pragma unroll
@@ -350,9 +353,9 @@ int launch_xcorr(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, 
     GJ_LAUNCH_CHECK(ctx);
     xc_cols(ctx, 0, P, n_ant, eff, valid, spec, nullptr);
     GJ_LAUNCH_CHECK(ctx);
-    if (n_pairs == 1) {
-        hipLaunchKernelGGL(xc_rows_pair_kernel, dim3((unsigned)P.L1), dim3(kBlockThreads), 0, ctx->stream, P, ctx->d_twiddle,
-                           spec, dbuf);
+    if (n_pairs <= 2 * n_ant) {
+        hipLaunchKernelGGL(xc_rows_pair_kernel, dim3((unsigned)P.L1, (unsigned)n_pairs), dim3(kBlockThreads), 0, ctx->stream,
+                           P, ctx->d_twiddle, spec, dbuf);
         GJ_LAUNCH_CHECK(ctx);
     } else {
         hipLaunchKernelGGL((xc_rows_kernel<0>), dim3((unsigned)P.L1, (unsigned)n_ant), dim3(kBlockThreads), 0, ctx->stream,
