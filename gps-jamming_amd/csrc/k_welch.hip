@@ -61,6 +61,11 @@
 // runs beside it on the second stream otherwise take issue slots away from it one for one.
 #define GJ_W_PRIO 0
 #endif
+#ifndef GJ_W_RAWREUSE
+// 1: (one transform per workgroup) the raw samples of a segment's second half are kept as the next segment's first
+// half -- eight register moves instead of eight of the sixteen 2-byte loads per step
+#define GJ_W_RAWREUSE 0
+#endif
 #ifndef GJ_W_SCANSUMS
 // feasibility prototype (timing only, tools/ab_build.sh): per step also sum |z|^2 and |z| over the NEW half segment
 // (what K1 / K3 / K4 need), reduce per wave and store -- "K2 as the one reader of the capture", DESIGN section 4
@@ -295,7 +300,23 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
                 v[s] = (s & 1) ? fma_hi(f, w2p[s >> 1], wcp[s >> 1]) : fma_lo(f, w2p[s >> 1], wcp[s >> 1]);
             if (!HS || s >= 8) fsum = cadd(fsum, f);
         }
-        if (GJ_W_PREFETCH) load_step(raw, (seg + B < seg_hi) ? seg + B : seg_lo);
+        if constexpr (GJ_W_PREFETCH && GJ_W_RAWREUSE && HS) {
+            const unsigned nseg_idx = (seg + B < seg_hi) ? seg + B : seg_lo;
+            const bool consecutive = seg + B < seg_hi;
+            const unsigned byte0 = (nseg_idx * (unsigned)(N / 2) + (unsigned)jl0) * 2u;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) raw[s] = raw[s + 8];
+            if (!consecutive) {   // wrap to the dummy segment: its first half must be loaded after all (values unused)
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                    raw[s] = GJ_LOAD_RAW(*reinterpret_cast<const uint16_t*>(chunk8 + (byte0 + 2u * TF * s)));
+            }
+#pragma unroll
+            for (int s = 8; s < 16; ++s)
+                raw[s] = GJ_LOAD_RAW(*reinterpret_cast<const uint16_t*>(chunk8 + (byte0 + 2u * TF * s)));
+        } else if (GJ_W_PREFETCH) {
+            load_step(raw, (seg + B < seg_hi) ? seg + B : seg_lo);
+        }
         float si, sq;
         if constexpr (TF >= 64) {
             si = group_sum_dpp_f<64>(fsum.x);   // wave-uniform
