@@ -404,7 +404,7 @@ def valu_roofline(pmc, welch_ms, solo_ms):
 
 def end_to_end(np, dev, cap, nbytes):
     """File / host buffer -> results, wall clock, PCIe included (never `value`): one upload of the
-    capture (pinned bounce buffers, four fill threads) + scan + threshold + Welch + the D2H of the
+    capture (pinned bounce buffers, eight fill threads) + scan + threshold + Welch + the D2H of the
     power map and the PSD rows.  The file leg reads a scratch copy of the same capture."""
     import tempfile
     import gpsjam
@@ -424,7 +424,7 @@ def end_to_end(np, dev, cap, nbytes):
         assert pm.size and psd.size and st.count and on.start_index
         return t1 - t0, t2 - t0
 
-    run(host[:1 << 26])                                     # pinned buffers allocated, code paths warm
+    run(host[:min(nbytes, 1 << 28)])                        # every fill thread's pinned buffers allocated, code paths warm
     up, tot = run(host)
     out["host_buffer"] = {"upload_ms": up * 1e3, "total_ms": tot * 1e3, "upload_GBps": nbytes / up / 1e9,
                           "msamples_per_s": nbytes / 2 / tot / 1e6}

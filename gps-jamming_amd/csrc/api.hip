@@ -430,7 +430,19 @@ constexpr size_t kPinThreshold = 64u << 20;
 // host threads (8) each copy their share of 16-MiB pieces into their own pair of pinned buffers and
 // queue the DMA (one memcpy thread tops out at ~31 GB/s end to end, below what the link carries;
 // pread out of the page cache needs the extra threads more than memcpy does).
-constexpr int kFillThreads = gj_ctx::kPinBufs / 2;
+constexpr int kMaxFillThreads = gj_ctx::kPinBufs / 2;
+
+// fill threads of one staged copy: GPSJAM_FILL_THREADS (1..16), default 8
+static int fill_threads() {
+    static const int n = [] {
+        const char* e = getenv("GPSJAM_FILL_THREADS");
+        int v = e ? atoi(e) : 8;
+        if (v < 1) v = 1;
+        if (v > kMaxFillThreads) v = kMaxFillThreads;
+        return v;
+    }();
+    return n;
+}
 
 // `fill(dst, off, len)` puts bytes [off, off+len) of the source into a pinned buffer: memcpy from a
 // numpy array, or pread from a capture file (then the file goes page cache -> pinned -> HBM with no
@@ -438,12 +450,12 @@ constexpr int kFillThreads = gj_ctx::kPinBufs / 2;
 template <typename Fill>
 static int staged_copy(gj_ctx* ctx, unsigned char* d_dst, size_t nbytes, Fill&& fill) {
     if (nbytes == 0) return GJ_OK;
-    for (int k = 0; k < gj_ctx::kPinBufs; ++k) {
+    const size_t npieces = (nbytes + kPinBytes - 1) / kPinBytes;
+    const int nthreads = (int)(npieces < (size_t)fill_threads() ? npieces : (size_t)fill_threads());
+    for (int k = 0; k < 2 * nthreads; ++k) {   // two bounce buffers per fill thread, made on first use
         if (!ctx->pin[k]) GJ_HIP(ctx, hipHostMalloc(&ctx->pin[k], kPinBytes, hipHostMallocDefault));
         if (!ctx->pin_ev[k]) GJ_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_ev[k], hipEventDisableTiming));
     }
-    const size_t npieces = (nbytes + kPinBytes - 1) / kPinBytes;
-    const int nthreads = (int)(npieces < (size_t)kFillThreads ? npieces : (size_t)kFillThreads);
     std::atomic<int> failed{0};
     auto worker = [&](int t) {
         if (hipSetDevice(ctx->device) != hipSuccess) { failed.store(1); return; }
@@ -536,13 +548,26 @@ int gj_upload_file(gj_ctx* ctx, const char* path, size_t offset, size_t max_byte
         close(fd);
         return fail(ctx, GJ_ERR_NOMEM, "hipMalloc(%zu)", nbytes);
     }
-    // Page-cache pages are mapped and copied in user space (the fill threads' memcpy runs at the host-buffer
-    // rate; pread's kernel-side copy reached 13-15 GB/s with eight threads on these hosts); pread remains the
-    // path for files that cannot be mapped.
+    // Two ways from the page cache into the pinned bounce buffers (tools/ingest_bench.py, tools/ingest_probe.cpp,
+    // profiles/r02_ingest.txt; 1 GiB in /dev/shm):
+    //  * mapping the file and copying in user space: 35-42 ms, of which 15-20 ms is the final munmap -- the same
+    //    whether the file has been read before or not.  Handing the munmap to a helper thread makes the call return
+    //    after 22 ms (49 GB/s) but the kernels and copies that follow then wait on the driver's MMU notifiers for
+    //    longer than the munmap took (file -> results 54-61 ms instead of 40), so it stays in the call;
+    //  * pread into the pinned buffers: 22-29 ms (37-48 GB/s) on a file that has been read before, but 75-100 ms on
+    //    the FIRST read of a freshly written one: the second touch of a page moves it to the active list, and eight
+    //    threads doing that fight over the LRU lock (the mapped path pays the same move inside munmap, from one
+    //    thread, uncontended).
+    // A capture is normally read once, soon after it was recorded, so mapping is the default; GPSJAM_FILE_READ=pread
+    // selects the other, which is also what a file that cannot be mapped gets.
     int rc = GJ_OK;
-    const long page = sysconf(_SC_PAGESIZE);
-    const size_t map_off = offset / (size_t)page * (size_t)page, lead = offset - map_off;
-    void* m = nbytes ? mmap(nullptr, nbytes + lead, PROT_READ, MAP_PRIVATE, fd, (off_t)map_off) : MAP_FAILED;
+    static const bool want_pread = [] {
+        const char* e = getenv("GPSJAM_FILE_READ");
+        return e && strcmp(e, "pread") == 0;
+    }();
+    const size_t pg = (size_t)sysconf(_SC_PAGESIZE);
+    const size_t map_off = offset / pg * pg, lead = offset - map_off;
+    void* m = (nbytes && !want_pread) ? mmap(nullptr, nbytes + lead, PROT_READ, MAP_PRIVATE, fd, (off_t)map_off) : MAP_FAILED;
     if (m != MAP_FAILED) {
         (void)madvise(m, nbytes + lead, MADV_SEQUENTIAL);
         const unsigned char* src = static_cast<const unsigned char*>(m) + lead;
@@ -550,9 +575,9 @@ int gj_upload_file(gj_ctx* ctx, const char* path, size_t offset, size_t max_byte
             memcpy(dst, src + off, len);
             return true;
         });
-        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, GJ_ERR_HIP, "upload failed");
         (void)munmap(m, nbytes + lead);
     } else {
+        (void)posix_fadvise(fd, 0, 0, POSIX_FADV_NOREUSE);   // regular file systems (Linux >= 6.3): no LRU promotion on read
         rc = staged_copy(ctx, static_cast<unsigned char*>(p), nbytes, [fd, offset](unsigned char* dst, size_t off, size_t len) {
             size_t done = 0;
             while (done < len) {

@@ -22,7 +22,7 @@ struct gj_ctx {
     size_t ws_bytes = 0;
     unsigned char* stage = nullptr;   // grow-only device staging for the host-buffer entry points
     size_t stage_bytes = 0;
-    static constexpr int kPinBufs = 16;   // pinned bounce buffers of the host-buffer entry points (2 per fill thread)
+    static constexpr int kPinBufs = 32;   // pinned bounce buffers of the host-buffer entry points (2 per fill thread)
     void* pin[kPinBufs] = {};
     hipEvent_t pin_ev[kPinBufs] = {};
     // unpack convention (gj_set_unpack): sample = (u8 - offset) * scale; off2 = 2 * offset is an integer

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(1024) void acq_check_kernel(AcqParams P, int step, 
     AcqBest b{-1.0, 0x7fffffff};
     for (int i = threadIdx.x; i < total; i += blockDim.x) b = acq_better(b, AcqBest{pw[i], i});
     b = acq_block_best(b, sh);
+    if (b.idx >= total) b.idx = 0;          // only if every power were NaN
     const int codei = b.idx % P.nsamp, freqi = b.idx / P.nsamp;
     int exinds = codei - 2 * nsampchip, exinde = codei + 2 * nsampchip;
     if (exinds < 0) exinds += P.nsamp;
@@ -345,6 +346,7 @@ __global__ __launch_bounds__(64) void acq_summary_kernel(AcqParams P, double cti
             o.idx = __shfl_xor(b.idx, off, 64);
             b = acq_better(b, o);
         }
+        if (b.idx >= P.n_freq) b.idx = 0;   // only if every row maximum were NaN
         const AcqRow w = rr[b.idx];
         const double meanP = w.sum / (double)w.cnt;
         const double peakr = w.maxv / w.max2;

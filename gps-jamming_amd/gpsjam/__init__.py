@@ -58,7 +58,7 @@ _resident_lock = __import__("threading").Lock()
 def resident_capture(path) -> "Capture":
     """The capture file ``path`` in HBM on the default device, uploaded on first use and kept
     (process-wide, least-recently-used eviction above GPSJAM_RESIDENT_GIB, default 64 of the
-    288 GB): the worker's power scan, the RSSI solver and the PSD script all read the same
+    288 GB; an evicted capture is freed once nobody holds it any more): the worker's power scan, the RSSI solver and the PSD script all read the same
     files (worker.py:209-217 -> :590-600 -> triangulateRSSI.py:29), and each used to pay its own
     host->device pass.  Raises FileNotFoundError like open()."""
     import os
@@ -72,7 +72,9 @@ def resident_capture(path) -> "Capture":
             return cap
         limit = int(float(os.environ.get("GPSJAM_RESIDENT_GIB", "64")) * (1 << 30))
         while _resident and sum(c.nbytes for c in _resident.values()) + st.st_size > limit:
-            _resident.pop(next(iter(_resident))).free()
+            # eviction only drops the cache's reference: a caller that still holds the Capture (a scan
+            # running in another thread) keeps it alive, and its memory is freed when that reference goes
+            _resident.pop(next(iter(_resident)))
         cap = dev.capture(path)
         _resident[key] = cap
         return cap

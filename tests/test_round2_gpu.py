@@ -119,6 +119,27 @@ def test_resident_capture_cache_one_upload_per_file(tmp_path, monkeypatch):
     gpsjam.release_resident()
 
 
+def test_resident_capture_eviction_keeps_held_captures_alive(tmp_path, monkeypatch):
+    """Above GPSJAM_RESIDENT_GIB the cache lets go of the least recently used capture, but a caller that
+    still holds it (a scan in another thread) keeps valid memory; it is freed with its last reference."""
+    monkeypatch.setattr(gpsjam, "_default", None)
+    gpsjam.release_resident()
+    monkeypatch.setenv("GPSJAM_RESIDENT_GIB", str(300000 / (1 << 30)))          # room for one 200 kB file
+    paths = []
+    for k in range(2):
+        p = tmp_path / f"e{k}.bin"
+        np.full(200000, 10 + k, np.uint8).tofile(p)
+        paths.append(str(p))
+    a = gpsjam.resident_capture(paths[0])
+    b = gpsjam.resident_capture(paths[1])                                      # evicts a from the cache
+    assert len(gpsjam._resident) == 1 and a.ptr and b.ptr
+    assert a.download(0, 4).tolist() == [10] * 4 and b.download(0, 4).tolist() == [11] * 4
+    np.testing.assert_array_equal(a.dev.chunk_power(a), a.dev.chunk_power(np.full(200000, 10, np.uint8)))
+    before = gpsjam.Capture.uploads
+    assert gpsjam.resident_capture(paths[0]) is not a and gpsjam.Capture.uploads == before + 1
+    gpsjam.release_resident()
+
+
 # ----------------------------------------------------------------------------- TDOA slots
 def test_slots_equal_separate_slices(dev):
     n, sl = 500000, 50000                                    # the reference's own slice size (L = 2^17)
