@@ -238,22 +238,34 @@ struct AcqRow {
     int argk, cnt;
 };
 
+// Reduction over the TF = N / 16 threads of one transform.  Inside a wave: four DPP steps per row of sixteen lanes
+// (quad_perm swaps, row_half_mirror, row_mirror -- plain VALU moves, no ds_bpermute round trip per step), then the
+// four row results through v_readlane (wave-uniform).  N >= 2048: the transform's waves meet through `sh` with ONE
+// barrier -- each of the two reductions of a step has its own `sh`, and between two uses of it lie the other
+// reduction's barrier and those of the exchanges; the barrier also orders the last gather of the X4096 exchange
+// before the next step's first scatter.
+__device__ __forceinline__ int acq_dpp(int v, int ctrl_sel) {
+    switch (ctrl_sel) {
+        case 0: return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+        case 1: return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+        case 2: return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);   // row_half_mirror
+        default: return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
+    }
+}
+__device__ __forceinline__ double acq_dpp(double v, int ctrl_sel) {
+    return __hiloint2double(acq_dpp(__double2hiint(v), ctrl_sel), acq_dpp(__double2loint(v), ctrl_sel));
+}
+__device__ __forceinline__ double acq_lane(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
 template <int N, typename T, typename F>
 __device__ __forceinline__ T acq_group_reduce(T v, F&& op, T* sh /* [kBlockThreads / 64] */, int b) {
     constexpr int TF = N / 16, WPF = TF / 64;   // waves per transform (N >= 1024)
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        T o;
-        if constexpr (sizeof(T) == 16) {
-            o.val = __shfl_xor(v.val, off, 64);
-            o.idx = __shfl_xor(v.idx, off, 64);
-        } else {
-            o = __shfl_xor(v, off, 64);
-        }
-        v = op(v, o);
-    }
+    for (int k = 0; k < 4; ++k) v = op(v, v.moved(k));
+    v = op(op(v.lane(0), v.lane(16)), op(v.lane(32), v.lane(48)));
     if constexpr (WPF == 1) return v;
-    __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
     T r = sh[b * WPF];
@@ -262,21 +274,74 @@ __device__ __forceinline__ T acq_group_reduce(T v, F&& op, T* sh /* [kBlockThrea
     return r;
 }
 
+struct AcqBestS : AcqBest {
+    __device__ __forceinline__ AcqBestS moved(int k) const {
+        AcqBestS o;
+        o.val = acq_dpp(val, k);
+        o.idx = acq_dpp(idx, k);
+        return o;
+    }
+    __device__ __forceinline__ AcqBestS lane(int l) const {
+        AcqBestS o;
+        o.val = acq_lane(val, l);
+        o.idx = __builtin_amdgcn_readlane(idx, l);
+        return o;
+    }
+};
+struct AcqTail {   // what checkacquisition takes from the rest of the row: meanvd's sum and maxvd's second peak
+    double sum, mx2;
+    __device__ __forceinline__ AcqTail moved(int k) const { return AcqTail{acq_dpp(sum, k), acq_dpp(mx2, k)}; }
+    __device__ __forceinline__ AcqTail lane(int l) const { return AcqTail{acq_lane(sum, l), acq_lane(mx2, l)}; }
+};
+
+// The three passes of one transform for the single-launch kernel.  N = 4096 takes the bank-conflict-free X4096
+// schedule of fft_core.h (thread tid transforms inputs tid + 256 s in pass 0 and ends up holding bins
+// jl1(tid) + 256 s); the barrier behind the last gather is left to the reductions that follow.
+template <int N>
+__device__ __forceinline__ void acq_transform(c2 (&v)[16], cf* lds, int tid, int base, int jl, const c2 (&tw)[3][15]) {
+    if constexpr (N == 4096) {
+        const InnerTw k = inner_twiddles();
+        fft_pass<4096, 0, false, true>(v, tw[0], k);
+        x4096_scatter<0>(v, lds, tid);
+        __syncthreads();
+        x4096_gather<0>(v, lds, tid);
+        __syncthreads();
+        fft_pass<4096, 1, false, true>(v, tw[1], k);
+        x4096_scatter<1>(v, lds, tid);
+        __syncthreads();
+        x4096_gather<1>(v, lds, tid);
+        fft_pass<4096, 2, false, true>(v, tw[2], k);
+    } else {
+        acq_passes_tw<N, 0>(v, lds, base, jl, tw);
+    }
+}
+
+// Grid: 8 x n_prn x ceil(groups / 8) workgroups, a group = the kBlockPoints / N Doppler bins one workgroup transforms
+// together.  Workgroups b and b + 8 share an XCD and its 4-MiB L2 (observed placement; a speed matter only): the bins
+// are dealt over the eight residues of b and the PRN runs fastest inside a residue, so the ~96 workgroups an XCD holds
+// at a time read the same three bins' data spectra (10 steps x 32 KB each) and the 1 MB of code spectra out of their
+// own L2 instead of each XCD streaming all 23 MB of data spectra from the Infinity Cache.
 template <int N>
 __global__ __launch_bounds__(kBlockThreads, 3) void acq_inv_all_kernel(AcqParams P, int nsampchip, const cf* __restrict__ twtab,
                                                                     const cf* __restrict__ xspec,
                                                                     const cf* __restrict__ cspec,
                                                                     AcqRow* __restrict__ rows /* [n_prn][intg][n_freq] */) {
     constexpr int TF = N / 16, B = kBlockPoints / N;
-    __shared__ cf lds[B * lds_span(N)];
-    __shared__ AcqBest shb[kBlockThreads / 64];
-    __shared__ double shd[kBlockThreads / 64];
-    __shared__ int shi[kBlockThreads / 64];
-    const int p = blockIdx.y;
-    const int tid = threadIdx.x, b = tid / TF, jl = tid % TF;
-    const int f = blockIdx.x * B + b;
+    constexpr bool XP = N == 4096;
+    __shared__ cf lds[XP ? X4096::kSpan : B * lds_span(N)];
+    __shared__ AcqBestS shb[kBlockThreads / 64];
+    __shared__ AcqTail sht[kBlockThreads / 64];
+    const int slot = blockIdx.x >> 3;
+    const int p = slot % P.n_prn, fg = (int)(blockIdx.x & 7) + 8 * (slot / P.n_prn);
+    if (fg * B >= P.n_freq) return;            // the whole workgroup: the grid is padded to a multiple of eight groups
+    const int tid = threadIdx.x, b = tid / TF, jl0 = tid % TF;
+    const int jl = XP ? X4096::jl1(tid) : jl0;   // butterfly of the later passes = the bins jl + TF s held at the end
+    const int f = fg * B + b;
     const bool live = f < P.n_freq;
-    const cf* c = cspec + (size_t)p * N;   // 32 KB per PRN, re-read every step: L2-resident, and 32 VGPRs cheaper than a copy
+    // 32 KB per PRN, re-read every step out of L2.  Keeping it in registers together with a prefetch of the next
+    // step's data spectrum needs 228 VGPRs = two workgroups per CU: 0.245 ms per search against 0.236 this way
+    // (2 272 workgroups are 2.96 rounds of 768 slots, but 4.44 rounds of 512)
+    const cf* c = cspec + (size_t)p * N;
     c2 tw[3][15];
 #pragma unroll
     for (int k = 0; k < 15; ++k) tw[0][k] = tw[1][k] = tw[2][k] = make_c2(1.f, 0.f);
@@ -285,45 +350,51 @@ __global__ __launch_bounds__(kBlockThreads, 3) void acq_inv_all_kernel(AcqParams
     double acc[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) acc[s] = 0.0;
+    // every index outside the +-2-chip zone around the peak counts towards the mean: nsamp - (4 nsampchip + 1) of them,
+    // wrapped or not (launch_acq_search checks 4 nsampchip < nsamp)
+    const int cnt = P.nsamp - 4 * nsampchip - 1;
     for (int step = 0; step < P.intg; ++step) {
-        const cf* x = xspec + ((size_t)step * P.n_freq + (live ? f : 0)) * N;
         c2 v[16];
+        const cf* x = xspec + ((size_t)step * P.n_freq + (live ? f : 0)) * N;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const cf a = x[jl + TF * s], q = c[jl + TF * s];
+            const cf a = x[jl0 + TF * s], q = c[jl0 + TF * s];
             v[s] = make_c2(-a.x * q.x - a.y * q.y, -(a.x * q.y - a.y * q.x));   // as in acq_inv_kernel
         }
-        acq_passes_tw<N, 0>(v, lds, b * lds_span(N), jl, tw);
-        AcqBest best{-1.0, 0x7fffffff};
+        acq_transform<N>(v, lds, tid, b * lds_span(N), jl, tw);
+        AcqBestS best;
+        best.val = -1.0;
+        best.idx = 0x7fffffff;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             acc[s] += (double)((v[s].x * v[s].x + v[s].y * v[s].y) * P.inv_m2);
-            best = acq_better(best, AcqBest{acc[s], jl + TF * s});
+            if (acc[s] > best.val) { best.val = acc[s]; best.idx = jl + TF * s; }   // indices rise with s: '>' keeps the first
         }
-        best = acq_group_reduce<N>(best, [](AcqBest a, AcqBest o) { return acq_better(a, o); }, shb, b);
+#ifdef GJ_ACQ_ABLATE_CHECK   // timing only (tools/ab_build.sh): no peak bookkeeping at all
+        if (step + 1 == P.intg && live && jl == 0) rows[((size_t)p * P.intg + step) * P.n_freq + f].maxv = best.val;
+        continue;
+#endif
+        best = acq_group_reduce<N>(best, [](AcqBestS a, AcqBestS o) {
+            return (o.val > a.val || (o.val == a.val && o.idx < a.idx)) ? o : a; }, shb, b);
         int exinds = best.idx - 2 * nsampchip, exinde = best.idx + 2 * nsampchip;
         if (exinds < 0) exinds += P.nsamp;
         if (exinde >= P.nsamp) exinde -= P.nsamp;
-        double sum = 0.0, mx2 = (jl == 0) ? acc[0] : -1.0;   // maxvd seeds with data[0] whatever the exclusion zone says
-        int cnt = 0;
+        AcqTail t{0.0, (jl == 0) ? acc[0] : -1.0};   // maxvd seeds with data[0] whatever the exclusion zone says
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int i = jl + TF * s;
             const bool kept = (exinds <= exinde) ? (i < exinds || i > exinde) : (i < exinds && i > exinde);
             if (kept) {
-                sum += acc[s];
-                ++cnt;
-                if (i >= 1) mx2 = acc[s] > mx2 ? acc[s] : mx2;
+                t.sum += acc[s];
+                if (i >= 1) t.mx2 = acc[s] > t.mx2 ? acc[s] : t.mx2;
             }
         }
-        sum = acq_group_reduce<N>(sum, [](double a, double o) { return a + o; }, shd, b);
-        mx2 = acq_group_reduce<N>(mx2, [](double a, double o) { return a > o ? a : o; }, shd, b);
-        cnt = acq_group_reduce<N>(cnt, [](int a, int o) { return a + o; }, shi, b);
+        t = acq_group_reduce<N>(t, [](AcqTail a, AcqTail o) { return AcqTail{a.sum + o.sum, a.mx2 > o.mx2 ? a.mx2 : o.mx2}; }, sht, b);
         if (live && jl == 0) {
             AcqRow r;
             r.maxv = best.val;
-            r.max2 = mx2;
-            r.sum = sum;
+            r.max2 = t.mx2;
+            r.sum = t.sum;
             r.argk = best.idx;
             r.cnt = cnt;
             rows[((size_t)p * P.intg + step) * P.n_freq + f] = r;
@@ -331,14 +402,18 @@ __global__ __launch_bounds__(kBlockThreads, 3) void acq_inv_all_kernel(AcqParams
     }
 }
 
-// the reference's loop over the integration steps (sdracq.c:15-28), replayed on the row records
-__global__ __launch_bounds__(64) void acq_summary_kernel(AcqParams P, double ctime, float threshold,
-                                                         const AcqRow* __restrict__ rows, gj_acq_result* __restrict__ out) {
-    const int p = blockIdx.x;
-    for (int step = 0; step < P.intg; ++step) {
+// the reference's loop over the integration steps (sdracq.c:15-28), replayed on the row records: wave w finds the
+// winning Doppler row of steps w, w + 16, ... (their loads are in flight together), then one thread walks the steps
+// in order and stops at the first that passes the peak test
+__global__ __launch_bounds__(1024) void acq_summary_kernel(AcqParams P, double ctime, float threshold,
+                                                           const AcqRow* __restrict__ rows, gj_acq_result* __restrict__ out) {
+    __shared__ AcqRow win[64];     // intg <= 64 (launch_acq_search)
+    __shared__ int winf[64];
+    const int p = blockIdx.x, lane = threadIdx.x & 63;
+    for (int step = threadIdx.x >> 6; step < P.intg; step += blockDim.x >> 6) {
         const AcqRow* rr = rows + ((size_t)p * P.intg + step) * P.n_freq;
         AcqBest b{-1.0, 0x7fffffff};   // idx = Doppler row; equal maxima: the smaller flat index = the smaller row
-        for (int f = threadIdx.x; f < P.n_freq; f += 64) b = acq_better(b, AcqBest{rr[f].maxv, f});
+        for (int f = lane; f < P.n_freq; f += 64) b = acq_better(b, AcqBest{rr[f].maxv, f});
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             AcqBest o;
@@ -347,24 +422,30 @@ __global__ __launch_bounds__(64) void acq_summary_kernel(AcqParams P, double cti
             b = acq_better(b, o);
         }
         if (b.idx >= P.n_freq) b.idx = 0;   // only if every row maximum were NaN
-        const AcqRow w = rr[b.idx];
+        if (lane == 0) {
+            win[step] = rr[b.idx];
+            winf[step] = b.idx;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int step = 0; step < P.intg; ++step) {
+        const AcqRow w = win[step];
         const double meanP = w.sum / (double)w.cnt;
         const double peakr = w.maxv / w.max2;
         const bool acquired = peakr > (double)threshold;
         if (acquired || step + 1 == P.intg) {
-            if (threadIdx.x == 0) {
-                gj_acq_result r;
-                r.max_power = w.maxv;
-                r.second_power = w.max2;
-                r.mean_power = meanP;
-                r.peak_ratio = peakr;
-                r.cn0 = 10.0 * log10(w.maxv / meanP / ctime);
-                r.code_index = w.argk;
-                r.freq_index = b.idx;
-                r.steps = step + 1;
-                r.acquired = acquired ? 1 : 0;
-                out[p] = r;
-            }
+            gj_acq_result r;
+            r.max_power = w.maxv;
+            r.second_power = w.max2;
+            r.mean_power = meanP;
+            r.peak_ratio = peakr;
+            r.cn0 = 10.0 * log10(w.maxv / meanP / ctime);
+            r.code_index = w.argk;
+            r.freq_index = winf[step];
+            r.steps = step + 1;
+            r.acquired = acquired ? 1 : 0;
+            out[p] = r;
             return;
         }
     }
@@ -392,7 +473,6 @@ static int acq_run(gj_ctx* ctx, const AcqParams& P, const short* d_codes, const 
     w += align_up((size_t)P.n_prn * N * sizeof(cf), 256);
     cf* xspec = reinterpret_cast<cf*>(w);
     w += align_up((size_t)P.intg * P.n_freq * N * sizeof(cf), 256);
-    GJ_HIP(ctx, hipMemsetAsync(d_out, 0, (size_t)P.n_prn * sizeof(gj_acq_result), ctx->stream));
     hipLaunchKernelGGL((acq_code_kernel<N>), dim3((unsigned)((P.n_prn + B - 1) / B)), dim3(kBlockThreads), 0, ctx->stream,
                        d_codes, P.nsamp, P.n_prn, ctx->d_twiddle, cspec);
     GJ_LAUNCH_CHECK(ctx);
@@ -401,16 +481,19 @@ static int acq_run(gj_ctx* ctx, const AcqParams& P, const short* d_codes, const 
     GJ_LAUNCH_CHECK(ctx);
     if (!d_power) {
         AcqRow* rows = reinterpret_cast<AcqRow*>(w);
-        hipLaunchKernelGGL((acq_inv_all_kernel<N>), dim3((unsigned)((P.n_freq + B - 1) / B), (unsigned)P.n_prn),
-                           dim3(kBlockThreads), 0, ctx->stream, P, nsampchip, ctx->d_twiddle, xspec, cspec, rows);
+        const unsigned groups = (unsigned)((P.n_freq + B - 1) / B);
+        hipLaunchKernelGGL((acq_inv_all_kernel<N>), dim3(8u * (unsigned)P.n_prn * ((groups + 7u) / 8u)), dim3(kBlockThreads), 0,
+                           ctx->stream, P, nsampchip, ctx->d_twiddle, xspec, cspec, rows);
         GJ_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(acq_summary_kernel, dim3((unsigned)P.n_prn), dim3(64), 0, ctx->stream, P, ctime, threshold, rows,
-                           d_out);
+        const unsigned waves = (unsigned)(P.intg < 16 ? P.intg : 16);
+        hipLaunchKernelGGL(acq_summary_kernel, dim3((unsigned)P.n_prn), dim3(64u * waves), 0, ctx->stream, P, ctime, threshold,
+                           rows, d_out);   // writes every PRN's record
         GJ_LAUNCH_CHECK(ctx);
         return GJ_OK;
     }
     // the caller wants the power array: step by step, P in memory, a PRN's rows frozen when it acquires
     double* power = d_power;
+    GJ_HIP(ctx, hipMemsetAsync(d_out, 0, (size_t)P.n_prn * sizeof(gj_acq_result), ctx->stream));
     GJ_HIP(ctx, hipMemsetAsync(done, 0, (size_t)P.n_prn * sizeof(int), ctx->stream));
     GJ_HIP(ctx, hipMemsetAsync(power, 0, (size_t)P.n_prn * P.n_freq * P.nsamp * sizeof(double), ctx->stream));   // calloc, sdrmain.c:346
     for (int step = 0; step < P.intg; ++step) {
