@@ -101,10 +101,12 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        import datetime
+        limit = datetime.timedelta(seconds=300)   # a collective that never completes must end the run, not hang it
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
         else:
-            dist.init_process_group(backend=args.backend)
+            dist.init_process_group(backend=args.backend, timeout=limit)
 
     dev = gpsjam.Device(local_rank)
     # one explicit HIP stream for everything in the step: the gpsjam kernels, torch's small

@@ -9,8 +9,13 @@ w = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]
 t0 = w[0][0]
 k2 = [(a - t0, b - a) for a, b, n, q in w if "welch_kernel<" in n]
 print("K2 durations (us):", [round(d / 1e3) for _, d in k2])
-if len(k2) >= 8:
-    start, stop = k2[-8][0] - 50000, k2[-7][0] - 50000
+# the last K2 launch of a pipeline step = the last one a fused scan starts beside (the solo timings that bench.py takes
+# afterwards have nothing next to them)
+scans = [a - t0 for a, b, n, q in w if "stream_scan_kernel" in n]
+steps = [i for i, (a, d) in enumerate(k2) if any(a - 200000 <= s < a + d for s in scans)]
+if len(steps) >= 3:
+    i = steps[-2]
+    start, stop = k2[i][0] - 50000, k2[i + 1][0] - 50000
     for a, b, n, q in w:
         if start <= a - t0 < stop:
             print(f"{(a - t0 - start) / 1e3:9.1f} us +{(b - a) / 1e3:8.1f}  q{q} {n}")
