@@ -112,3 +112,31 @@ def test_extreme_k5_lags(dev, name):
         np.testing.assert_allclose(peaks[0], pk01, rtol=1e-4)
     else:
         np.testing.assert_allclose(margins, 1.0 / n, rtol=0.02)
+
+
+@pytest.mark.parametrize("name", list(CAPTURES))
+def test_extreme_fused_scan(dev, name):
+    """The one-pass scan of the pipeline (gj_stream_scan_dev) on the same captures: power map, amplitude statistics and
+    onset as from K1 / K3 / K4 alone and as the oracle has them."""
+    raw = CAPTURES[name]
+    nbytes, chunk = raw.size, 65536
+    buf = dev.alloc(nbytes).upload(raw)
+    nch = dev.chunk_count(nbytes, chunk)
+    z = orc.tdoa_unpack(raw)
+    for thr, (noise, window, factor) in ((0.0, (200000, 1000, 50.0)), (1.2, (1000, 64, 3.0))):
+        d_pow, d_amp, d_on = dev.alloc(4 * nch), dev.alloc(32), dev.alloc(32)
+        dev.stream_scan_dev(buf, nbytes, chunk, d_pow, thr, d_amp, noise, window, factor, d_on)
+        dev.synchronize()
+        amp = np.frombuffer(d_amp.download(np.uint8).tobytes(), dtype=[("i", "<i8"), ("c", "<u8"), ("s", "<f8"),
+                                                                       ("m", "<f4"), ("r", "<f4")])[0]
+        np.testing.assert_allclose(d_pow.download(np.float32, nch), orc.chunk_power(raw, chunk), rtol=1e-6)
+        k, avg = orc.rssi_amp_stats(raw, thr)
+        if k is None:
+            assert amp["i"] == -1 and amp["c"] == 0, (name, thr)
+        else:
+            assert amp["i"] == k and amp["c"] == N - k, (name, thr)
+            np.testing.assert_allclose(amp["m"], avg, rtol=1e-6)
+        assert int(d_on.download(np.int64, 1)[0]) == orc.tdoa_onset(z, noise, window, factor), (name, noise, window)
+        for b in (d_pow, d_amp, d_on):
+            b.free()
+    buf.free()
