@@ -369,3 +369,25 @@ def test_unpack_convention_offset_128(dev):
     finally:
         dev.set_unpack()                                      # back to the reference's convention
     np.testing.assert_array_equal(dev.chunk_power(raw), ref_default)
+
+
+# ----------------------------------------------------------------------------- the binding shown in INTEGRATION.md
+def test_integration_md_ctypes_stub_runs():
+    """The minimal ctypes binding printed in INTEGRATION.md section B is executed as it stands (only the library path
+    is made absolute) and gives the oracle's numbers."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    start = text.index("```python\n# gpsjam_ffi.py") + len("```python\n")
+    code = text[start:text.index("```", start)]
+    assert 'C.CDLL("csrc/libgpsjam_hip.so")' in code
+    code = code.replace('"csrc/libgpsjam_hip.so"', repr(gpsjam.library_path()))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    raw = generate(StreamSpec(seed=8, jam_start=60000, jam_end=1 << 40, jam_sigma=55.0), 150001)
+    np.testing.assert_allclose(ns["chunk_power"](raw), orc.chunk_power(raw), rtol=1e-6)
+    k, avg = ns["amp_stats"](raw, 0.5)
+    want_k, want_avg = orc.rssi_amp_stats(raw, 0.5)
+    assert k == want_k
+    np.testing.assert_allclose(avg, want_avg, rtol=1e-6)
+    assert ns["amp_stats"](raw, 5.0) == (None, None)
+    ns["lib"].gj_destroy(ns["ctx"])
