@@ -1,6 +1,7 @@
 /* A plain C11 consumer of include/gpsjam.h (the reference's backend, gnssdec, is C): links
  * libgpsjam_hip.so, runs K1, K3 and K4 on a small deterministic capture through the host-buffer
- * entry points and checks them against the same arithmetic done here in integers/doubles.
+ * entry points and checks them against the same arithmetic done here in integers/doubles, then
+ * the device-resident per-stream flow with the library's own collectives.
  * Built and run by tests/test_c_abi_gpu.py (gcc, no HIP headers needed). */
 #include <math.h>
 #include <stdio.h>
@@ -82,6 +83,66 @@ int main(void) {
     if (gj_chunk_power_u8(ctx, iq, nbytes, chunk_bytes, 0.f, 0, power, nchunks - 1, &n_out, &ms) != GJ_ERR_CAPACITY) {
         fprintf(stderr, "capacity error not reported\n");
         return 1;
+    }
+    /* The per-stream flow of INTEGRATION.md section C from a host with no torch: resident capture, one-pass scan,
+     * Welch rows, TDOA slot, the library's own RCCL collectives (a communicator of one rank here), pair solve, result
+     * vector, gather.  With one antenna the only pair is (0, 0): lag 0. */
+    {
+        void *d_iq = NULL, *d_power = NULL, *d_stats = NULL, *d_amp = NULL, *d_on = NULL, *d_psd = NULL, *d_slot = NULL,
+             *d_slots = NULL, *d_pairs = NULL, *d_lags = NULL, *d_peaks = NULL, *d_margins = NULL, *d_res = NULL, *d_all = NULL;
+        const int nperseg = 1024;
+        const size_t chunk_samples = 100000, nslice = 50000;
+        const size_t rows = gj_welch_rows(nbytes, chunk_samples, nperseg), sb = gj_tdoa_slot_bytes(nslice);
+        const size_t rlen = GJ_RESULT_HEADER + nchunks + (size_t)nperseg + GJ_RESULT_PAIR_FIELDS * 1;
+        CHECK(gj_upload(ctx, iq, nbytes, &d_iq));
+        CHECK(gj_malloc(ctx, nchunks * 4, &d_power));
+        CHECK(gj_malloc(ctx, 16, &d_stats));
+        CHECK(gj_malloc(ctx, sizeof(gj_amp_stats), &d_amp));
+        CHECK(gj_malloc(ctx, sizeof(gj_onset), &d_on));
+        CHECK(gj_malloc(ctx, rows * nperseg * 4, &d_psd));
+        CHECK(gj_malloc(ctx, sb, &d_slot));
+        CHECK(gj_malloc(ctx, sb, &d_slots));
+        CHECK(gj_malloc(ctx, 8, &d_pairs));
+        CHECK(gj_malloc(ctx, 4, &d_lags));
+        CHECK(gj_malloc(ctx, 4, &d_peaks));
+        CHECK(gj_malloc(ctx, 4, &d_margins));
+        CHECK(gj_malloc(ctx, rlen * 8, &d_res));
+        CHECK(gj_malloc(ctx, rlen * 8, &d_all));
+        CHECK(gj_stream_scan_dev(ctx, d_iq, nbytes, chunk_bytes, 1e-10f, 0, d_power, 0.5f, d_amp, 200000, 1000, 50.0f, d_on));
+        CHECK(gj_power_threshold_dev(ctx, d_power, nchunks, 5.0f, 6.0f, d_stats, NULL));
+        CHECK(gj_welch_dev(ctx, d_iq, nbytes, chunk_samples, nperseg, 2.048e6, GJ_WELCH_SHIFT, d_psd, NULL));
+        CHECK(gj_tdoa_slot_dev(ctx, d_iq, nbytes, (const int64_t*)d_on /* &start_index */, nslice, d_slot));
+        unsigned char id[GJ_COMM_ID_BYTES];
+        gj_comm* comm = NULL;
+        const int rc_id = gj_comm_unique_id(id);
+        if (rc_id != GJ_OK) { fprintf(stderr, "gj_comm_unique_id -> %d (librccl missing?)\n", rc_id); return 2; }
+        CHECK(gj_comm_init_rank(ctx, id, 0, 1, &comm));
+        int r = -1, nr = -1;
+        CHECK(gj_comm_rank(comm, &r, &nr));
+        CHECK(gj_comm_allgather_dev(comm, d_slot, sb, d_slots));
+        const int32_t pair[2] = {0, 0};
+        CHECK(gj_memcpy_h2d(ctx, d_pairs, pair, sizeof(pair)));
+        CHECK(gj_xcorr_slots_dev(ctx, d_slots, sb, 1, nslice, pair, 1, d_lags, d_peaks, d_margins));
+        CHECK(gj_pack_result_dev(ctx, nchunks, d_power, d_stats, d_amp, d_on, d_psd, rows, nperseg, 0, 1, 1, d_pairs, d_lags,
+                                 d_peaks, d_margins, d_res));
+        CHECK(gj_comm_gather_dev(comm, d_res, rlen * 8, d_all, 0));
+        double* res = (double*)malloc(rlen * 8);
+        CHECK(gj_memcpy_d2h(ctx, res, d_all, rlen * 8));
+        const double* blk = res + GJ_RESULT_HEADER + nchunks + nperseg;
+        int bad = r != 0 || nr != 1 || res[0] != (double)nchunks || res[4] != (double)st.first_index ||
+                  res[5] != (double)st.count || res[7] != (double)on.start_index || res[11] != (double)rows ||
+                  res[12] != (double)nperseg || res[13] != 0.0 || res[14] != 1.0 || res[15] != 1.0 || blk[0] != 0.0 ||
+                  blk[1] != 0.0 || blk[2] != 0.0 /* lag of a slice against itself */ || !(blk[3] > 0.0);
+        for (size_t c = 0; c < nchunks && !bad; ++c) bad = (float)res[GJ_RESULT_HEADER + c] != power[c];
+        if (bad) {
+            fprintf(stderr, "result vector: n %g first %g count %g onset %g rows %g nperseg %g rank %g pairs %g/%g lag %g peak %g\n",
+                    res[0], res[4], res[5], res[7], res[11], res[12], res[13], res[14], res[15], blk[2], blk[3]);
+            return 1;
+        }
+        free(res);
+        CHECK(gj_comm_destroy(comm));
+        void* all[] = {d_iq, d_power, d_stats, d_amp, d_on, d_psd, d_slot, d_slots, d_pairs, d_lags, d_peaks, d_margins, d_res, d_all};
+        for (size_t k = 0; k < sizeof(all) / sizeof(all[0]); ++k) CHECK(gj_free(ctx, all[k]));
     }
     CHECK(gj_destroy(ctx));
     printf("c_abi_smoke OK: %zu chunks, first %lld, onset %lld\n", nchunks, first, (long long)on.start_index);
