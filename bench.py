@@ -80,7 +80,15 @@ def main():
                     help="run the scan/TDOA kernels on the K2 stream instead of concurrently on a second one")
     ap.add_argument("--cpu-sample-chunks", type=int, default=None,
                     help="1-s chunks of the capture given to the CPU oracle (default 24 at N = 1, 8 per rank otherwise)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="diagnostic: ranks only form the process group, all-reduce one number and print it")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="seconds the self-launched ranks of --gpus N > 1 may take before they are stopped")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process never touches the GPU, it starts one rank per GPU
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout))
 
     import numpy as np
     import torch
@@ -91,12 +99,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
     if args.share_gpu:
         local_rank = 0
+    if args.rendezvous_only:
+        raise SystemExit(rendezvous_only(args, torch, world, rank, local_rank))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -313,6 +321,69 @@ def main():
         dist.destroy_process_group()
     stream.close()
     dev.close()
+
+
+def launch_ranks(n, argv, limit_s):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under
+    torch.distributed.run as a CHILD process (never an exec; this parent has not initialised the GPU
+    and never does), pass their output through -- rank 0's JSON line goes to stdout as it is -- and
+    return their exit status: non-zero when any rank died, when the 300-s collective timeout inside
+    the ranks fired, or when the whole run outlived --launch-timeout."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as s:                  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print("[bench] launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        print(f"[bench] ranks still running after {limit_s:.0f} s: stopping them", file=sys.stderr, flush=True)
+    except KeyboardInterrupt:
+        pass
+    try:                                        # exactly the process group this call started
+        os.killpg(proc.pid, signal.SIGTERM)
+        proc.wait(timeout=20)
+    except (subprocess.TimeoutExpired, ProcessLookupError):
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        proc.wait()
+    return 124
+
+
+def rendezvous_only(args, torch, world, rank, local_rank):
+    """Form the process group, all-reduce one number, rank 0 prints what it saw: separates "the ranks
+    cannot find each other / RCCL cannot start" from anything the DSP path does."""
+    import datetime
+    if world == 1:
+        print(json.dumps({"rendezvous": "single process", "world": 1}), flush=True)
+        return 0
+    import torch.distributed as dist
+    limit = datetime.timedelta(seconds=120)
+    if args.backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
+        t = torch.tensor([float(rank + 1)], device="cuda")
+    else:
+        dist.init_process_group(backend=args.backend, timeout=limit)
+        t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    ok = float(t.item()) == world * (world + 1) / 2
+    if rank == 0:
+        print(json.dumps({"rendezvous": "ok" if ok else "wrong sum", "world": world, "backend": args.backend,
+                          "sum": float(t.item())}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def self_check(results, tdoa, onsets, nsamp, n_ant):

@@ -210,13 +210,16 @@ def gather_rows(row: torch.Tensor, rank: int, world_size: int, dst: int = 0,
 
 
 def allgather_rows(row: torch.Tensor, world_size: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Every rank's ``row`` on EVERY rank as one [world, len] tensor (torch.distributed.all_gather)."""
+    """Every rank's ``row`` on EVERY rank as one [world, len] tensor: ONE collective straight into the
+    contiguous receive buffer (all_gather_into_tensor = ncclAllGather on HIP tensors; the list form of
+    all_gather flattens and copies out once more)."""
     if world_size == 1:
         return row.unsqueeze(0)
     import torch.distributed as dist
     if out is None:
         out = torch.empty((world_size, row.numel()), dtype=row.dtype, device=row.device)
-    dist.all_gather([out[r] for r in range(world_size)], row)
+    assert out.is_contiguous() and out.shape == (world_size, row.numel()) and out.dtype == row.dtype
+    dist.all_gather_into_tensor(out.view(-1), row.contiguous().view(-1))   # flat form: accepted by nccl and gloo alike
     return out
 
 

@@ -1,0 +1,69 @@
+"""`python bench.py --gpus N` starts its own ranks (VERDICT r02 missing 1): the parent never touches the GPU,
+spawns torch.distributed.run as a child, passes rank 0's JSON line through and returns the ranks' status."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(REPO, "bench.py")
+
+
+def _env():
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    return env
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(300)
+def test_self_launch_rendezvous_cpu():
+    """No launcher on the command line: two gloo ranks find each other and rank 0's line comes through."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--rendezvous-only"],
+                       capture_output=True, text=True, env=_env(), timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line == {"rendezvous": "ok", "world": 2, "backend": "gloo", "sum": 3.0}
+    assert "torch.distributed.run" in r.stderr          # the parent says what it started
+
+
+@pytest.mark.timeout(300)
+def test_self_launch_relays_failure_cpu():
+    """A rank that dies makes the parent exit non-zero (here: a backend that does not exist)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "no_such_backend", "--rendezvous-only"],
+                       capture_output=True, text=True, env=_env(), timeout=280)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_parent_does_not_import_torch_before_launch():
+    """The launching parent must not initialise the GPU: the launch happens before torch / gpsjam are imported."""
+    src = open(BENCH).read()
+    main = src[src.index("def main():"):]
+    assert main.index("launch_ranks(") < main.index("import torch")
+    assert "os.exec" not in src and "execv" not in src
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_self_launch_two_ranks_share_gpu():
+    """`python bench.py --gpus 2 --backend gloo --share-gpu --steps 3`: the real step on two ranks that share
+    cuda:0, started by bench.py itself; one line, n_gpus 2, self_check passed."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "3",
+                        "--warmup", "1", "--precondition", "2", "--cpu-sample-chunks", "1"],
+                       capture_output=True, text=True, env=_env(), timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["steps"] == 3
+    assert line["self_check"]["passed"] is True, line["self_check"]
+    assert line["self_check"]["pairs_checked"] == 1 and line["self_check"]["streams_checked"] == 2
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0
