@@ -274,11 +274,13 @@ def main():
                                  "scan + TDOA kernels executing concurrently on a second stream when "
                                  "overlap is true; 'solo' is K2 with nothing else in flight"},
             "roofline_valu": valu_roofline(pmc, welch_ms, solo_ms),
+            "roofline_flops": flops_roofline(nbytes, welch_ms, solo_ms),
             "secondary": {
                 "stream_scan_kernel (K1+K3+K4 fused) + threshold + tail kernels, solo": {
                     "bound": "hbm", "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": scan_ms,
                     "achieved": (nbytes / 1e9) / (scan_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": (nbytes / 1e9) / (scan_ms / 1e3) / HBM_PEAK_GBS},
+                    "frac": (nbytes / 1e9) / (scan_ms / 1e3) / HBM_PEAK_GBS,
+                    **family_traffic("profiles/r03_pmc_scan/summary.json", nbytes)},
             },
             "results": {"pairs": [list(p) for p in tdoa.pairs], "lags": tdoa.lags,
                         "lag_margins": [round(m, 4) for m in tdoa.margins], "onsets": onsets,
@@ -296,7 +298,9 @@ def main():
                 "bound": "hbm", "algorithmic_bytes_per_launch": k5_bytes, "avg_launch_ms": k5_ms,
                 "achieved": (k5_bytes / 1e9) / (k5_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (k5_bytes / 1e9) / (k5_ms / 1e3) / HBM_PEAK_GBS,
-                "note": "working set (spectra) is L2 / Infinity-Cache resident"}
+                **family_traffic("profiles/r03_pmc_xcorr/summary.json", nbytes),
+                "note": "PMC: about half of the four-step floor reaches HBM -- the spectra are written through "
+                        "(50 MB) and about a third of the reads miss L2 / Infinity Cache (56 MB)"}
         if acq_ms is not None:
             n_prn, n_freq, intg, nsamp = acq_shape
             n_fft = intg * n_freq * (1 + n_prn) + n_prn
@@ -307,6 +311,7 @@ def main():
                 "transforms_per_s": n_fft / (acq_ms / 1e3),
                 "real_time_factor": (intg * 1e-3) / (acq_ms / 1e3),
                 "k2_transforms_per_s_for_scale": (nbytes / 2 / (NPERSEG // 2)) / (solo_ms / 1e3),
+                **family_traffic("profiles/r03_pmc_acq/summary.json", nbytes),
                 "parity": "unpinned (gnssdec unbuildable here); oracle = numpy restatement of sdracq.c / sdrcmn.c"}
         if cpu is not None:
             line["cpu_baseline"] = cpu
@@ -456,6 +461,54 @@ def pmc_summary(nbytes):
         out["matches_build"] = (js.get("_source_hash") == source_hash()) if js.get("_source_hash") else None
         return out
     return out
+
+
+def family_traffic(rel, nbytes):
+    """HBM bytes per repetition of a secondary kernel family from its committed PMC summary
+    (tools/pmc_secondary.sh + tools/pmc_family.py: FETCH_SIZE x gfx950 read correction + WRITE_SIZE, summed over
+    the family's kernels), with the check that the family's sources still hash to what was measured."""
+    out = {"traffic": None, "traffic_unit": "HBM bytes per repetition (all kernels of the family)",
+           "traffic_source": "no PMC summary found", "traffic_measured_on_this_source": None}
+    try:
+        with open(os.path.join(REPO, rel)) as f:
+            js = json.load(f)
+        corr = js["_hbm_bytes_corrected"]
+    except (OSError, KeyError, ValueError):
+        return out
+    if nbytes != CAPTURE_BYTES:
+        out["traffic_source"] = "PMC summary is for the 1-GiB capture only"
+        return out
+    h = hashlib.sha256()
+    for name in js.get("_sources", []):
+        with open(os.path.join(REPO, "gps-jamming_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    out["traffic"] = corr.get("hbm_bytes_per_repetition")
+    out["traffic_read"] = corr.get("read_bytes")
+    out["traffic_write"] = corr.get("write_bytes")
+    out["valu_insts"] = js.get("per_repetition", {}).get("SQ_INSTS_VALU")
+    out["traffic_source"] = rel + " (commit " + str(js.get("_commit", "not recorded")) + ")"
+    out["traffic_measured_on_this_source"] = js.get("_source_hash") == h.hexdigest()[:16]
+    return out
+
+
+def flops_roofline(nbytes, welch_ms, solo_ms):
+    """K2 priced in arithmetic: 5 N log2 N flops per 4096-point segment (the butterflies alone; window, detrend
+    and |X|^2 not counted) against the FP32 vector peak of the chip (= its FP32 MFMA peak: 256 CUs x 4 SIMDs x
+    16 lanes x 2 (packed) x 2 (FMA) x 2.4 GHz).  Butterflies are add-dominated, so an FFT cannot reach the FMA
+    peak: the VALU-issue view (roofline_valu) is the binding one."""
+    nsamp = nbytes // 2
+    full, rem = divmod(nsamp, CHUNK_SAMPLES)
+    segs = full * ((CHUNK_SAMPLES - NPERSEG) // (NPERSEG // 2) + 1)
+    if rem >= NPERSEG:
+        segs += (rem - NPERSEG) // (NPERSEG // 2) + 1
+    flops = segs * 5.0 * NPERSEG * 12
+    peak = 157.3
+    return {"bound": "valu_fp32", "flops_per_launch": flops, "segments_per_launch": segs, "peak": peak, "unit": "TFLOP/s",
+            "achieved": flops / (welch_ms / 1e3) / 1e12, "frac": flops / (welch_ms / 1e3) / 1e12 / peak,
+            "solo": {"achieved": flops / (solo_ms / 1e3) / 1e12, "frac": flops / (solo_ms / 1e3) / 1e12 / peak},
+            "hbm_frac_if_arithmetic_ran_at_peak": (nbytes / 1e9) / (flops / (peak * 1e12)) / HBM_PEAK_GBS,
+            "note": "FP32 vector peak = FP32 MFMA peak on gfx950, so no matrix-pipe route lifts this ceiling "
+                    "(DESIGN.md section 5)"}
 
 
 def valu_roofline(pmc, welch_ms, solo_ms):

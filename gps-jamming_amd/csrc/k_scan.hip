@@ -1034,8 +1034,13 @@ int launch_stream_scan(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t c
     // the K4 noise span rides along in the same pass when it ends on a 16-byte boundary
     const size_t noise_bytes = (size_t)2 * noise_samples;
     const bool noise_fused = valid && (noise_bytes % 16 == 0);
-    // amplitudes are >= sqrt(2)/255 > 0.0055: a threshold below that makes every sample a hit
-    const bool track = !(rssi_threshold < 0.005f);
+    // When the offset is a half-integer (off2 odd) no component of 2u - off2 is zero, so every amplitude is at
+    // least sqrt(2) * half_scale (0.0055 for the default unpack): a threshold below that makes every sample a hit
+    // and the first index needs no tracking.  With an integer offset (gj_set_unpack(128, ...)) amplitudes can be
+    // zero and the shortcut never applies.  Same float expression as the kernels' `a > thr`.
+    const Unpack upk = unpack_of(ctx);
+    const bool all_hit = (ctx->off2 & 1) && (sqrtf(2.0f) * upk.half_scale > rssi_threshold);
+    const bool track = !all_hit;
     // experiment knob: dynamic LDS the scan workgroups declare but never touch (residency limiter)
     static const unsigned lds_pad = getenv("GPSJAM_SCAN_LDS_PAD") ? (unsigned)atoi(getenv("GPSJAM_SCAN_LDS_PAD")) : 0u;
     if (track)

@@ -5,6 +5,7 @@ the thing to put after `rocprofv3 ... --` for kernel-trace and PMC passes.
     python tools/run_kernel.py welch --reps 5 [--nperseg 4096] [--bytes 1073741824]
     python tools/run_kernel.py scan  --reps 5      (K1 + threshold + K3 + K4)
     python tools/run_kernel.py xcorr --reps 5
+    python tools/run_kernel.py acq   --reps 5      (one cold acquisition search per repetition)
 Prints the average wall time per repetition measured with HIP events on the launch stream.
 """
 import argparse
@@ -17,7 +18,7 @@ sys.path.insert(0, os.path.join(REPO, "gps-jamming_amd"))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["welch", "scan", "fscan", "thr", "xcorr", "xcorr3", "k1", "k3", "k4"])
+    ap.add_argument("what", choices=["welch", "scan", "fscan", "thr", "xcorr", "xcorr3", "k1", "k3", "k4", "acq"])
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--nperseg", type=int, default=4096)
     ap.add_argument("--bytes", type=int, default=1 << 30)
@@ -41,8 +42,15 @@ def main():
     d_starts3, d_lags3, d_peaks3 = dev.alloc(24), dev.alloc(12), dev.alloc(12)
     d_starts3.upload(np.array([int(0.4 * ns), int(0.4 * ns) + 3, int(0.4 * ns) - 5], np.int64))
 
+    srch = None
+    if args.what == "acq":            # 32 PRNs x 71 Doppler bins x 10 ms on the quiet start of the capture
+        from gpsjam.gnss import AcqSearch
+        srch = AcqSearch(dev)
+
     def once():
-        if args.what == "welch":
+        if args.what == "acq":
+            srch.search_dev(cap, nbytes, 0)
+        elif args.what == "welch":
             dev.welch_dev(cap, nbytes, 2048000, args.nperseg, 2.048e6, d_psd)
         elif args.what == "k1":
             dev.chunk_power_dev(cap, nbytes, 65536, d_pow)
