@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>   // types and prototypes only; nothing is linked
 
 #include "gj_common.h"
+#include "host_io.h"
 
 struct gj_comm {
     gj_ctx* ctx = nullptr;
@@ -68,6 +69,17 @@ static int rccl_fail(gj_ctx* ctx, const char* what, ncclResult_t rc) {
     return fail(ctx, GJ_ERR_HIP, "%s failed: %s", what, r->GetErrorString ? r->GetErrorString(rc) : "?");
 }
 
+// gj_destroy: communicators made on the context go down with it; their handles stay valid for gj_comm_destroy
+// (which then only frees the handle), so the order in which a host drops the two does not matter.
+void comm_detach_all(gj_ctx* ctx) {
+    for (gj_comm* c : ctx->comms) {
+        if (c->comm) (void)rccl()->CommDestroy(c->comm);
+        c->comm = nullptr;
+        c->ctx = nullptr;
+    }
+    ctx->comms.clear();
+}
+
 }   // namespace gj
 
 using namespace gj;
@@ -88,7 +100,6 @@ int gj_comm_unique_id(void* id) {
 int gj_comm_init_rank(gj_ctx* ctx, const void* id, int rank, int n_ranks, gj_comm** out) {
     if (!ctx || !id || !out) return GJ_ERR_INVALID;
     *out = nullptr;
-    Guard g(ctx);
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(ctx, GJ_ERR_INVALID, "rank %d of %d", rank, n_ranks);
     Rccl* r = rccl();
     if (!r->handle || r->why[0]) return fail(ctx, GJ_ERR_UNSUPPORTED, "%s", r->why);
@@ -99,10 +110,16 @@ int gj_comm_init_rank(gj_ctx* ctx, const void* id, int rank, int n_ranks, gj_com
     c->ctx = ctx;
     c->rank = rank;
     c->n_ranks = n_ranks;
+    // the rendezvous blocks until every rank has arrived: outside the context lock
+    (void)hipSetDevice(ctx->device);
     const ncclResult_t rc = r->CommInitRank(&c->comm, n_ranks, u, rank);   // binds to the current device = ctx's
     if (rc != ncclSuccess) {
         delete c;
         return rccl_fail(ctx, "ncclCommInitRank", rc);
+    }
+    {
+        Guard g(ctx);
+        ctx->comms.push_back(c);
     }
     *out = c;
     return GJ_OK;
@@ -116,7 +133,7 @@ int gj_comm_rank(gj_comm* c, int* rank, int* n_ranks) {
 }
 
 int gj_comm_gather_dev(gj_comm* c, const void* d_send, size_t bytes, void* d_recv, int root) {
-    if (!c) return GJ_ERR_INVALID;
+    if (!c || !c->ctx || !c->comm) return GJ_ERR_INVALID;   // destroyed, or its context is gone
     gj_ctx* ctx = c->ctx;
     Guard g(ctx);
     if (root < 0 || root >= c->n_ranks) return fail(ctx, GJ_ERR_INVALID, "root %d of %d", root, c->n_ranks);
@@ -127,7 +144,7 @@ int gj_comm_gather_dev(gj_comm* c, const void* d_send, size_t bytes, void* d_rec
 }
 
 int gj_comm_allgather_dev(gj_comm* c, const void* d_send, size_t bytes, void* d_recv) {
-    if (!c) return GJ_ERR_INVALID;
+    if (!c || !c->ctx || !c->comm) return GJ_ERR_INVALID;   // destroyed, or its context is gone
     gj_ctx* ctx = c->ctx;
     Guard g(ctx);
     if (!d_send || !d_recv) return fail(ctx, GJ_ERR_INVALID, "null buffer");
@@ -137,7 +154,7 @@ int gj_comm_allgather_dev(gj_comm* c, const void* d_send, size_t bytes, void* d_
 }
 
 int gj_comm_bcast_dev(gj_comm* c, void* d_buf, size_t bytes, int root) {
-    if (!c) return GJ_ERR_INVALID;
+    if (!c || !c->ctx || !c->comm) return GJ_ERR_INVALID;   // destroyed, or its context is gone
     gj_ctx* ctx = c->ctx;
     Guard g(ctx);
     if (root < 0 || root >= c->n_ranks) return fail(ctx, GJ_ERR_INVALID, "root %d of %d", root, c->n_ranks);
@@ -149,9 +166,18 @@ int gj_comm_bcast_dev(gj_comm* c, void* d_buf, size_t bytes, int root) {
 
 int gj_comm_destroy(gj_comm* c) {
     if (!c) return GJ_OK;
-    {
-        Guard g(c->ctx);
-        (void)hipStreamSynchronize(c->ctx->stream);
+    gj_ctx* ctx = c->ctx;
+    if (ctx) {   // still attached: collectives queued on the context's stream must have finished
+        (void)wait_stream(ctx, current_stream(ctx));
+        {
+            Guard g(ctx);
+            for (size_t k = 0; k < ctx->comms.size(); ++k)
+                if (ctx->comms[k] == c) {
+                    ctx->comms.erase(ctx->comms.begin() + (long)k);
+                    break;
+                }
+        }
+        (void)hipSetDevice(ctx->device);
         if (c->comm) (void)rccl()->CommDestroy(c->comm);
     }
     delete c;

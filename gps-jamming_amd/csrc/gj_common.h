@@ -2,33 +2,67 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <pthread.h>
+
+#include <cerrno>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "../../include/gpsjam.h"
 #include "fft_core.h"
+
+struct gj_comm;
+
+// What ONE host-buffer call owns from entry to return: device staging for its input and results, pinned bounce
+// buffers, a pinned landing area for its results, its own events.  A call checks a lane out under the context
+// lock, then stages, waits and copies with NO lock held; two host threads therefore never share a buffer, and a
+// caller that is killed inside a wait (the GUI stops an analysis with QThread.terminate(),
+// GpsJammerApp/app/ui_mainwindow.py:818-826) leaves nothing locked: its lane is taken back once its thread is gone.
+struct gj_lane {
+    static constexpr int kPinBufs = 32;   // pinned bounce buffers (2 per fill thread)
+    bool busy = false;
+    int owner_tid = 0;                    // kernel thread id of the caller that holds the lane
+    unsigned char* stage = nullptr;       // grow-only device staging: [input][results]
+    size_t stage_bytes = 0;
+    void* pin[kPinBufs] = {};
+    hipEvent_t pin_ev[kPinBufs] = {};
+    unsigned char* rpin = nullptr;        // pinned host memory the results are copied into (async D2H)
+    size_t rpin_bytes = 0;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr;
+};
+
+struct gj_retired {                       // an arena replaced while queued kernels may still read it
+    void* p;
+    hipEvent_t ev;
+};
 
 struct gj_ctx {
     int device = 0;
     int num_cus = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    std::recursive_mutex mu;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // gj_timer_*
+    // Robust + recursive: held only while work is ENQUEUED (never across a host wait, a file read or a staged
+    // copy); if its owner dies inside a critical section the next locker gets EOWNERDEAD and carries on.
+    pthread_mutex_t mu;
+    bool mu_ready = false;
+    int owner_deaths = 0;
     gj::cf* d_twiddle = nullptr;   // W_4096^m
     unsigned char* ws = nullptr;   // grow-only workspace for partial results
     size_t ws_bytes = 0;
-    unsigned char* stage = nullptr;   // grow-only device staging for the host-buffer entry points
-    size_t stage_bytes = 0;
-    static constexpr int kPinBufs = 32;   // pinned bounce buffers of the host-buffer entry points (2 per fill thread)
-    void* pin[kPinBufs] = {};
-    hipEvent_t pin_ev[kPinBufs] = {};
+    std::vector<gj_retired> retired;
+    std::vector<gj_lane*> lanes;
+    std::vector<gj_comm*> comms;   // communicators created on this context (gj_destroy takes them down)
+    int lanes_reclaimed = 0;
     // unpack convention (gj_set_unpack): sample = (u8 - offset) * scale; off2 = 2 * offset is an integer
     int off2 = 255;
     double scale = 1.0 / 127.5;
-    char last_error[512] = {0};
+    // diagnostics (gj_debug_set_wait_hook): called with NO lock held right before every host-side wait
+    void (*wait_hook)(void*, int) = nullptr;
+    void* wait_hook_arg = nullptr;
 };
 
 namespace gj {
@@ -47,13 +81,18 @@ inline double unpack_norm2(const gj_ctx* ctx) {
     return n * n;
 }
 
+// detailed message of the calling thread's last failure (gj_last_error): per thread, so that two host threads on
+// one context never read each other's text
+inline char* last_error_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
 inline int fail(gj_ctx* ctx, int code, const char* fmt, ...) {
-    if (ctx) {
-        va_list ap;
-        va_start(ap, fmt);
-        vsnprintf(ctx->last_error, sizeof(ctx->last_error), fmt, ap);
-        va_end(ap);
-    }
+    (void)ctx;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buf(), 512, fmt, ap);
+    va_end(ap);
     return code;
 }
 
@@ -73,18 +112,33 @@ inline int fail(gj_ctx* ctx, int code, const char* fmt, ...) {
                             hipGetErrorString(e__), __FILE__, __LINE__);                          \
     } while (0)
 
+// The context lock, for the ENQUEUE part of a call only.  Nothing that can block for long is done under it:
+// waits go through wait_event / wait_stream below, after the Guard has been left.
 struct Guard {
     gj_ctx* c;
     explicit Guard(gj_ctx* ctx) : c(ctx) {
-        c->mu.lock();
+        if (pthread_mutex_lock(&c->mu) == EOWNERDEAD) {   // the previous owner died inside a critical section
+            (void)pthread_mutex_consistent(&c->mu);
+            ++c->owner_deaths;
+        }
         (void)hipSetDevice(c->device);
     }
-    ~Guard() { c->mu.unlock(); }
+    ~Guard() { (void)pthread_mutex_unlock(&c->mu); }
+    Guard(const Guard&) = delete;
+    Guard& operator=(const Guard&) = delete;
 };
 
-// grow-only device arenas
+// wait sites reported to the diagnostic hook
+enum WaitSite { kWaitEvent = 1, kWaitStream = 2, kWaitPiece = 3, kWaitLane = 4, kUnderLock = 5 };
+inline void wait_hook(gj_ctx* ctx, int site) {
+    void (*h)(void*, int) = ctx->wait_hook;
+    if (h) h(ctx->wait_hook_arg, site);
+}
+
+// grow-only workspace of the *_dev kernels.  Growing never waits: the old arena is retired behind an event on the
+// stream and freed later, outside the lock (reap_retired).
 int ensure_workspace(gj_ctx* ctx, size_t bytes);
-int ensure_stage(gj_ctx* ctx, size_t bytes);
+void reap_retired(gj_ctx* ctx);
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

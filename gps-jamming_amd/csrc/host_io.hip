@@ -1,0 +1,550 @@
+// Host-buffer side of the C-ABI (include/gpsjam.h): resident-capture uploads and the "*_u8" entry points that take
+// numpy arrays.  Every call works in a LANE of its own (device staging, pinned bounce buffers, pinned result area,
+// events: gj_common.h) and follows one shape:
+//     check a lane out (lock, short) -> stage the input (no lock) -> enqueue kernels + result copy (lock, short)
+//     -> wait for the call's own event (no lock) -> copy the results out of the lane's pinned area -> check in.
+// Nothing waits, reads a file or copies a capture while holding ctx->mu, so a caller killed at any of those points
+// (QThread.terminate(), GpsJammerApp/app/ui_mainwindow.py:818-826) blocks nobody; the lane it held is taken back
+// when its thread is seen to be gone.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cmath>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "gj_common.h"
+#include "host_io.h"
+
+namespace gj {
+
+constexpr int kMaxLanes = 8;
+
+static int this_tid() { return (int)syscall(SYS_gettid); }
+static bool thread_alive(int tid) {
+    if (tid <= 0) return false;
+    return syscall(SYS_tgkill, (int)getpid(), tid, 0) == 0 || errno != ESRCH;
+}
+
+void lane_free(gj_lane* L) {
+    if (!L) return;
+    if (L->stage) (void)hipFree(L->stage);
+    for (int k = 0; k < gj_lane::kPinBufs; ++k) {
+        if (L->pin[k]) (void)hipHostFree(L->pin[k]);
+        if (L->pin_ev[k]) (void)hipEventDestroy(L->pin_ev[k]);
+    }
+    if (L->rpin) (void)hipHostFree(L->rpin);
+    for (hipEvent_t e : {L->ev_start, L->ev_stop, L->ev_done})
+        if (e) (void)hipEventDestroy(e);
+    delete L;
+}
+
+gj_lane* lane_checkout(gj_ctx* ctx) {
+    reap_retired(ctx);
+    const int me = this_tid();
+    for (;;) {
+        gj_lane* taken = nullptr;
+        hipStream_t drain = nullptr;
+        bool reclaimed = false;
+        {
+            Guard g(ctx);
+            for (gj_lane* L : ctx->lanes)
+                if (!L->busy) {
+                    taken = L;
+                    break;
+                }
+            if (!taken)
+                for (gj_lane* L : ctx->lanes)
+                    if (!thread_alive(L->owner_tid)) {   // its caller was killed inside a call
+                        taken = L;
+                        reclaimed = true;
+                        drain = ctx->stream;
+                        ++ctx->lanes_reclaimed;
+                        break;
+                    }
+            if (!taken && (int)ctx->lanes.size() < kMaxLanes) {
+                taken = new (std::nothrow) gj_lane();
+                if (!taken) {
+                    fail(ctx, GJ_ERR_NOMEM, "lane");
+                    return nullptr;
+                }
+                ctx->lanes.push_back(taken);
+            }
+            if (taken) {
+                taken->busy = true;
+                taken->owner_tid = me;
+            }
+        }
+        if (taken) {
+            // what the dead caller queued may still be reading or writing the lane's buffers
+            if (reclaimed) (void)wait_stream(ctx, drain);
+            return taken;
+        }
+        wait_hook(ctx, kWaitLane);   // every lane is held by a live caller: wait for one, holding nothing
+        usleep(200);
+    }
+}
+
+void lane_checkin(gj_ctx* ctx, gj_lane* L) {
+    if (!L) return;
+    Guard g(ctx);
+    L->busy = false;
+    L->owner_tid = 0;
+}
+
+namespace {
+
+struct LaneHold {
+    gj_ctx* ctx;
+    gj_lane* L;
+    explicit LaneHold(gj_ctx* c) : ctx(c), L(lane_checkout(c)) { (void)hipSetDevice(c->device); }
+    ~LaneHold() { lane_checkin(ctx, L); }
+    LaneHold(const LaneHold&) = delete;
+    LaneHold& operator=(const LaneHold&) = delete;
+};
+
+// The lane belongs to the calling thread: its buffers are grown without the lock.  hipFree waits for the device, so
+// nothing queued earlier can still be using the old arena.
+int lane_stage(gj_ctx* ctx, gj_lane* L, size_t bytes) {
+    if (bytes <= L->stage_bytes) return GJ_OK;
+    bytes = align_up(bytes, 1 << 20);
+    if (L->stage) (void)hipFree(L->stage);
+    L->stage = nullptr;
+    L->stage_bytes = 0;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return fail(ctx, GJ_ERR_NOMEM, "staging buffer of %zu bytes", bytes);
+    L->stage = static_cast<unsigned char*>(p);
+    L->stage_bytes = bytes;
+    return GJ_OK;
+}
+
+int lane_rpin(gj_ctx* ctx, gj_lane* L, size_t bytes) {
+    if (bytes <= L->rpin_bytes) return GJ_OK;
+    bytes = align_up(bytes, 1 << 16);
+    if (L->rpin) (void)hipHostFree(L->rpin);
+    L->rpin = nullptr;
+    L->rpin_bytes = 0;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return fail(ctx, GJ_ERR_NOMEM, "pinned result area of %zu bytes", bytes);
+    L->rpin = static_cast<unsigned char*>(p);
+    L->rpin_bytes = bytes;
+    return GJ_OK;
+}
+
+int lane_events(gj_ctx* ctx, gj_lane* L) {
+    if (!L->ev_start) GJ_HIP(ctx, hipEventCreate(&L->ev_start));
+    if (!L->ev_stop) GJ_HIP(ctx, hipEventCreate(&L->ev_stop));
+    if (!L->ev_done) GJ_HIP(ctx, hipEventCreateWithFlags(&L->ev_done, hipEventDisableTiming));
+    return GJ_OK;
+}
+
+// Is `p` device memory (a resident capture from gj_upload* / gj_malloc)?  Host memory the runtime has never seen
+// answers with an error or "unregistered", depending on the ROCm release.
+bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+
+// Large captures go through pinned 16 MiB bounce buffers (the host copy of piece k+1 overlaps the DMA of piece k:
+// 29 GB/s with one fill thread against 21 GB/s for a pageable hipMemcpy of 1 GiB on the MI355X box,
+// tools/h2d_bench.hip); small ones take the plain path.
+constexpr size_t kPinBytes = 16u << 20;
+constexpr size_t kPinThreshold = 64u << 20;
+constexpr int kMaxFillThreads = gj_lane::kPinBufs / 2;
+
+// fill threads of one staged copy: GPSJAM_FILL_THREADS (1..16), default 8 (one memcpy thread tops out at ~31 GB/s
+// end to end, below what the link carries; pread out of the page cache needs the extra threads more than memcpy)
+int fill_threads() {
+    static const int n = [] {
+        const char* e = getenv("GPSJAM_FILL_THREADS");
+        int v = e ? atoi(e) : 8;
+        if (v < 1) v = 1;
+        if (v > kMaxFillThreads) v = kMaxFillThreads;
+        return v;
+    }();
+    return n;
+}
+
+// Host source -> d_dst through the lane's pinned buffers, on `stream`, with no lock held anywhere.
+// `fill(dst, off, len)` puts bytes [off, off+len) of the source into a pinned buffer: memcpy from a numpy array or a
+// mapped file, or pread from a capture file.  `landed(piece)`, when given, is called by the fill thread right after
+// it has queued piece `piece` (16 MiB, in HBM once ev fires): the overlapped ingest hangs its kernels there.
+struct PieceSink {
+    virtual void queued(size_t piece, size_t off, size_t len, hipEvent_t ev) = 0;
+    virtual ~PieceSink() = default;
+};
+
+template <typename Fill>
+int staged_copy(gj_ctx* ctx, gj_lane* L, hipStream_t stream, unsigned char* d_dst, size_t nbytes, Fill&& fill,
+                PieceSink* sink = nullptr) {
+    if (nbytes == 0) return GJ_OK;
+    const size_t npieces = (nbytes + kPinBytes - 1) / kPinBytes;
+    const int nthreads = (int)(npieces < (size_t)fill_threads() ? npieces : (size_t)fill_threads());
+    for (int k = 0; k < 2 * nthreads; ++k) {   // two bounce buffers per fill thread, made on first use
+        if (!L->pin[k]) GJ_HIP(ctx, hipHostMalloc(&L->pin[k], kPinBytes, hipHostMallocDefault));
+        if (!L->pin_ev[k]) GJ_HIP(ctx, hipEventCreateWithFlags(&L->pin_ev[k], hipEventDisableTiming));
+    }
+    wait_hook(ctx, kWaitPiece);
+    std::atomic<int> failed{0};
+    const int device = ctx->device;
+    auto worker = [&](int t) {
+        if (hipSetDevice(device) != hipSuccess) { failed.store(1); return; }
+        size_t mine = 0;
+        for (size_t piece = (size_t)t; piece < npieces; piece += (size_t)nthreads, ++mine) {
+            const size_t off = piece * kPinBytes;
+            const size_t len = (nbytes - off < kPinBytes) ? nbytes - off : kPinBytes;
+            const int b = 2 * t + (int)(mine & 1);
+            if (mine >= 2 && hipEventSynchronize(L->pin_ev[b]) != hipSuccess) { failed.store(1); return; }
+            if (!fill(static_cast<unsigned char*>(L->pin[b]), off, len)) { failed.store(2); return; }
+            if (hipMemcpyAsync(d_dst + off, L->pin[b], len, hipMemcpyHostToDevice, stream) != hipSuccess ||
+                hipEventRecord(L->pin_ev[b], stream) != hipSuccess) { failed.store(1); return; }
+            if (sink) sink->queued(piece, off, len, L->pin_ev[b]);
+        }
+        // the bounce buffers are reused by the lane's next call: the tail pieces must have left them
+        for (int k = 0; k < 2; ++k)
+            if (mine > (size_t)k && hipEventSynchronize(L->pin_ev[2 * t + k]) != hipSuccess) failed.store(1);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto& th : pool) th.join();
+    if (failed.load() == 2) return fail(ctx, GJ_ERR_INVALID, "reading the capture failed");
+    if (failed.load()) return fail(ctx, GJ_ERR_HIP, "host-to-device staging failed");
+    return GJ_OK;
+}
+
+int copy_in(gj_ctx* ctx, gj_lane* L, hipStream_t s, unsigned char* d_dst, const uint8_t* host, size_t nbytes) {
+    if (nbytes == 0) return GJ_OK;
+    if (nbytes < kPinThreshold) {
+        GJ_HIP(ctx, hipMemcpyAsync(d_dst, host, nbytes, hipMemcpyHostToDevice, s));
+        return GJ_OK;
+    }
+    return staged_copy(ctx, L, s, d_dst, nbytes, [host](unsigned char* dst, size_t off, size_t len) {
+        memcpy(dst, host + off, len);
+        return true;
+    });
+}
+
+// One host-buffer call.  begin(): lane + input (a device pointer is used in place, a host buffer is staged) + a
+// result region of `result_bytes` in the lane; run(): kernels under the lock, results queued into the lane's pinned
+// area; finish(): wait for this call's event with nothing held, then hand out the results.
+struct HostCall {
+    gj_ctx* ctx;
+    LaneHold hold;
+    gj_lane* L;
+    hipStream_t s = nullptr;            // stream the input was staged on
+    const uint8_t* d_in = nullptr;
+    unsigned char* d_res = nullptr;
+    size_t result_bytes = 0;
+    bool staged = false;
+
+    explicit HostCall(gj_ctx* c) : ctx(c), hold(c), L(hold.L) {}
+
+    int begin(const uint8_t* iq, size_t nbytes, size_t res_bytes) {
+        if (!L) return GJ_ERR_NOMEM;
+        int rc = lane_events(ctx, L);
+        if (rc) return rc;
+        result_bytes = res_bytes;
+        const bool resident = nbytes && is_device_ptr(iq);
+        const size_t in_bytes = resident ? 0 : align_up(nbytes, 256) + 256;
+        rc = lane_stage(ctx, L, in_bytes + align_up(res_bytes, 256) + 256);
+        if (!rc) rc = lane_rpin(ctx, L, res_bytes + 256);
+        if (rc) return rc;
+        d_res = L->stage + in_bytes;
+        s = current_stream(ctx);
+        if (resident) {
+            d_in = iq;
+        } else {
+            d_in = L->stage;
+            rc = copy_in(ctx, L, s, L->stage, iq, nbytes);
+            if (rc) return rc;
+            staged = nbytes != 0;
+            if (staged) GJ_HIP(ctx, hipEventRecord(L->ev_done, s));   // "input staged", for a stream change in between
+        }
+        return GJ_OK;
+    }
+
+    // fn(): the launch_* calls, entered under the lock with the timing events around them
+    template <typename Fn>
+    int run(Fn&& fn) {
+        Guard g(ctx);
+        if (staged && ctx->stream != s) GJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, L->ev_done, 0));
+        s = ctx->stream;
+        GJ_HIP(ctx, hipEventRecord(L->ev_start, s));
+        const int rc = fn();
+        if (rc) return rc;
+        GJ_HIP(ctx, hipEventRecord(L->ev_stop, s));
+        if (result_bytes) GJ_HIP(ctx, hipMemcpyAsync(L->rpin, d_res, result_bytes, hipMemcpyDeviceToHost, s));
+        GJ_HIP(ctx, hipEventRecord(L->ev_done, s));
+        return GJ_OK;
+    }
+
+    int finish(float* kernel_ms) {
+        int rc = wait_event(ctx, L->ev_done);
+        if (rc) return rc;
+        if (kernel_ms) {
+            float t = 0.f;
+            GJ_HIP(ctx, hipEventElapsedTime(&t, L->ev_start, L->ev_stop));
+            *kernel_ms = t;
+        }
+        return GJ_OK;
+    }
+
+    template <typename T>
+    T* dev(size_t off = 0) const { return reinterpret_cast<T*>(d_res + off); }
+    const unsigned char* host(size_t off = 0) const { return L->rpin + off; }
+};
+
+}   // namespace
+}   // namespace gj
+
+using namespace gj;
+
+extern "C" {
+
+// ---------------------------------------------------------------- resident captures
+// One upload per capture, then any number of calls on it (gpsjam.Capture): the host-buffer entry points below stage
+// a host input on every call (21 ms per GiB of PCIe against 0.2-1.3 ms of kernel time) and use a device pointer in
+// place.
+int gj_upload(gj_ctx* ctx, const uint8_t* host, size_t nbytes, void** dptr) {
+    if (!ctx) return GJ_ERR_INVALID;
+    if (!dptr || (nbytes && !host)) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    *dptr = nullptr;
+    LaneHold hold(ctx);
+    gj_lane* L = hold.L;
+    if (!L) return GJ_ERR_NOMEM;
+    int rc = lane_events(ctx, L);
+    if (rc) return rc;
+    void* p = nullptr;
+    if (hipMalloc(&p, align_up(nbytes, 256) + 256) != hipSuccess) return fail(ctx, GJ_ERR_NOMEM, "hipMalloc(%zu)", nbytes);
+    const hipStream_t s = current_stream(ctx);
+    rc = copy_in(ctx, L, s, static_cast<unsigned char*>(p), host, nbytes);
+    if (!rc && hipEventRecord(L->ev_done, s) != hipSuccess) rc = fail(ctx, GJ_ERR_HIP, "upload failed");
+    if (!rc) rc = wait_event(ctx, L->ev_done);
+    if (rc) {
+        (void)hipFree(p);
+        return rc;
+    }
+    *dptr = p;
+    return GJ_OK;
+}
+
+// The reference's ingest (np.fromfile / f.read, worker.py:209-217, triangulateRSSI.py:29) as file -> pinned bounce
+// buffers -> HBM.  max_bytes = 0: to the end of the file.
+int gj_upload_file(gj_ctx* ctx, const char* path, size_t offset, size_t max_bytes, void** dptr, size_t* nbytes_out) {
+    if (!ctx) return GJ_ERR_INVALID;
+    if (!path || !dptr || !nbytes_out) return fail(ctx, GJ_ERR_INVALID, "null argument");
+    *dptr = nullptr;
+    *nbytes_out = 0;
+    LaneHold hold(ctx);
+    gj_lane* L = hold.L;
+    if (!L) return GJ_ERR_NOMEM;
+    int rc = lane_events(ctx, L);
+    if (rc) return rc;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(ctx, GJ_ERR_INVALID, "cannot open %s", path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+        close(fd);
+        return fail(ctx, GJ_ERR_INVALID, "cannot stat %s", path);
+    }
+    size_t nbytes = (size_t)st.st_size > offset ? (size_t)st.st_size - offset : 0;
+    if (max_bytes && nbytes > max_bytes) nbytes = max_bytes;
+    void* p = nullptr;
+    if (hipMalloc(&p, align_up(nbytes, 256) + 256) != hipSuccess) {
+        close(fd);
+        return fail(ctx, GJ_ERR_NOMEM, "hipMalloc(%zu)", nbytes);
+    }
+    const hipStream_t s = current_stream(ctx);
+    // Two ways from the page cache into the pinned bounce buffers (tools/ingest_bench.py, tools/ingest_probe.cpp,
+    // profiles/r02_ingest.txt; 1 GiB in /dev/shm):
+    //  * mapping the file and copying in user space: 35-42 ms, of which 15-20 ms is the final munmap -- the same
+    //    whether the file has been read before or not.  Handing the munmap to a helper thread makes the call return
+    //    after 22 ms (49 GB/s) but the kernels and copies that follow then wait on the driver's MMU notifiers for
+    //    longer than the munmap took (file -> results 54-61 ms instead of 40), so it stays in the call;
+    //  * pread into the pinned buffers: 22-29 ms (37-48 GB/s) on a file that has been read before, but 75-100 ms on
+    //    the FIRST read of a freshly written one: the second touch of a page moves it to the active list, and eight
+    //    threads doing that fight over the LRU lock (the mapped path pays the same move inside munmap, from one
+    //    thread, uncontended).
+    // A capture is normally read once, soon after it was recorded, so mapping is the default; GPSJAM_FILE_READ=pread
+    // selects the other, which is also what a file that cannot be mapped gets.
+    static const bool want_pread = [] {
+        const char* e = getenv("GPSJAM_FILE_READ");
+        return e && strcmp(e, "pread") == 0;
+    }();
+    const size_t pg = (size_t)sysconf(_SC_PAGESIZE);
+    const size_t map_off = offset / pg * pg, lead = offset - map_off;
+    void* m = (nbytes && !want_pread) ? mmap(nullptr, nbytes + lead, PROT_READ, MAP_PRIVATE, fd, (off_t)map_off) : MAP_FAILED;
+    if (nbytes == 0) {
+        rc = GJ_OK;
+    } else if (m != MAP_FAILED) {
+        (void)madvise(m, nbytes + lead, MADV_SEQUENTIAL);
+        const unsigned char* src = static_cast<const unsigned char*>(m) + lead;
+        rc = staged_copy(ctx, L, s, static_cast<unsigned char*>(p), nbytes, [src](unsigned char* dst, size_t off, size_t len) {
+            memcpy(dst, src + off, len);
+            return true;
+        });
+        (void)munmap(m, nbytes + lead);
+    } else {
+        (void)posix_fadvise(fd, 0, 0, POSIX_FADV_NOREUSE);   // regular file systems (Linux >= 6.3): no LRU promotion on read
+        rc = staged_copy(ctx, L, s, static_cast<unsigned char*>(p), nbytes, [fd, offset](unsigned char* dst, size_t off, size_t len) {
+            size_t done = 0;
+            while (done < len) {
+                const ssize_t k = pread(fd, dst + done, len - done, (off_t)(offset + off + done));
+                if (k <= 0) return false;
+                done += (size_t)k;
+            }
+            return true;
+        });
+    }
+    close(fd);
+    if (!rc && hipEventRecord(L->ev_done, s) != hipSuccess) rc = fail(ctx, GJ_ERR_HIP, "upload failed");
+    if (!rc) rc = wait_event(ctx, L->ev_done);
+    if (rc) {
+        (void)hipFree(p);
+        return rc;
+    }
+    *dptr = p;
+    *nbytes_out = nbytes;
+    return GJ_OK;
+}
+
+// ---------------------------------------------------------------- host-buffer entry points
+// `iq` is a host buffer (staged into the call's lane) or a DEVICE pointer (a resident capture: used in place).
+// kernel_ms excludes the copies.
+int gj_chunk_power_u8(gj_ctx* ctx, const uint8_t* iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
+                      float* power, size_t power_cap, size_t* n_out, float* kernel_ms) {
+    if (!ctx) return GJ_ERR_INVALID;
+    if (chunk_bytes == 0) return fail(ctx, GJ_ERR_INVALID, "chunk_bytes must be > 0");
+    const size_t n = gj_chunk_count(nbytes, chunk_bytes);
+    if (n_out) *n_out = n;
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (n == 0) return GJ_OK;
+    if (!iq || !power) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    if (power_cap < n) return fail(ctx, GJ_ERR_CAPACITY, "power buffer holds %zu, need %zu", power_cap, n);
+    HostCall call(ctx);
+    int rc = call.begin(iq, nbytes, n * sizeof(float));
+    if (!rc) rc = call.run([&] { return launch_chunk_power(ctx, call.d_in, nbytes, chunk_bytes, eps, flags, call.dev<float>()); });
+    if (!rc) rc = call.finish(kernel_ms);
+    if (rc) return rc;
+    memcpy(power, call.host(), n * sizeof(float));
+    return GJ_OK;
+}
+
+int gj_welch_u8(gj_ctx* ctx, const uint8_t* iq, size_t nbytes, size_t chunk_samples, int nperseg, double fs, int flags,
+                float* psd, float* psd_db, size_t cap_floats, size_t* rows_out, float* kernel_ms) {
+    if (!ctx) return GJ_ERR_INVALID;
+    const size_t rows = gj_welch_rows(nbytes, chunk_samples, nperseg);
+    if (rows_out) *rows_out = rows;
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (nperseg < 16 || nperseg > 4096 || (nperseg & (nperseg - 1)))
+        return fail(ctx, GJ_ERR_UNSUPPORTED, "nperseg must be a power of two in [16, 4096]");
+    if (rows == 0) return GJ_OK;
+    if (!iq || !psd) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    const size_t nfl = rows * (size_t)nperseg;
+    if (cap_floats < nfl) return fail(ctx, GJ_ERR_CAPACITY, "psd buffer holds %zu floats, need %zu", cap_floats, nfl);
+    HostCall call(ctx);
+    int rc = call.begin(iq, nbytes, (psd_db ? 2 : 1) * nfl * sizeof(float));
+    if (!rc)
+        rc = call.run([&] {
+            return launch_welch(ctx, call.d_in, nbytes, chunk_samples, nperseg, fs, flags, call.dev<float>(),
+                                psd_db ? call.dev<float>() + nfl : nullptr);
+        });
+    if (!rc) rc = call.finish(kernel_ms);
+    if (rc) return rc;
+    memcpy(psd, call.host(), nfl * sizeof(float));
+    if (psd_db) memcpy(psd_db, call.host(nfl * sizeof(float)), nfl * sizeof(float));
+    return GJ_OK;
+}
+
+int gj_amp_stats_u8(gj_ctx* ctx, const uint8_t* iq, size_t nbytes, float threshold, gj_amp_stats* out, float* kernel_ms) {
+    if (!ctx) return GJ_ERR_INVALID;
+    if (!out || (nbytes && !iq)) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    HostCall call(ctx);
+    int rc = call.begin(iq, nbytes, sizeof(gj_amp_stats));
+    if (!rc) rc = call.run([&] { return launch_amp_stats(ctx, call.d_in, nbytes, threshold, call.dev<gj_amp_stats>()); });
+    if (!rc) rc = call.finish(kernel_ms);
+    if (rc) return rc;
+    memcpy(out, call.host(), sizeof(gj_amp_stats));
+    return GJ_OK;
+}
+
+int gj_onset_u8(gj_ctx* ctx, const uint8_t* iq, size_t nbytes, int noise_samples, int window, float factor, gj_onset* out,
+                float* kernel_ms) {
+    if (!ctx) return GJ_ERR_INVALID;
+    if (!out || (nbytes && !iq)) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    HostCall call(ctx);
+    int rc = call.begin(iq, nbytes, sizeof(gj_onset));
+    if (!rc) rc = call.run([&] { return launch_onset(ctx, call.d_in, nbytes, noise_samples, window, factor, call.dev<gj_onset>()); });
+    if (!rc) rc = call.finish(kernel_ms);
+    if (rc) return rc;
+    memcpy(out, call.host(), sizeof(gj_onset));
+    return GJ_OK;
+}
+
+// slices[a] may each be a host buffer (staged) or a device pointer into a resident capture (used in place)
+int gj_xcorr_lags_u8(gj_ctx* ctx, const uint8_t* const* slices, int n_ant, size_t n_samples, const int32_t* pairs,
+                     int n_pairs, int32_t* lags, float* peaks, float* margins, float* kernel_ms) {
+    if (!ctx) return GJ_ERR_INVALID;
+    if (!slices || !pairs || !lags || !peaks) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    if (n_ant < 1 || n_ant > GJ_MAX_ANTENNAS) return fail(ctx, GJ_ERR_INVALID, "n_ant must be 1..%d", GJ_MAX_ANTENNAS);
+    if (n_pairs < 1 || n_pairs > 4096) return fail(ctx, GJ_ERR_INVALID, "bad n_pairs");
+    for (int a = 0; a < n_ant; ++a)
+        if (!slices[a]) return fail(ctx, GJ_ERR_INVALID, "null slice %d", a);
+    HostCall call(ctx);
+    gj_lane* L = call.L;
+    if (!L) return GJ_ERR_NOMEM;
+    // lane staging: [slot x n_ant of staged slices][starts: 16 x int64][lags | peaks | margins]
+    const size_t slot = align_up(2 * n_samples, 256);
+    const size_t off_starts = slot * (size_t)n_ant + 256;
+    const size_t off_res = off_starts + 128;
+    const size_t res_bytes = 12 * (size_t)n_pairs;
+    int rc = lane_events(ctx, L);
+    if (!rc) rc = lane_stage(ctx, L, off_res + res_bytes + 256);
+    if (!rc) rc = lane_rpin(ctx, L, res_bytes + 256);
+    if (rc) return rc;
+    hipStream_t s = current_stream(ctx);
+    const uint8_t* d_ptrs[GJ_MAX_ANTENNAS];
+    size_t nbytes[GJ_MAX_ANTENNAS];
+    for (int a = 0; a < n_ant; ++a) {
+        nbytes[a] = 2 * n_samples;
+        if (n_samples && is_device_ptr(slices[a])) {
+            d_ptrs[a] = slices[a];
+        } else {
+            if (n_samples) GJ_HIP(ctx, hipMemcpyAsync(L->stage + slot * a, slices[a], 2 * n_samples, hipMemcpyHostToDevice, s));
+            d_ptrs[a] = L->stage + slot * a;
+        }
+    }
+    int64_t* d_starts = reinterpret_cast<int64_t*>(L->stage + off_starts);   // zeros: slices start at their first sample
+    int32_t* d_lags = reinterpret_cast<int32_t*>(L->stage + off_res);
+    float* d_peaks = reinterpret_cast<float*>(L->stage + off_res + 4 * (size_t)n_pairs);
+    float* d_margins = reinterpret_cast<float*>(L->stage + off_res + 8 * (size_t)n_pairs);
+    GJ_HIP(ctx, hipMemsetAsync(d_starts, 0, 128, s));
+    GJ_HIP(ctx, hipEventRecord(L->ev_done, s));
+    const int64_t* sp[GJ_MAX_ANTENNAS];
+    for (int a = 0; a < n_ant; ++a) sp[a] = d_starts + a;
+    call.s = s;
+    call.staged = true;
+    call.d_res = L->stage + off_res;
+    call.result_bytes = res_bytes;
+    rc = call.run([&] { return launch_xcorr(ctx, d_ptrs, nbytes, n_ant, sp, n_samples, pairs, n_pairs, d_lags, d_peaks, d_margins); });
+    if (!rc) rc = call.finish(kernel_ms);
+    if (rc) return rc;
+    memcpy(lags, call.host(), 4 * (size_t)n_pairs);
+    memcpy(peaks, call.host(4 * (size_t)n_pairs), 4 * (size_t)n_pairs);
+    if (margins) memcpy(margins, call.host(8 * (size_t)n_pairs), 4 * (size_t)n_pairs);
+    return GJ_OK;
+}
+
+}   // extern "C"

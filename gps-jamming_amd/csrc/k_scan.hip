@@ -529,7 +529,7 @@ struct OnsetScratch {
     unsigned long long first_inv;   // ~(min index whose moving average is above the threshold)
     unsigned long long cand_inv;    // ~(first sample of the first block that fails the screening proof)
     unsigned long long noise_S;     // sum of (2I-255)^2 + (2Q-255)^2 = 4 |z|^2 over the first noise_samples samples
-    unsigned long long reserved;
+    unsigned long long guard_inv;   // ~(min index whose moving average is above threshold * (1 - kOnsetGuard))
     float noise;
     float thr;
     // decision margin (gj_onset.margin_before): the largest window sum that stayed below the
@@ -540,6 +540,11 @@ struct OnsetScratch {
     unsigned max_below;
     unsigned max_screen;
 };
+
+// Rounding band of the decision (gj_onset.guard_index): the window sums here are exact, the reference's carry ~3e-7
+// of float32 rounding (|z|^2 per sample, the pairwise noise mean, the factor).  A moving average below
+// threshold * (1 - kOnsetGuard) is below the reference's threshold whatever its rounding did.
+constexpr double kOnsetGuard = 1e-6;
 
 __device__ __forceinline__ float onset_threshold(const OnsetScratch* sc, int noise_samples, float factor, float* noise_out) {
     float noise = (float)((double)sc->noise_S / (4.0 * (double)noise_samples));
@@ -584,8 +589,9 @@ __global__ __launch_bounds__(kScanThreads) void onset_coarse_kernel(const uint8_
     const size_t j0 = (size_t)blockIdx.x * kCoarseBlocks;   // first block of this tile
     const int tid = threadIdx.x;
     float noise;
-    const double thr = (double)onset_threshold(sc, noise_samples, factor, &noise);
-    if (blockIdx.x == 0 && tid == 0) { sc->noise = noise; sc->thr = (float)thr; }   // for the exact scan + report
+    const float thr_f = onset_threshold(sc, noise_samples, factor, &noise);
+    if (blockIdx.x == 0 && tid == 0) { sc->noise = noise; sc->thr = thr_f; }   // for the exact scan + report
+    const double thr = (double)thr_f * (1.0 - kOnsetGuard);   // screening proves blocks quiet against the guard band
     if (BS * j0 >= nout) return;
     if (~__hip_atomic_load(&sc->cand_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < BS * j0) return;
     const int cb = (window + BS - 2) / BS + 1;
@@ -726,25 +732,32 @@ __global__ __launch_bounds__(kScanThreads) void onset_scan_kernel(const uint8_t*
         const unsigned add = thread_tot[tid];
         for (int k = lo; k < hi; ++k) pre[onset_pad(k + 1)] += add;
         __syncthreads();
-        const double thr = (double)sc->thr;
+        const double thr = (double)sc->thr, thr_lo = thr * (1.0 - kOnsetGuard);
         const double scale = 0.25 / (double)window;
-        unsigned long long best = ~0ull;
+        unsigned long long best = ~0ull, best_lo = ~0ull;
         unsigned below = 0;   // largest window sum at the positions in front of this thread's first crossing
         const int nloc = (int)(o1 - o0);
         for (int k = tid; k < nloc; k += kScanThreads) {
             const unsigned S = pre[onset_pad(k + window)] - pre[onset_pad(k)];
-            if ((double)S * scale > thr) { best = o0 + k; break; }
+            const double ma = (double)S * scale;
+            if (ma > thr_lo) {
+                if (best_lo == ~0ull) best_lo = o0 + k;   // inside the rounding band (or above it)
+                if (ma > thr) { best = o0 + k; break; }
+            }
             below = S > below ? S : below;
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const unsigned long long o = __shfl_xor(best, off, 64);
             best = o < best ? o : best;
+            const unsigned long long ol = __shfl_xor(best_lo, off, 64);
+            best_lo = ol < best_lo ? ol : best_lo;
             const unsigned ob = __shfl_xor(below, off, 64);
             below = ob > below ? ob : below;
         }
         if ((tid & 63) == 0) {
             if (best != ~0ull) atomicMax(&sc->first_inv, ~best);
+            if (best_lo != ~0ull) atomicMax(&sc->guard_inv, ~best_lo);
             if (below) atomicMax(&sc->max_below, below);
         }
         __syncthreads();   // LDS is reused by the next tile
@@ -767,7 +780,7 @@ __global__ __launch_bounds__(64) void onset_finalize_kernel(const uint8_t* __res
     if (!valid) {
         if (tid == 0) {
             out->start_index = -1; out->noise_power = 0.f; out->threshold = 0.f;
-            out->margin_hit = 0.f; out->margin_before = 0.f; out->reserved = 0;
+            out->margin_hit = 0.f; out->margin_before = 0.f; out->guard_index = -1;
         }
         return;
     }
@@ -786,7 +799,11 @@ __global__ __launch_bounds__(64) void onset_finalize_kernel(const uint8_t* __res
         out->threshold = sc->thr;
         out->margin_hit = found ? (float)(((double)S * scale - thr) / thr) : 0.f;
         out->margin_before = (float)((thr - (double)mb * scale) / thr);
-        out->reserved = 0;
+        // first position inside (or above) the rounding band.  A tile in front of the crossing always runs to its
+        // end, so every band position before i0 has been seen; one behind i0 cannot be first.
+        unsigned long long ig = sc->guard_inv != 0ull ? ~sc->guard_inv : ~0ull;
+        if (found && i0 < ig) ig = i0;
+        out->guard_index = ig != ~0ull ? (long long)ig + window / 2 : -1;
     }
 }
 

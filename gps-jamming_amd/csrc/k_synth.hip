@@ -118,6 +118,13 @@ __global__ __launch_bounds__(1024) void pack_result_kernel(size_t n_chunks, cons
                 case 13: v = (double)rank; break;
                 case 14: v = (double)n_pairs; break;
                 case 15: v = (double)pair_cap; break;
+                case 16: v = onset->margin_hit; break;      // the decision margins travel with the result (gj_onset)
+                case 17: v = onset->margin_before; break;
+                case 18: v = (double)onset->guard_index; break;
+                case 19: v = onset->threshold; break;
+                case 20: v = (double)rank; break;           // antenna: the stream's own capture
+                case 22: v = 1.0; break;                    // parts: the whole capture
+                case 26: v = amp->sum; break;
                 default: v = 0.0;
             }
         } else if (i < head) {

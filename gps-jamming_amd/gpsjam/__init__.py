@@ -163,7 +163,10 @@ class Capture:
     byte_histogram / xcorr_lags_at`` any number of times.  The array-taking forms of those calls
     stage their input on every call (21 ms per GiB of PCIe against 0.2-1.3 ms of kernel time), so
     a caller that runs scan + PSD + RSSI on one file (widmo_plot, the worker's scan ->
-    triangulation flow) uses this instead.  ``uploads`` counts host->device passes (tests)."""
+    triangulation flow) uses this instead.  The library's ``*_u8`` entry points take the device
+    address as it is, so a call on a Capture works in a lane of its own like any other: several
+    host threads may use one Capture (and one Device) at once.  ``uploads`` counts host->device
+    passes (tests)."""
 
     uploads = 0
 
@@ -228,7 +231,6 @@ class Device:
         self._ctx = ctx
         self.index = int(index)
         self.last_kernel_ms = 0.0
-        self._scratch = None          # grow-only device buffer for the results of calls on a Capture
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc: int):
@@ -240,20 +242,24 @@ class Device:
         """Upload a capture file (path) or a uint8 array once; see ``Capture``."""
         return Capture(self, source, offset, max_bytes)
 
-    def _out(self, nbytes: int) -> DevBuf:
-        if self._scratch is None or self._scratch.nbytes < nbytes:
-            if self._scratch is not None:
-                self._scratch.free()
-            self._scratch = DevBuf(self, max(int(nbytes) + 256, 1 << 16))
-        return self._scratch
+    @staticmethod
+    def _input(raw):
+        """(address, nbytes, keep-alive) of a call's input: a resident Capture goes in by its device
+        address (the library uses it in place), anything else as a host uint8 buffer (staged)."""
+        if isinstance(raw, Capture):
+            if not raw.ptr and raw.nbytes:
+                raise ValueError("the capture has been freed")
+            return raw.ptr, raw.nbytes, raw
+        arr = as_u8(raw)
+        return (arr.ctypes.data if arr.size else None), int(arr.size), arr
+
+    def debug_counters(self):
+        """Lanes made / in use / taken back from dead callers, dead-owner recoveries of the mutex."""
+        v = [C.c_int(0) for _ in range(4)]
+        self._check(self._lib.gj_debug_counters(self._ctx, *[C.byref(x) for x in v]))
+        return dict(zip(("lanes", "lanes_busy", "lanes_reclaimed", "owner_deaths"), (x.value for x in v)))
 
     def close(self):
-        if getattr(self, "_scratch", None) is not None:
-            try:
-                self._scratch.free()
-            except Exception:
-                pass
-            self._scratch = None
         if getattr(self, "_ctx", None):
             self._lib.gj_destroy(self._ctx)
             self._ctx = None
@@ -311,22 +317,12 @@ class Device:
     # ------------------------------------------------------------------ host arrays
     def chunk_power(self, raw, chunk_bytes: int = 65536, eps: float = 1e-10,
                     odd_chunk_zero: bool = False) -> np.ndarray:
-        if isinstance(raw, Capture):
-            n = self._lib.gj_chunk_count(raw.nbytes, chunk_bytes)
-            if n == 0:
-                return np.empty(0, np.float32)
-            d = self._out(4 * n)
-            self.timer_start()
-            self.chunk_power_dev(raw, raw.nbytes, chunk_bytes, d, eps,
-                                 _ffi.GJ_CP_ODD_CHUNK_ZERO if odd_chunk_zero else 0)
-            self.last_kernel_ms = self.timer_stop()
-            return d.download(np.float32, n)
-        raw = as_u8(raw)
-        n = self._lib.gj_chunk_count(raw.size, chunk_bytes)
+        ptr, nbytes, _keep = self._input(raw)
+        n = self._lib.gj_chunk_count(nbytes, chunk_bytes)
         out = np.empty(n, np.float32)
         n_out, ms = C.c_size_t(0), C.c_float(0)
         self._check(self._lib.gj_chunk_power_u8(
-            self._ctx, raw.ctypes.data, raw.size, chunk_bytes, eps,
+            self._ctx, ptr, nbytes, chunk_bytes, eps,
             _ffi.GJ_CP_ODD_CHUNK_ZERO if odd_chunk_zero else 0, out.ctypes.data, out.size,
             C.byref(n_out), C.byref(ms)))
         self.last_kernel_ms = ms.value
@@ -335,57 +331,31 @@ class Device:
     def welch(self, raw, chunk_samples: int = 2048000, nperseg: int = 1024, fs: float = 2.048e6,
               shift: bool = True, want_db: bool = True):
         """(psd[rows, nperseg], psd_db[rows, nperseg] | None), float32."""
-        if isinstance(raw, Capture):
-            rows = self._lib.gj_welch_rows(raw.nbytes, chunk_samples, nperseg)
-            if rows == 0:
-                if nperseg < 16 or nperseg > 4096 or (nperseg & (nperseg - 1)):
-                    raise GpsJamError(-5, "unsupported size or parameter: nperseg must be a power of two in [16, 4096]")
-                return np.empty((0, nperseg), np.float32), (np.empty((0, nperseg), np.float32) if want_db else None)
-            nfl = rows * nperseg
-            d = self._out(8 * nfl)
-            self.timer_start()
-            self.welch_dev(raw, raw.nbytes, chunk_samples, nperseg, fs, d.ptr, d.ptr + 4 * nfl if want_db else None, shift)
-            self.last_kernel_ms = self.timer_stop()
-            psd = d.download(np.float32, nfl).reshape(rows, nperseg)
-            db = d.download(np.float32, nfl, offset=4 * nfl).reshape(rows, nperseg) if want_db else None
-            return psd, db
-        raw = as_u8(raw)
-        rows = self._lib.gj_welch_rows(raw.size, chunk_samples, nperseg)
+        ptr, nbytes, _keep = self._input(raw)
+        rows = self._lib.gj_welch_rows(nbytes, chunk_samples, nperseg)
         psd = np.empty((rows, nperseg), np.float32)
         db = np.empty((rows, nperseg), np.float32) if want_db else None
         rows_out, ms = C.c_size_t(0), C.c_float(0)
         self._check(self._lib.gj_welch_u8(
-            self._ctx, raw.ctypes.data, raw.size, chunk_samples, nperseg, fs,
+            self._ctx, ptr, nbytes, chunk_samples, nperseg, fs,
             _ffi.GJ_WELCH_SHIFT if shift else 0, psd.ctypes.data,
             db.ctypes.data if want_db else None, psd.size, C.byref(rows_out), C.byref(ms)))
         self.last_kernel_ms = ms.value
         return psd, db
 
     def amp_stats(self, raw, threshold: float) -> AmpStats:
-        if isinstance(raw, Capture):
-            d = self._out(64)
-            self.timer_start()
-            self.amp_stats_dev(raw, raw.nbytes, threshold, d)
-            self.last_kernel_ms = self.timer_stop()
-            return AmpStats.from_buffer_copy(d.download(np.uint8, C.sizeof(AmpStats)).tobytes())
-        raw = as_u8(raw)
+        ptr, nbytes, _keep = self._input(raw)
         out, ms = AmpStats(), C.c_float(0)
-        self._check(self._lib.gj_amp_stats_u8(self._ctx, raw.ctypes.data, raw.size, threshold,
+        self._check(self._lib.gj_amp_stats_u8(self._ctx, ptr, nbytes, threshold,
                                               C.byref(out), C.byref(ms)))
         self.last_kernel_ms = ms.value
         return out
 
     def onset(self, raw, noise_samples: int = 200000, window: int = 1000,
               factor: float = 50.0) -> Onset:
-        if isinstance(raw, Capture):
-            d = self._out(64)
-            self.timer_start()
-            self.onset_dev(raw, raw.nbytes, noise_samples, window, factor, d)
-            self.last_kernel_ms = self.timer_stop()
-            return Onset.from_buffer_copy(d.download(np.uint8, C.sizeof(Onset)).tobytes())
-        raw = as_u8(raw)
+        ptr, nbytes, _keep = self._input(raw)
         out, ms = Onset(), C.c_float(0)
-        self._check(self._lib.gj_onset_u8(self._ctx, raw.ctypes.data, raw.size, noise_samples,
+        self._check(self._lib.gj_onset_u8(self._ctx, ptr, nbytes, noise_samples,
                                           window, factor, C.byref(out), C.byref(ms)))
         self.last_kernel_ms = ms.value
         return out
@@ -394,31 +364,40 @@ class Device:
                       pairs: Sequence[Sequence[int]], want_margins: bool = False):
         """Lags between resident captures: slice a = n_samples I/Q pairs of captures[a] from
         starts[a] (negative / out of range -> GJ_LAG_INVALID for its pairs).  No slice ever
-        leaves HBM."""
-        flat = np.asarray(pairs, np.int32).reshape(-1)
-        npairs = flat.size // 2
-        na = len(captures)
-        d = self._out(8 * na + 12 * npairs + 64)
-        off_l = 8 * na
-        d.upload(np.asarray(starts, np.int64))
-        self.timer_start()
-        self.xcorr_lags_dev(captures, [c.nbytes for c in captures], d.ptr, n_samples, pairs, d.ptr + off_l,
-                            d.ptr + off_l + 4 * npairs, d.ptr + off_l + 8 * npairs)
-        self.last_kernel_ms = self.timer_stop()
-        lags = d.download(np.int32, npairs, offset=off_l)
-        peaks = d.download(np.float32, npairs, offset=off_l + 4 * npairs)
+        leaves HBM: the slices go to the library as device addresses inside the captures."""
+        prs = [tuple(int(x) for x in p) for p in np.asarray(pairs, np.int64).reshape(-1, 2)]
+        ok = [0 <= int(st) and 2 * (int(st) + n_samples) <= c.nbytes for c, st in zip(captures, starts)]
+        lags = np.full(len(prs), GJ_LAG_INVALID, np.int32)
+        peaks = np.zeros(len(prs), np.float32)
+        margins = np.zeros(len(prs), np.float32)
+        live = [k for k, (i, j) in enumerate(prs) if ok[i] and ok[j]]
+        if live and n_samples > 0:
+            used = sorted({a for k in live for a in prs[k]})
+            local = {a: n for n, a in enumerate(used)}
+            ptrs = (C.c_void_p * len(used))(*[captures[a].ptr + 2 * int(starts[a]) for a in used])
+            flat = np.ascontiguousarray(np.array([[local[prs[k][0]], local[prs[k][1]]] for k in live], np.int32).reshape(-1))
+            l2, p2, m2 = (np.empty(len(live), np.int32), np.empty(len(live), np.float32), np.empty(len(live), np.float32))
+            ms = C.c_float(0)
+            self._check(self._lib.gj_xcorr_lags_u8(
+                self._ctx, ptrs, len(used), n_samples, flat.ctypes.data_as(C.POINTER(C.c_int32)), len(live),
+                l2.ctypes.data_as(C.POINTER(C.c_int32)), p2.ctypes.data_as(C.POINTER(C.c_float)),
+                m2.ctypes.data_as(C.POINTER(C.c_float)), C.byref(ms)))
+            self.last_kernel_ms = ms.value
+            lags[live], peaks[live], margins[live] = l2, p2, m2
         if want_margins:
-            return lags, peaks, d.download(np.float32, npairs, offset=off_l + 8 * npairs)
+            return lags, peaks, margins
         return lags, peaks
 
     def byte_histogram(self, cap: "Capture", chunk_samples: int = 2048000, nperseg: int = 1024,
                        stride: int = 100) -> np.ndarray:
         """256-bin histogram of raw_chunk[::stride] over the chunks the waterfall keeps
         (widmo_plot.py:35,85)."""
-        d = self._out(8 * 256)
-        self.byte_histogram_dev(cap, cap.nbytes, chunk_samples, nperseg, stride, d)
-        self.synchronize()
-        return d.download(np.uint64, 256)
+        d = DevBuf(self, 8 * 256)          # a buffer of this call's own: several threads may histogram at once
+        try:
+            self.byte_histogram_dev(cap, cap.nbytes, chunk_samples, nperseg, stride, d)
+            return d.download(np.uint64, 256)
+        finally:
+            d.free()
 
     def xcorr_lags(self, slices: Sequence, pairs: Sequence[Sequence[int]], want_margins: bool = False):
         """lags[p], peaks[p] (, margins[p]) for pairs (i, j): lag of slice j relative to slice i

@@ -31,7 +31,9 @@ class AmpStats(C.Structure):
 class Onset(C.Structure):
     _fields_ = [("start_index", C.c_int64), ("noise_power", C.c_float),
                 ("threshold", C.c_float), ("margin_hit", C.c_float),
-                ("margin_before", C.c_float), ("reserved", C.c_int64)]
+                ("margin_before", C.c_float), ("guard_index", C.c_int64)]
+
+    NEAR_TIE = 1e-6       # the rounding band of include/gpsjam.h (gj_onset.guard_index)
 
     @property
     def margin(self) -> float:
@@ -39,6 +41,15 @@ class Onset(C.Structure):
         if self.start_index < 0:
             return float(self.margin_before)
         return float(min(self.margin_hit, self.margin_before))
+
+    @property
+    def near_tie(self) -> bool:
+        """True when the reference's float32 arithmetic could decide differently: a moving average sits
+        inside the rounding band in front of the crossing, or the crossing itself clears the threshold by
+        less than the band."""
+        if self.guard_index != self.start_index:
+            return True
+        return self.start_index >= 0 and self.margin_hit < self.NEAR_TIE
 
 
 class SynthParams(C.Structure):
@@ -53,7 +64,7 @@ GJ_MAX_ANTENNAS = 16
 GJ_LAG_INVALID = -(1 << 31)
 GJ_SLOT_HEADER = 16
 GJ_COMM_ID_BYTES = 128
-GJ_VERSION = 110
+GJ_VERSION = 120
 
 _vp, _sz, _i, _f, _d = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double
 _pf, _psz = C.POINTER(C.c_float), C.POINTER(C.c_size_t)
@@ -72,6 +83,8 @@ SIGNATURES = {
     "gj_get_unpack": (_i, [_vp, C.POINTER(_d), C.POINTER(_d)]),
     "gj_device_info": (_i, [_vp, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(C.c_uint64)]),
     "gj_reserve": (_i, [_vp, _sz]),
+    "gj_debug_set_wait_hook": (_i, [_vp, _vp, _vp]),
+    "gj_debug_counters": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "gj_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "gj_free": (_i, [_vp, _vp]),
     "gj_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),

@@ -27,13 +27,22 @@ import contextlib
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple  # noqa: F401
 
+import logging
+
 import numpy as np
 import torch
 
-HEADER = 16          # scalars in front of the vectors, see RESULT_FIELDS
+_log = logging.getLogger("gpsjam.sharded")
+
+HEADER = 32          # GJ_RESULT_HEADER: scalars in front of the vectors, see RESULT_FIELDS
 RESULT_FIELDS = ("n_chunks", "baseline", "threshold", "n_above", "amp_first", "amp_count",
                  "amp_mean", "onset", "lag", "peak", "noise_power", "n_rows", "nperseg",
-                 "rank", "reserved0", "reserved1")
+                 "rank", "n_pairs", "pair_capacity", "onset_margin_hit", "onset_margin_before",
+                 "onset_guard", "onset_threshold", "antenna", "part", "parts", "first_chunk",
+                 "first_row", "first_sample", "amp_sum", "amp_tail", "tiles",
+                 "reserved0", "reserved1", "reserved2")
+ONSET_NEAR_TIE = 1e-6     # gj_onset: the rounding band of K4's decision (include/gpsjam.h)
+LAG_NEAR_TIE = 2e-5       # K5: 1 - runner-up/peak below the rounding of a complex64 FFT
 SLOT_HEADER = 16     # GJ_SLOT_HEADER: int64 flag (0 valid / -1 invalid), int64 start sample
 LAG_INVALID = -(1 << 31)
 
@@ -87,7 +96,8 @@ def pack_results(n_chunks: int, nperseg: int, power_map: torch.Tensor, stats: to
                  noise_power: torch.Tensor, mean_spectrum: torch.Tensor, n_rows: int,
                  rank: int, pairs: Sequence[Tuple[int, int]] = (), pair_lags: Optional[torch.Tensor] = None,
                  pair_peaks: Optional[torch.Tensor] = None, pair_margins: Optional[torch.Tensor] = None,
-                 capacity: int = 0) -> torch.Tensor:
+                 capacity: int = 0, onset_margins: Sequence[float] = (1.0, 1.0), onset_guard: Optional[torch.Tensor] = None,
+                 onset_threshold: float = 0.0, amp_sum: float = 0.0) -> torch.Tensor:
     """float64 vector [HEADER + n_chunks + nperseg + 5 capacity] (the layout of gj_pack_result_dev) built
     with device-side ops only (no host synchronisation).  int64 scalars are exact in float64 up to 2^53."""
     dev = power_map.device
@@ -106,6 +116,12 @@ def pack_results(n_chunks: int, nperseg: int, power_map: torch.Tensor, stats: to
     head[13] = rank
     head[14] = len(pairs)
     head[15] = capacity
+    head[16], head[17] = float(onset_margins[0]), float(onset_margins[1])
+    head[18] = onset.to(torch.float64) if onset_guard is None else onset_guard.to(torch.float64)
+    head[19] = onset_threshold
+    head[20] = rank
+    head[22] = 1
+    head[26] = float(amp_sum)
     block = torch.zeros((capacity, PAIR_FIELDS), dtype=torch.float64, device=dev)
     if len(pairs):
         block[:len(pairs), 0:2] = torch.tensor(list(pairs), dtype=torch.float64, device=dev)
@@ -131,6 +147,19 @@ class StreamResult:
     noise_power: float
     mean_spectrum: np.ndarray
     solved: List[Tuple[int, int, int, float, float]] = field(default_factory=list)   # (i, j, lag, peak, margin) this stream solved
+    onset_margin_hit: float = 1.0      # gj_onset margins: how clearly K4's crossing cleared the threshold ...
+    onset_margin_before: float = 1.0   # ... and how clearly everything in front of it stayed below
+    onset_guard: int = -1              # first index inside K4's rounding band (== onset when the decision is clear)
+    onset_threshold: float = 0.0
+
+    @property
+    def onset_near_tie(self) -> bool:
+        """The onset was decided inside the rounding band of the reference's float32 arithmetic
+        (skrypty/triangulateTDOA.py:37-49): a caller that needs the reference's exact index re-evaluates its
+        expression from ``onset_guard`` on (the drop-in skrypty/triangulateTDOA.py does)."""
+        if self.onset_guard != self.onset:
+            return True
+        return self.onset >= 0 and self.onset_margin_hit < ONSET_NEAR_TIE
 
     def jamming_byte_ranges(self, chunk_bytes: int = 65536):
         """(start_byte, end_byte) runs above the threshold (worker.py:248-264)."""
@@ -159,6 +188,12 @@ class TdoaResult:
     def lag(self, i: int, j: int) -> int:
         return self.lags[self.pairs.index((i, j))]
 
+    @property
+    def near_ties(self) -> List[Tuple[int, int]]:
+        """Pairs whose arg-max was decided inside the rounding of a complex64 FFT (margin < LAG_NEAR_TIE):
+        the reference's own choice between the two lags depends on ITS rounding (triangulateTDOA.py:86-89)."""
+        return [p for p, lag, m in zip(self.pairs, self.lags, self.margins) if lag != LAG_INVALID and m < LAG_NEAR_TIE]
+
 
 def unpack_results(vec: torch.Tensor) -> StreamResult:
     v = vec.detach().to("cpu", torch.float64).numpy()
@@ -171,7 +206,9 @@ def unpack_results(vec: torch.Tensor) -> StreamResult:
     return StreamResult(rank=int(v[13]), power_map=pm, baseline=float(v[1]), threshold=float(v[2]),
                         n_above=int(v[3]), amp_first=int(v[4]), amp_count=int(v[5]),
                         amp_mean=float(v[6]), onset=int(v[7]), lag=int(v[8]), peak=float(v[9]),
-                        noise_power=float(v[10]), mean_spectrum=spec, solved=solved)
+                        noise_power=float(v[10]), mean_spectrum=spec, solved=solved,
+                        onset_margin_hit=float(v[16]), onset_margin_before=float(v[17]), onset_guard=int(v[18]),
+                        onset_threshold=float(v[19]))
 
 
 def make_slot(capture_u8: torch.Tensor, start: int, n_samples: int) -> torch.Tensor:
@@ -238,6 +275,7 @@ class StepResults:
 
     def __init__(self, vectors, event, n_ant):
         self.vectors, self.event, self.n_ant = vectors, event, n_ant
+        self.near_ties = None      # filled by unpack(): {"onset": [ranks], "lag": [pairs]} decided inside a rounding band
 
     def wait(self, stream=None):
         """Make ``stream`` (default: torch's current stream) wait for the exchange."""
@@ -272,6 +310,12 @@ class StepResults:
                 r.lag, r.peak = 0, 0.0
             elif (0, r.rank) in table:
                 r.lag, r.peak = table[(0, r.rank)][0], table[(0, r.rank)][1]
+        # decisions taken inside a rounding band: rank 0 knows, and says so once per step
+        self.near_ties = {"onset": [r.rank for r in res if r.onset_near_tie], "lag": td.near_ties}
+        if self.near_ties["onset"] or self.near_ties["lag"]:
+            _log.warning("near-tie decisions: onset of stream(s) %s, lag of pair(s) %s -- decided by the GPU's exact "
+                         "arithmetic; the reference's float32 rounding could choose a neighbouring index",
+                         self.near_ties["onset"], self.near_ties["lag"])
         return res, td
 
     def tdoa(self) -> TdoaResult:
@@ -288,14 +332,17 @@ class AntennaStream:
     three antennas, three pairs on one GPU).
     ``transport``: "torch" = torch.distributed (nccl = RCCL on HIP tensors, gloo for rehearsal);
     "rccl" = the library's own gj_comm_* entry points (gpsjam.comm), no torch.distributed; or a
-    ready ``gpsjam.comm.Communicator`` on the context the side stream uses."""
+    ready ``gpsjam.comm.Communicator``.  The collectives are enqueued on the stream of the context the
+    communicator was made on, and that must be the context the slot and K5 kernels run on -- with
+    ``overlap`` the side context: pass it in as ``side_device`` (and build the Communicator on it);
+    a communicator bound to any other context is refused."""
 
     def __init__(self, dev, capture: torch.Tensor, *, chunk_bytes: int = 65536,
                  chunk_samples: int = 2048000, nperseg: int = 4096, fs: float = 2.048e6,
                  slice_samples: int = 1 << 19, noise_samples: int = 200000, window: int = 1000,
                  factor: float = 50.0, rssi_threshold: float = 0.0, rank: int = 0, world_size: int = 1,
                  overlap: Optional[bool] = None, aux_slots: Optional[torch.Tensor] = None,
-                 transport="torch"):
+                 transport="torch", side_device=None):
         assert capture.dtype == torch.uint8 and capture.is_contiguous()
         self.dev, self.cap = dev, capture
         # K2 is bound by VALU issue and leaves ~90 % of the HBM bandwidth idle, the fused scan is HBM
@@ -310,8 +357,10 @@ class AntennaStream:
             # the pipeline's torch ops, its events and the gpsjam kernels must share one stream
             self._main = torch.cuda.current_stream(capture.device)
             dev.set_stream(self._main.cuda_stream)
+        self._own_side = False
         if self.overlap:
-            self.dev_side = type(dev)(dev.index)
+            self.dev_side = side_device if side_device is not None else type(dev)(dev.index)
+            self._own_side = side_device is None
             self._side = torch.cuda.Stream(device=capture.device)
             self.dev_side.set_stream(self._side.cuda_stream)
             self._ev_free = torch.cuda.Event()      # main: previous results consumed, buffers may be rewritten
@@ -340,6 +389,9 @@ class AntennaStream:
             from .comm import Communicator
             self.comm = Communicator(self.dev_side, rank, world_size)
         elif not isinstance(transport, str):
+            if getattr(transport, "dev", None) is not self.dev_side:
+                raise ValueError("the Communicator must be made on the context the exchange runs on"
+                                 + (" (pass that Device as side_device=)" if self.overlap else ""))
             self.comm = transport
         self._exchange = world_size > 1 or self.comm is not None   # a communicator is used even when alone
         # TDOA: the slots of every antenna (all-gathered: every rank holds them all), the pairs THIS rank solves
@@ -474,5 +526,5 @@ class AntennaStream:
     def close(self):
         if self.comm is not None and hasattr(self.comm, "close"):
             self.comm.close()
-        if self.overlap and self.dev_side is not self.dev:
+        if self.overlap and self._own_side and self.dev_side is not self.dev:
             self.dev_side.close()

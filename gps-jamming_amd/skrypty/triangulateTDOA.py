@@ -11,6 +11,7 @@ complex64 expansion of the whole file that the reference performs (:33-34) never
 ``load_iq_data`` therefore returns a light handle that keeps the bytes; code that indexes it
 like an array still gets the reference's un-normalised complex64 values.
 """
+import logging
 import math
 import os
 import sys
@@ -71,25 +72,35 @@ def _raw_of(iq_data):
     return iq_data.raw if isinstance(iq_data, IQCapture) else None
 
 
-# Decision margins below which the GPU's decision and the reference's may differ: the kernels sum
+# Rounding bands inside which the GPU's decision and the reference's may differ: the kernels sum
 # exact integers / run a radix-16 complex64 FFT, the reference sums float32 |z|^2 (pairwise mean,
-# float64 inside np.convolve) / runs pocketfft.  Either side carries ~1e-7 (onset threshold) and
-# ~1e-6 (correlation peak) of rounding, so inside these margins the reference's own expression is
-# evaluated on the host and decides -- outside them the index is the reference's by construction.
+# float64 inside np.convolve) / runs pocketfft.  Either side carries ~3e-7 (onset threshold) and
+# ~1e-6 (correlation peak) of rounding.  K4 reports the first index whose exact moving average is
+# inside (or above) the band, ``guard_index``: in front of it the reference cannot cross, so when a
+# decision does fall inside the band the reference's own expression is evaluated on the host FROM
+# THERE ON (a few windows, not the capture) and decides; outside the band the index is the
+# reference's by construction.
 ONSET_NEAR_TIE = 1e-6
 LAG_NEAR_TIE = 2e-5
 near_tie_events = []     # (what, margin): filled when the host re-evaluation ran (diagnostics / tests)
+_log = logging.getLogger("gpsjam.tdoa")
 
 
-def _onset_reference_expression(raw, noise_samples, window_size, threshold_factor, stop_after=None):
-    """The reference's own arithmetic (:37-49) on the raw bytes, block by block so that a long
-    capture never needs its 8x float expansion at once: float32 |z|^2, float32 mean of the noise
-    span, float64 moving average by np.convolve(..., 'valid'), first index above the threshold.
-    Only used inside ONSET_NEAR_TIE; ``stop_after``: no crossing can lie beyond this index."""
-    n = raw.size // 2
+def _onset_reference_expression(raw, noise_samples, window_size, threshold_factor, first_position=0,
+                                fetch=None, n_samples=None):
+    """The reference's own arithmetic (:37-49) on the raw bytes: float32 |z|^2, float32 mean of the
+    noise span, float64 moving average by np.convolve(..., 'valid'), first index above the threshold.
+    Evaluated from moving-average position ``first_position`` on, in blocks that grow from a few
+    windows to 4 Mi positions, so that the usual near-tie (the reference crosses within a window or
+    two of the exact crossing) costs microseconds and a capture is never expanded 8x at once.
+    ``fetch(a, b)`` returns the uint8 bytes of samples [a, b) (a resident capture); default: ``raw``."""
+    n = (raw.size // 2) if n_samples is None else int(n_samples)
+    if fetch is None:
+        def fetch(a, b):
+            return raw[2 * a:2 * b]
 
     def power_of(a, b):
-        seg = raw[2 * a:2 * b]
+        seg = fetch(a, b)
         z = (seg[0::2].astype(np.float32) - 127.5) + 1j * (seg[1::2].astype(np.float32) - 127.5)
         return np.abs(z.astype(np.complex64)) ** 2
 
@@ -99,16 +110,31 @@ def _onset_reference_expression(raw, noise_samples, window_size, threshold_facto
     threshold = noise_power * threshold_factor
     kernel = np.ones(window_size) / window_size
     n_out = n - window_size + 1
-    if stop_after is not None:
-        n_out = min(n_out, int(stop_after) + 1)
-    block = 1 << 22
-    for o0 in range(0, n_out, block):
+    o0 = max(int(first_position), 0)
+    block = max(4 * window_size, 1 << 12)
+    while o0 < n_out:
         o1 = min(o0 + block, n_out)
         ma = np.convolve(power_of(o0, o1 + window_size - 1), kernel, mode='valid')
         hit = np.where(ma > threshold)[0]
         if hit.size:
             return int(o0 + hit[0] + window_size // 2)
+        o0, block = o1, min(4 * block, 1 << 22)
     return -1
+
+
+def _resolve_near_tie(res, window_size, evaluate):
+    """K4's result -> the reference's index.  ``evaluate(first_position)`` runs the reference expression."""
+    if not res.near_tie:
+        return int(res.start_index)
+    near_tie_events.append(("onset", float(res.margin)))
+    if res.guard_index < 0:        # nothing reaches even the band: cannot happen with near_tie, kept for safety
+        return -1
+    first = int(res.guard_index) - int(window_size) // 2
+    got = evaluate(first)
+    _log.warning("onset decided inside the rounding band (margin %.2e at index %d, band from %d): the reference's "
+                 "float32 expression was evaluated on the host from there on -> %d",
+                 res.margin, res.start_index, res.guard_index, got)
+    return got
 
 
 def find_interference_start(iq_data, noise_samples, window_size, threshold_factor):
@@ -120,13 +146,8 @@ def find_interference_start(iq_data, noise_samples, window_size, threshold_facto
     if len(iq_data) < noise_samples + window_size:
         return -1
     res = gpsjam.default_device().onset(raw, int(noise_samples), int(window_size), float(threshold_factor))
-    if res.margin >= ONSET_NEAR_TIE:
-        return int(res.start_index)
-    # a moving average within rounding of the threshold: let the reference's expression decide.  The
-    # exact crossing bounds the search: nothing later than it (+ one window of slack) can be first.
-    near_tie_events.append(("onset", float(res.margin)))
-    stop = None if res.start_index < 0 else int(res.start_index) + int(window_size)
-    return _onset_reference_expression(raw, int(noise_samples), int(window_size), float(threshold_factor), stop)
+    return _resolve_near_tie(res, window_size, lambda first: _onset_reference_expression(
+        raw, int(noise_samples), int(window_size), float(threshold_factor), first))
 
 
 def correlation_lag(signal1_slice, signal0_slice):
@@ -141,6 +162,8 @@ def correlation_lag(signal1_slice, signal0_slice):
     # two lags within FFT rounding of each other: the reference's choice depends on ITS rounding,
     # so its own call (:86-89) decides
     near_tie_events.append(("lag", float(margins[0])))
+    _log.warning("lag decided inside the rounding of a complex64 FFT (peak margin %.2e): scipy.signal.correlate "
+                 "evaluated on the host", float(margins[0]))
     from scipy import signal
     corr = signal.correlate(np.asarray(signal1_slice), np.asarray(signal0_slice), mode='full')
     k = int(np.argmax(np.abs(corr)))

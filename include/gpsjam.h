@@ -10,15 +10,22 @@
  *  - every function returns GJ_OK (0) or a negative gj_status; gj_strerror() gives text,
  *    gj_last_error() the detailed message of the last failure on a context;
  *  - plain pointers and sizes only; the caller owns every buffer;
- *  - one opaque gj_ctx per GPU; calls on one context are serialised by an internal
- *    mutex, different contexts are independent; the library may be entered from several
- *    host threads (the GUI's QThread, its HTTP handler thread, its triangulation thread);
+ *  - one opaque gj_ctx per GPU; different contexts are independent; the library may be entered
+ *    from several host threads (the GUI's QThread, its HTTP handler thread, its triangulation
+ *    thread).  The context's internal mutex is held only while work is ENQUEUED, never across a
+ *    host-side wait, a file read or a staged copy, and it is a robust mutex: a caller that is
+ *    killed inside a call (QThread.terminate(), GpsJammerApp/app/ui_mainwindow.py:818-826) does
+ *    not block the next one.  Every "*_u8" / upload call works in buffers of its own (a "lane":
+ *    device staging, pinned bounce buffers, events), so concurrent calls on one context never
+ *    share a result area; kernels of all calls are ordered on the context's one stream;
  *  - "*_dev" functions take DEVICE pointers, enqueue on the context's stream and return
  *    without synchronising (results land in device memory; no host synchronisation, no
  *    allocation when the workspace has been reserved) -- this is what bench.py times;
  *  - "*_u8" functions take HOST buffers (numpy arrays), stage them to HBM, run the same
  *    kernels, copy the small results back and return synchronously, reporting the
- *    kernel-only time measured with HIP events on the context's stream.
+ *    kernel-only time measured with HIP events on the context's stream.  Their input may also
+ *    be a DEVICE pointer (a resident capture from gj_upload / gj_upload_file / gj_malloc, or
+ *    an address inside one): it is then used in place and nothing is staged;
  *  - samples are interleaved unsigned 8-bit I,Q,I,Q,... (RTL-SDR, README.md:95); one
  *    "sample" = one I/Q pair = 2 bytes.
  */
@@ -32,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GJ_VERSION 110 /* 0.1.1: gj_onset grew to 32 bytes, K5 margins, TDOA slots, gj_comm_*, captures, acquisition */
+#define GJ_VERSION 120 /* 0.1.2: lanes (no lock across waits), *_u8 take device pointers, result header 32, capture parts */
 
 typedef struct gj_ctx gj_ctx;
 
@@ -49,7 +56,7 @@ typedef enum gj_status {
 /* ---------------------------------------------------------------- context ---------- */
 int gj_version(void);
 const char* gj_strerror(int status);
-const char* gj_last_error(gj_ctx* ctx);
+const char* gj_last_error(gj_ctx* ctx); /* of the CALLING THREAD's last failure (kept per thread) */
 int gj_device_count(int* count);
 int gj_create(int device_id, gj_ctx** out);
 int gj_destroy(gj_ctx* ctx); /* idempotent on NULL */
@@ -73,6 +80,15 @@ int gj_device_info(gj_ctx* ctx, char* name, size_t name_cap, int* compute_units,
                    uint64_t* hbm_bytes);
 /* Pre-size the internal workspace so that later *_dev calls allocate nothing. */
 int gj_reserve(gj_ctx* ctx, size_t workspace_bytes);
+/* Diagnostics.  The hook is called, with NO internal lock held, right before every host-side wait of
+ * the library (site: 1 event, 2 stream, 3 staged copy, 4 waiting for a free lane); tests park or end
+ * a thread there to show that an abandoned caller blocks nobody.  Site 5 is the exception: it is
+ * inside gj_debug_counters WITH the lock held, so that a test can end a thread as the mutex's owner
+ * and watch the next caller recover it.  NULL removes the hook.  The counters:
+ * lanes made, lanes in use, lanes taken back from callers whose thread had gone, and how often the
+ * mutex was found with a dead owner. */
+int gj_debug_set_wait_hook(gj_ctx* ctx, void (*hook)(void* arg, int site), void* arg);
+int gj_debug_counters(gj_ctx* ctx, int* lanes, int* lanes_busy, int* lanes_reclaimed, int* owner_deaths);
 
 /* device memory for callers that do not bring their own allocator (torch) */
 int gj_malloc(gj_ctx* ctx, size_t bytes, void** dptr);
@@ -172,15 +188,20 @@ typedef struct gj_onset {
     /* Decision margins, relative to the threshold.  The window sums here are exact integers and
      * the noise mean is rounded once; the reference sums float32 |z|^2 (pairwise for the noise
      * mean, float64 inside np.convolve), so its threshold and moving averages differ from these in
-     * the last ulps (~1e-7 relative).  When both margins are >= 1e-6 the index is the reference's
-     * index by construction; below that a caller that needs the reference's exact decision
-     * re-evaluates the reference's expression (skrypty/triangulateTDOA.py does, on the host). */
+     * the last ulps (~1e-7 relative).  See guard_index below for the exact statement of when the
+     * index is the reference's by construction. */
     float margin_hit;    /* (moving average at the crossing - threshold) / threshold; 0 if not found */
     float margin_before; /* (threshold - largest moving average in front of the crossing) / threshold;
                           * positions the screening pass proved quiet enter with their upper bound, so
                           * this can under-state the true gap, never over-state it.  Not found: over the
                           * whole capture. */
-    int64_t reserved;
+    /* First index (+ window/2, like start_index) whose moving average exceeds threshold * (1 - 1e-6),
+     * -1 if none.  In front of it every moving average is below the reference's threshold whatever
+     * the reference's float32 rounding did, so the reference's own first crossing cannot lie before
+     * it.  guard_index == start_index and margin_hit >= 1e-6: the index is the reference's by
+     * construction.  Otherwise only the positions from guard_index on need the reference's
+     * arithmetic (skrypty/triangulateTDOA.py evaluates it there, on the host). */
+    int64_t guard_index;
 } gj_onset;
 int gj_onset_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, int noise_samples, int window,
                  float factor, gj_onset* d_out);
@@ -241,15 +262,21 @@ int gj_xcorr_slots_dev(gj_ctx* ctx, const uint8_t* d_slots, size_t slot_stride, 
 
 /* ------------------------------------------------- per-stream result vector ---------- */
 /* What one rank sends to rank 0 (gpsjam/sharded.py):
- * double[16 + n_chunks + nperseg + 5*pair_capacity] =
- * { n_chunks, baseline, threshold, n_above, amp.first_index, amp.count, amp.mean,
- *   onset.start_index, lag vs antenna 0 (0 on rank 0, GJ_LAG_INVALID elsewhere: the receiver fills
- *   it in from the pair table), 0, onset.noise_power, rows, nperseg, rank, n_pairs, pair_capacity },
+ * double[32 + n_chunks + nperseg + 5*pair_capacity] =
+ * header {  0 n_chunks, 1 baseline, 2 threshold, 3 n_above, 4 amp.first_index, 5 amp.count, 6 amp.mean,
+ *           7 onset.start_index, 8 lag vs antenna 0 (0 on rank 0, GJ_LAG_INVALID elsewhere: the receiver
+ *           fills it in from the pair table), 9 0, 10 onset.noise_power, 11 rows, 12 nperseg, 13 rank,
+ *          14 n_pairs, 15 pair_capacity,
+ *          16 onset.margin_hit, 17 onset.margin_before, 18 onset.guard_index, 19 onset.threshold -- the
+ *             decision margins of K4 travel with the result, so the receiver knows when an onset was
+ *             decided inside the rounding band (skrypty/triangulateTDOA.py:37-49),
+ *          20 antenna, 21 part, 22 parts (1 = the stream is a whole capture), 23 first chunk, 24 first row,
+ *          25 first sample of the part, 26 amp.sum, 27 amp tail, 28 tiles, 29-31 reserved },
  * the float32 power map, the mean over the rows of the PSD waterfall, and the pairs THIS stream
  * solved as {i, j, lag, peak, margin} each (d_pairs = {i0,j0,i1,j1,...} and the outputs of
  * gj_xcorr_slots_dev, all DEVICE arrays), zero-padded to pair_capacity -- packed by one kernel
  * from device-resident outputs (no host synchronisation). */
-#define GJ_RESULT_HEADER 16
+#define GJ_RESULT_HEADER 32
 #define GJ_RESULT_PAIR_FIELDS 5
 int gj_pack_result_dev(gj_ctx* ctx, size_t n_chunks, const float* d_power, const float* d_stats,
                        const gj_amp_stats* d_amp, const gj_onset* d_onset, const float* d_psd, size_t rows,

@@ -1,0 +1,103 @@
+/* A caller that is killed inside the library must not take the context with it (the GUI stops
+ * an analysis with QThread.terminate(), GpsJammerApp/app/ui_mainwindow.py:818-826).  Threads are ended with a raw
+ * exit system call -- no unwinding, no destructors, exactly what a hard kill leaves behind -- at the library's own
+ * wait sites (gj_debug_set_wait_hook), and the main thread then keeps using the same context:
+ *   A dies inside a 256-MiB gj_upload (staged copy)          -> its lane is taken back, the next call is correct
+ *   B dies inside gj_chunk_power_u8, waiting for its event   -> same
+ *   C dies as the OWNER of the context mutex                 -> the next locker recovers the mutex
+ * gcc tests/c_abandoned_caller.c -Iinclude -Lgps-jamming_amd/csrc -lgpsjam_hip -lpthread */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
+#include "gpsjam.h"
+
+static __thread int doomed_site = 0;
+static void hook(void* arg, int site) {
+    (void)arg;
+    if (doomed_site && site == doomed_site) syscall(SYS_exit, 0); /* this thread only; nothing is unwound */
+}
+
+static gj_ctx* ctx;
+static uint8_t* big;
+static const size_t BIG = (size_t)256 << 20;
+
+static void* die_in_upload(void* p) {
+    (void)p;
+    doomed_site = 3;
+    void* d = NULL;
+    gj_upload(ctx, big, BIG, &d);
+    return (void*)1; /* not reached */
+}
+static void* die_in_event_wait(void* p) {
+    (void)p;
+    doomed_site = 1;
+    float pw[4096], ms;
+    size_t n;
+    gj_chunk_power_u8(ctx, big, 64u << 20, 65536, 0.f, 0, pw, 4096, &n, &ms);
+    return (void*)1;
+}
+static void* die_holding_lock(void* p) {
+    (void)p;
+    doomed_site = 5;
+    int a, b, c, d;
+    gj_debug_counters(ctx, &a, &b, &c, &d);
+    return (void*)1;
+}
+
+static int check_power(const char* what) {
+    /* bytes alternate 100, 150: (100-127.5)^2 + (150-127.5)^2 = 1262.5 per I/Q pair */
+    static float pw[64];
+    size_t n = 0;
+    float ms = 0.f;
+    int rc = gj_chunk_power_u8(ctx, big, (size_t)4 << 20, 65536, 0.f, 0, pw, 64, &n, &ms);
+    if (rc != GJ_OK || n != 64) {
+        fprintf(stderr, "%s: rc %d (%s) n %zu\n", what, rc, gj_last_error(ctx), n);
+        return 1;
+    }
+    for (size_t k = 0; k < n; ++k)
+        if (pw[k] != 1262.5f) {
+            fprintf(stderr, "%s: power[%zu] = %f\n", what, k, pw[k]);
+            return 1;
+        }
+    return 0;
+}
+
+int main(void) {
+    if (gj_create(0, &ctx) != GJ_OK) return 2;
+    big = (uint8_t*)malloc(BIG);
+    for (size_t i = 0; i < BIG; ++i) big[i] = (i & 1) ? 150 : 100;
+    gj_debug_set_wait_hook(ctx, hook, NULL);
+    int lanes, busy, reclaimed, deaths;
+    pthread_t t;
+    void* (*killers[3])(void*) = {die_in_upload, die_in_event_wait, die_holding_lock};
+    const char* names[3] = {"after a caller died inside gj_upload", "after a caller died waiting for its event",
+                            "after a caller died holding the context mutex"};
+    for (int k = 0; k < 3; ++k) {
+        void* ret = NULL;
+        pthread_create(&t, NULL, killers[k], NULL);
+        pthread_join(t, &ret);
+        if (ret == (void*)1) {
+            fprintf(stderr, "the doomed thread of step %d came back\n", k);
+            return 3;
+        }
+        if (check_power(names[k])) return 4;
+        if (check_power(names[k])) return 4;
+        gj_debug_counters(ctx, &lanes, &busy, &reclaimed, &deaths);
+        printf("%s: lanes %d busy %d reclaimed %d owner_deaths %d\n", names[k], lanes, busy, reclaimed, deaths);
+        if (busy != 0) return 5;
+    }
+    if (reclaimed < 2 || deaths < 1) return 6;
+    /* the context still uploads and frees */
+    void* d = NULL;
+    if (gj_upload(ctx, big, BIG, &d) != GJ_OK || gj_free(ctx, d) != GJ_OK) return 7;
+    gj_debug_set_wait_hook(ctx, NULL, NULL);
+    gj_destroy(ctx);
+    free(big);
+    printf("abandoned callers: ok\n");
+    return 0;
+}

@@ -21,3 +21,17 @@ def test_c_program_links_and_runs():
         out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "c_abi_smoke OK" in out.stdout
+
+
+def test_abandoned_callers_do_not_block_the_context():
+    """tests/c_abandoned_caller.c: threads ended by a raw exit inside gj_upload, inside an event wait and as the
+    owner of the context mutex; the same context keeps answering correctly and takes their lanes back."""
+    libdir = os.path.join(REPO, "gps-jamming_amd", "csrc")
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "c_abandoned_caller")
+        subprocess.run(["gcc", "-std=gnu11", "-O2", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"),
+                        os.path.join(REPO, "tests", "c_abandoned_caller.c"), "-o", exe, "-L", libdir, "-lgpsjam_hip",
+                        "-lpthread", f"-Wl,-rpath,{libdir}"], check=True)
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "abandoned callers: ok" in out.stdout

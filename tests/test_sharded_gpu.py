@@ -29,9 +29,12 @@ def test_antenna_stream_single_gpu():
     # the kernel-packed vector equals the torch-packed one
     amp_mean = st.amp[3:4].view(torch.float32)[0]
     noise = st.onset[1:2].view(torch.float32)[0]
+    margins = st.onset[2:3].view(torch.float32).tolist()           # gj_onset: margin_hit, margin_before
     ref = sharded.pack_results(st.n_chunks, st.nperseg, st.power, st.stats, st.amp[0], st.amp[1], amp_mean,
                                st.onset[0], torch.tensor(0), torch.tensor(0.0), noise, st.psd[:st.rows].mean(dim=0),
-                               st.rows, 0)
+                               st.rows, 0, onset_margins=margins, onset_guard=st.onset[3],
+                               onset_threshold=float(st.onset[1:2].view(torch.float32)[1]),
+                               amp_sum=float(st.amp[2:3].view(torch.float64)[0]))
     np.testing.assert_allclose(got[0].cpu().numpy(), ref.cpu().numpy(), rtol=1e-6)
     np.testing.assert_array_equal(got[0][:sharded.HEADER + st.n_chunks].cpu().numpy(),
                                   ref[:sharded.HEADER + st.n_chunks].cpu().numpy())
@@ -45,6 +48,8 @@ def test_antenna_stream_single_gpu():
     np.testing.assert_allclose(res.amp_mean, avg, rtol=1e-6)
     z = orc.tdoa_unpack(raw)
     assert res.onset == orc.tdoa_onset(z)
+    assert res.onset_guard == res.onset and res.onset_margin_hit > 1e-6 and not res.onset_near_tie
+    assert res.onset_threshold == np.float32(res.noise_power) * np.float32(50.0)
     assert res.lag == 0                                   # rank 0 is the reference antenna
     results, td = got.unpack()
     assert td.pairs == [] and results[0].onset == res.onset   # one antenna: nothing to correlate
