@@ -464,6 +464,88 @@ int gj_pack_result_dev(gj_ctx* ctx, size_t n_chunks, const float* d_power, const
                               pair_capacity, d_pairs, d_lags, d_peaks, d_margins, d_out);
 }
 
+// ---- one capture over several GPUs
+size_t gj_amp_tile_count(size_t nbytes) { return amp_tile_count(nbytes); }
+
+int gj_part_scan_dev(gj_ctx* ctx, const gj_part_view* part, size_t chunk_bytes, float eps, int flags, float* d_power,
+                     float rssi_threshold, void* d_tiles, gj_amp_part* d_amp, int noise_samples, int window, float factor,
+                     gj_onset* d_onset) {
+    GJ_ENTER(ctx);
+    if (!part || !part->d_buf || !d_power || !d_tiles || !d_amp || !d_onset) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    return launch_part_scan(ctx, *part, chunk_bytes, eps, flags, d_power, rssi_threshold, d_tiles, d_amp, noise_samples,
+                            window, factor, d_onset);
+}
+
+static int part_own(gj_ctx* ctx, const gj_part_view* part, const uint8_t** own) {
+    if (!part || !part->d_buf) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    if (part->own_first_byte < part->buf_first_byte || part->own_first_byte + part->own_bytes > part->buf_first_byte + part->buf_bytes)
+        return fail(ctx, GJ_ERR_INVALID, "the own range does not lie inside the buffer");
+    *own = part->d_buf + (part->own_first_byte - part->buf_first_byte);
+    return GJ_OK;
+}
+
+int gj_part_welch_dev(gj_ctx* ctx, const gj_part_view* part, size_t chunk_samples, int nperseg, double fs, int flags,
+                      float* d_psd, float* d_psd_db) {
+    GJ_ENTER(ctx);
+    const uint8_t* own = nullptr;
+    int rc = part_own(ctx, part, &own);
+    if (rc) return rc;
+    if (!d_psd) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    if (chunk_samples == 0 || part->own_first_byte % (2 * chunk_samples))
+        return fail(ctx, GJ_ERR_UNSUPPORTED, "a part must start on a PSD chunk boundary");
+    if (part->own_first_byte + part->own_bytes != part->total_bytes && part->own_bytes % (2 * chunk_samples))
+        return fail(ctx, GJ_ERR_UNSUPPORTED, "only the capture's last part may end inside a PSD chunk");
+    return launch_welch(ctx, own, part->own_bytes, chunk_samples, nperseg, fs, flags, d_psd, d_psd_db, part->total_bytes);
+}
+
+size_t gj_part_welch_workspace(gj_ctx* ctx, const gj_part_view* part, size_t chunk_samples, int nperseg) {
+    return (ctx && part) ? welch_workspace(ctx, part->own_bytes, chunk_samples, nperseg, part->total_bytes) : 0;
+}
+
+int gj_part_slot_dev(gj_ctx* ctx, const gj_part_view* part, const int64_t* d_start, size_t n_samples, uint8_t* d_slot) {
+    GJ_ENTER(ctx);
+    if (!part || !part->d_buf || !d_start || !d_slot) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    if (part->buf_first_byte & 1) return fail(ctx, GJ_ERR_INVALID, "the buffer must start on a sample");
+    return launch_tdoa_slot(ctx, part->d_buf, part->buf_bytes, d_start, n_samples, d_slot, (long long)(part->buf_first_byte / 2),
+                            part->total_bytes / 2);
+}
+
+int gj_slots_pick_dev(gj_ctx* ctx, const uint8_t* d_slots, size_t slot_stride, const int32_t* d_offsets, const int32_t* d_members,
+                      int n_groups, uint8_t* d_out) {
+    GJ_ENTER(ctx);
+    if (!d_slots || !d_offsets || !d_members || !d_out) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    return launch_slots_pick(ctx, d_slots, slot_stride, d_offsets, d_members, n_groups, d_out);
+}
+
+int gj_amp_combine_dev(gj_ctx* ctx, const void* d_tiles, size_t n_tiles, const gj_amp_part* d_parts, int n_parts,
+                       size_t total_bytes, gj_amp_stats* d_out) {
+    GJ_ENTER(ctx);
+    if (!d_tiles || !d_parts || !d_out) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    return launch_amp_combine(ctx, d_tiles, n_tiles, d_parts, n_parts, total_bytes, d_out);
+}
+
+int gj_onset_combine_dev(gj_ctx* ctx, const gj_onset* d_parts, int n_parts, gj_onset* d_out) {
+    GJ_ENTER(ctx);
+    if (!d_parts || !d_out) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    return launch_onset_combine(ctx, d_parts, n_parts, d_out);
+}
+
+size_t gj_part_result_len(size_t chunk_cap, size_t tile_cap, size_t rows_cap, int nperseg, int pair_cap) {
+    if (nperseg < 0 || pair_cap < 0) return 0;
+    return GJ_RESULT_HEADER + chunk_cap + 2 * tile_cap + (size_t)GJ_RESULT_PAIR_FIELDS * (size_t)pair_cap +
+           (rows_cap * (size_t)nperseg + 1) / 2;
+}
+
+int gj_pack_part_dev(gj_ctx* ctx, const gj_part_pack* a, double* d_out) {
+    GJ_ENTER(ctx);
+    if (!a || !d_out || !a->d_power || !a->d_amp || !a->d_onset || !a->d_tiles || (a->rows && !a->d_psd))
+        return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    if (a->n_chunks > a->chunk_cap || a->n_tiles > a->tile_cap || a->rows > a->rows_cap || a->n_pairs > a->pair_cap || a->n_pairs < 0)
+        return fail(ctx, GJ_ERR_CAPACITY, "a part's arrays exceed the capacities of the vector");
+    if (a->n_pairs && (!a->d_pairs || !a->d_lags || !a->d_peaks || !a->d_margins)) return fail(ctx, GJ_ERR_INVALID, "null pair buffer");
+    return launch_pack_part(ctx, *a, d_out);
+}
+
 int gj_acq_search_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t first_sample, int nsamp, int intg,
                       const int16_t* d_codes, int n_prn, const uint8_t* d_phase, int n_freq, int nsampchip, double ctime,
                       float threshold, gj_acq_result* d_out, double* d_power) {

@@ -205,11 +205,17 @@ int launch_onset(gj_ctx*, const uint8_t*, size_t, int, int, float, gj_onset*);
 int launch_stream_scan(gj_ctx*, const uint8_t*, size_t, size_t, float, int, float*, float, gj_amp_stats*, int, int,
                        float, gj_onset*);
 int launch_histogram(gj_ctx*, const uint8_t*, size_t, size_t, int, int, unsigned long long*);
-int launch_welch(gj_ctx*, const uint8_t*, size_t, size_t, int, double, int, float*, float*);
-size_t welch_workspace(gj_ctx*, size_t, size_t, int);
+int launch_welch(gj_ctx*, const uint8_t*, size_t, size_t, int, double, int, float*, float*, size_t plan_bytes = 0);
+size_t welch_workspace(gj_ctx*, size_t, size_t, int, size_t plan_bytes = 0);
 int launch_xcorr(gj_ctx*, const uint8_t* const*, const size_t*, int, const int64_t* const*, size_t,
                  const int32_t*, int, int32_t*, float*, float*);
-int launch_tdoa_slot(gj_ctx*, const uint8_t*, size_t, const int64_t*, size_t, uint8_t*);
+int launch_tdoa_slot(gj_ctx*, const uint8_t*, size_t, const int64_t*, size_t, uint8_t*, long long sample0 = 0, size_t total_samples = 0);
+int launch_slots_pick(gj_ctx*, const uint8_t*, size_t, const int*, const int*, int, uint8_t*);
+int launch_part_scan(gj_ctx*, const gj_part_view&, size_t, float, int, float*, float, void*, gj_amp_part*, int, int, float, gj_onset*);
+size_t amp_tile_count(size_t nbytes);
+int launch_amp_combine(gj_ctx*, const void*, size_t, const gj_amp_part*, int, size_t, gj_amp_stats*);
+int launch_onset_combine(gj_ctx*, const gj_onset*, int, gj_onset*);
+int launch_pack_part(gj_ctx*, const gj_part_pack&, double*);
 int launch_acq_search(gj_ctx*, const uint8_t*, size_t, size_t, int, int, const int16_t*, int, const uint8_t*, int, int, double,
                       float, gj_acq_result*, double*);
 size_t acq_workspace(int, int, int, int, bool);

@@ -11,9 +11,6 @@
 
 namespace gj {
 
-#ifndef GJ_SCAN_PRIO
-#define GJ_SCAN_PRIO 0   // s_setprio level of the fused scan's waves (experiment knob)
-#endif
 constexpr int kScanThreads = 256;
 constexpr size_t kScanTile = 65536;   // bytes per workgroup step
 
@@ -428,23 +425,16 @@ __device__ double block_sum_f64(double v, double* sh /* [blockDim/64] */) {
     return t;
 }
 
-// 256 threads: a workgroup this size fits into whatever a finishing K2 workgroup frees (a 1024-thread one needs four
-// waves on every SIMD of one CU at once and waited ~100 us for that beside K2)
-__global__ __launch_bounds__(256) void amp_finalize_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
-                                                            const AmpTile* __restrict__ tiles, size_t ntiles,
-                                                            gj_amp_stats* __restrict__ out, Unpack up,
-                                                            float* __restrict__ power = nullptr, size_t nchunks = 0,
-                                                            size_t nbytes = 0, size_t chunk_bytes = 1, int flags = 0) {
-    // (fused scan only) the last chunk when no tile wrote it or the odd-chunk rule applies
-    if (power && nchunks && threadIdx.x == 0) {
-        const size_t off = (nchunks - 1) * chunk_bytes;
-        const size_t len = nbytes - off;
-        if ((flags & GJ_CP_ODD_CHUNK_ZERO) && (len & 1)) power[nchunks - 1] = 0.0f;
-        else if ((len >> 1) == 0) power[nchunks - 1] = __builtin_nanf("");
-    }
-    __shared__ double sh[16];
-    __shared__ long long first_s;
-    if (threadIdx.x == 0) first_s = 0x7fffffffffffffffll;
+// ---- amplitude totals, in three steps whose results do not depend on how a capture is cut into parts ----
+//   first : smallest first-hit index over the tiles (exact)
+//   tail  : sum of the amplitudes from `first` to the end of ITS tile (block reduction over a fixed thread stride;
+//           the tile's own sum when the hit is the tile's first sample)
+//   total : sum of the tile sums BEHIND that tile (fixed thread stride over the global tile index) + tail
+// A whole capture runs the three in one kernel; a capture split over GPUs runs first + tail where the bytes are
+// (amp_part_finalize_kernel) and total where the tile sums have been gathered (amp_combine_kernel): same code, same
+// order, same bits.
+__device__ long long amp_block_first(const AmpTile* __restrict__ tiles, size_t ntiles, long long* first_s) {
+    if (threadIdx.x == 0) *first_s = 0x7fffffffffffffffll;
     __syncthreads();
     long long f = 0x7fffffffffffffffll;
     // eight independent loads in flight per thread: this single workgroup is latency-bound, and beside K2 every
@@ -459,16 +449,23 @@ __global__ __launch_bounds__(256) void amp_finalize_kernel(const uint8_t* __rest
 #pragma unroll
         for (int k = 0; k < 8; ++k) f = v[k] < f ? v[k] : f;
     }
-    if (f != 0x7fffffffffffffffll) atomicMin(&first_s, f);
+    if (f != 0x7fffffffffffffffll) atomicMin(first_s, f);
     __syncthreads();
-    const long long first = first_s;
-    if (first == 0x7fffffffffffffffll) {
-        if (threadIdx.x == 0) {
-            out->first_index = -1; out->count = 0; out->sum = 0.0; out->mean = 0.f; out->reserved = 0.f;
-        }
-        return;
-    }
+    return *first_s;
+}
+
+// `first` and the tile array are in the coordinates of `iq` (sample 0 = iq[0], tile 0 starts there)
+__device__ double amp_block_tail(const uint8_t* __restrict__ iq, size_t nsamples, const AmpTile* __restrict__ tiles,
+                                 long long first, Unpack up, double* sh) {
     const size_t t0 = (size_t)first / kAmpTileSamples;
+    if ((size_t)first == t0 * kAmpTileSamples) return tiles[t0].sum;   // hit on the tile's first sample: its sum is the tail
+    const size_t e0 = ((t0 + 1) * kAmpTileSamples < nsamples) ? (t0 + 1) * kAmpTileSamples : nsamples;
+    double acc = 0.0;
+    for (size_t s = (size_t)first + threadIdx.x; s < e0; s += blockDim.x) acc += (double)amp_of(iq[2 * s], iq[2 * s + 1], up);
+    return block_sum_f64(acc, sh);
+}
+
+__device__ double amp_block_total(const AmpTile* __restrict__ tiles, size_t ntiles, size_t t0, double* sh) {
     double acc = 0.0;
     for (size_t t = t0 + 1 + threadIdx.x; t < ntiles; t += 8 * (size_t)blockDim.x) {
         double v[8];
@@ -479,16 +476,93 @@ __global__ __launch_bounds__(256) void amp_finalize_kernel(const uint8_t* __rest
         }
         acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }
-    if ((size_t)first == t0 * kAmpTileSamples) {
-        if (threadIdx.x == 0) acc += tiles[t0].sum;   // hit on the tile's first sample: its sum is the remainder
-    } else {
-        // remainder of the tile that holds the first hit
-        const size_t e0 = ((t0 + 1) * kAmpTileSamples < nsamples) ? (t0 + 1) * kAmpTileSamples : nsamples;
-        for (size_t s = (size_t)first + threadIdx.x; s < e0; s += blockDim.x)
-            acc += (double)amp_of(iq[2 * s], iq[2 * s + 1], up);
+    return block_sum_f64(acc, sh);
+}
+
+// (fused scan only) the last chunk when no tile wrote it or the odd-chunk rule applies
+__device__ __forceinline__ void power_edge_cases(float* __restrict__ power, size_t nchunks, size_t nbytes, size_t chunk_bytes,
+                                                 int flags) {
+    if (power && nchunks && threadIdx.x == 0) {
+        const size_t off = (nchunks - 1) * chunk_bytes;
+        const size_t len = nbytes - off;
+        if ((flags & GJ_CP_ODD_CHUNK_ZERO) && (len & 1)) power[nchunks - 1] = 0.0f;
+        else if ((len >> 1) == 0) power[nchunks - 1] = __builtin_nanf("");
     }
-    const double total = block_sum_f64(acc, sh);
+}
+
+// 256 threads: a workgroup this size fits into whatever a finishing K2 workgroup frees (a 1024-thread one needs four
+// waves on every SIMD of one CU at once and waited ~100 us for that beside K2)
+__global__ __launch_bounds__(256) void amp_finalize_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
+                                                            const AmpTile* __restrict__ tiles, size_t ntiles,
+                                                            gj_amp_stats* __restrict__ out, Unpack up,
+                                                            float* __restrict__ power = nullptr, size_t nchunks = 0,
+                                                            size_t nbytes = 0, size_t chunk_bytes = 1, int flags = 0) {
+    power_edge_cases(power, nchunks, nbytes, chunk_bytes, flags);
+    __shared__ double sh[16];
+    __shared__ long long first_s;
+    const long long first = amp_block_first(tiles, ntiles, &first_s);
+    if (first == 0x7fffffffffffffffll) {
+        if (threadIdx.x == 0) {
+            out->first_index = -1; out->count = 0; out->sum = 0.0; out->mean = 0.f; out->reserved = 0.f;
+        }
+        return;
+    }
+    const double tail = amp_block_tail(iq, nsamples, tiles, first, up, sh);
+    const double behind = amp_block_total(tiles, ntiles, (size_t)first / kAmpTileSamples, sh);
     if (threadIdx.x == 0) {
+        const double total = behind + tail;
+        const unsigned long long cnt = nsamples - (size_t)first;
+        out->first_index = first;
+        out->count = cnt;
+        out->sum = total;
+        out->mean = (float)(total / (double)cnt);
+        out->reserved = 0.f;
+    }
+}
+
+// One part of a split capture: first hit (made global with `sample0`) and the tail of its tile; the tile sums travel
+// to the combining rank as they are.  `iq` / `tiles`: the part's OWN range.
+__global__ __launch_bounds__(256) void amp_part_finalize_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
+                                                                 const AmpTile* __restrict__ tiles, size_t ntiles,
+                                                                 long long sample0, gj_amp_part* __restrict__ out, Unpack up,
+                                                                 float* __restrict__ power, size_t nchunks, size_t nbytes,
+                                                                 size_t chunk_bytes, int flags) {
+    power_edge_cases(power, nchunks, nbytes, chunk_bytes, flags);
+    __shared__ double sh[16];
+    __shared__ long long first_s;
+    const long long first = amp_block_first(tiles, ntiles, &first_s);
+    if (first == 0x7fffffffffffffffll) {
+        if (threadIdx.x == 0) { out->first_index = -1; out->count = 0; out->sum = 0.0; out->tail = 0.0; }
+        return;
+    }
+    const double tail = amp_block_tail(iq, nsamples, tiles, first, up, sh);
+    const double behind = amp_block_total(tiles, ntiles, (size_t)first / kAmpTileSamples, sh);
+    if (threadIdx.x == 0) {
+        out->first_index = sample0 + first;
+        out->count = nsamples - (size_t)first;
+        out->sum = behind + tail;            // of this part alone (informational)
+        out->tail = tail;
+    }
+}
+
+// The combining rank: tile sums of the WHOLE capture (gathered, in tile order) + the parts' first hits and tails.
+__global__ __launch_bounds__(256) void amp_combine_kernel(const AmpTile* __restrict__ tiles, size_t ntiles,
+                                                           const gj_amp_part* __restrict__ parts, int n_parts,
+                                                           size_t nsamples, gj_amp_stats* __restrict__ out) {
+    __shared__ double sh[16];
+    long long first = 0x7fffffffffffffffll;
+    double tail = 0.0;
+    for (int p = 0; p < n_parts; ++p)        // every thread: n_parts is small
+        if (parts[p].first_index >= 0 && parts[p].first_index < first) { first = parts[p].first_index; tail = parts[p].tail; }
+    if (first == 0x7fffffffffffffffll) {
+        if (threadIdx.x == 0) {
+            out->first_index = -1; out->count = 0; out->sum = 0.0; out->mean = 0.f; out->reserved = 0.f;
+        }
+        return;
+    }
+    const double behind = amp_block_total(tiles, ntiles, (size_t)first / kAmpTileSamples, sh);
+    if (threadIdx.x == 0) {
+        const double total = behind + tail;
         const unsigned long long cnt = nsamples - (size_t)first;
         out->first_index = first;
         out->count = cnt;
@@ -774,8 +848,10 @@ __global__ void onset_set_cand_kernel(OnsetScratch* __restrict__ sc, int noise_s
 
 // One wave.  Besides the index: the two decision margins of gj_onset (exact window sum at the
 // crossing, recomputed here from the capture; largest sum that stayed below, from the scratch).
+// `sample0`: index of iq[0] in the whole capture (0 unless the buffer is a part of a split capture).
 __global__ __launch_bounds__(64) void onset_finalize_kernel(const uint8_t* __restrict__ iq, const OnsetScratch* __restrict__ sc,
-                                                            int window, int valid, gj_onset* __restrict__ out, int o2) {
+                                                            int window, int valid, gj_onset* __restrict__ out, int o2,
+                                                            long long sample0 = 0) {
     const int tid = threadIdx.x;
     if (!valid) {
         if (tid == 0) {
@@ -794,7 +870,7 @@ __global__ __launch_bounds__(64) void onset_finalize_kernel(const uint8_t* __res
         const double thr = (double)sc->thr, scale = 0.25 / (double)window;
         // the screening sums cover cb blocks >= one window: they bound every window sum inside
         const unsigned mb = sc->max_below > sc->max_screen ? sc->max_below : sc->max_screen;
-        out->start_index = found ? (long long)i0 + window / 2 : -1;
+        out->start_index = found ? sample0 + (long long)i0 + window / 2 : -1;
         out->noise_power = sc->noise;
         out->threshold = sc->thr;
         out->margin_hit = found ? (float)(((double)S * scale - thr) / thr) : 0.f;
@@ -803,7 +879,7 @@ __global__ __launch_bounds__(64) void onset_finalize_kernel(const uint8_t* __res
         // end, so every band position before i0 has been seen; one behind i0 cannot be first.
         unsigned long long ig = sc->guard_inv != 0ull ? ~sc->guard_inv : ~0ull;
         if (found && i0 < ig) ig = i0;
-        out->guard_index = ig != ~0ull ? (long long)ig + window / 2 : -1;
+        out->guard_index = ig != ~0ull ? sample0 + (long long)ig + window / 2 : -1;
     }
 }
 
@@ -884,11 +960,14 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
                                                                    unsigned long long* __restrict__ acc, float thr,
                                                                    AmpTile* __restrict__ tiles,
                                                                    unsigned* __restrict__ cblk, size_t noise_bytes,
-                                                                   OnsetScratch* __restrict__ sc, Unpack up) {
+                                                                   OnsetScratch* __restrict__ sc, Unpack up,
+                                                                   unsigned skip_tiles = 0) {
+    // skip_tiles (a part of a split capture): the first tiles of the buffer are the HALO in front of the part's own
+    // range -- they feed K4's block sums only; chunk powers and amplitude tiles start at the own range (`nbytes` =
+    // its length, `power` / `tiles` / `acc` its arrays).
     __shared__ unsigned long long red_m[2][kScanThreads / 64];
     __shared__ double red_s[kScanThreads / 64];
     __shared__ long long red_f[kScanThreads / 64];
-    if constexpr (GJ_SCAN_PRIO != 0) __builtin_amdgcn_s_setprio(GJ_SCAN_PRIO);
     const int tid = threadIdx.x;
     const size_t t = blockIdx.x;
     const size_t b0 = t * kScanTile;                               // first byte of the tile
@@ -996,15 +1075,17 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
     }
     if ((tid & 63) == 0) { red_m[0][tid >> 6] = mS; red_s[tid >> 6] = sum; red_f[tid >> 6] = first; }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && t >= skip_tiles) {
         const unsigned long long tS = red_m[0][0] + red_m[0][1] + red_m[0][2] + red_m[0][3];
         AmpTile at;
         at.sum = ((red_s[0] + red_s[1]) + (red_s[2] + red_s[3])) * (double)up.half_scale;
         long long f = red_f[0];
         for (int k = 1; k < 4; ++k) f = red_f[k] < f ? red_f[k] : f;
-        at.first = f;
-        tiles[t] = at;
-        const size_t c = t / tiles_per_chunk;
+        // first hit in the coordinates of the own range
+        at.first = (f == 0x7fffffffffffffffll) ? f : f - (long long)((size_t)skip_tiles * (kScanTile / 2));
+        const size_t to = t - skip_tiles;
+        tiles[to] = at;
+        const size_t c = to / tiles_per_chunk;
         const size_t off = c * chunk_bytes;
         const size_t len = (nbytes - off < chunk_bytes) ? nbytes - off : chunk_bytes;
         const bool zero_rule = (flags & GJ_CP_ODD_CHUNK_ZERO) && ((len & 1) || len == 0);
@@ -1014,6 +1095,108 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
             atomicAdd(&acc[2 * c], tS);
         }
     }
+}
+
+// One implementation for a whole capture (part == nullptr) and for one part of a capture split over GPUs.
+// A part's buffer is [halo][own range]: the halo (whole 64-KiB tiles of the capture in front of the own range, at
+// least window - 1 samples; none for the capture's first part) lets K4 evaluate every window that ENDS inside the
+// own range, so that the parts' position ranges tile the capture; chunk powers and amplitude tiles cover the own
+// range only.  A position inside the halo that crosses is reported by the part in front as well -- the combining
+// rank takes the smallest index, so duplicates are harmless.
+struct ScanPart {
+    size_t halo_bytes;         // multiple of kScanTile
+    long long buf_sample0;     // index of the buffer's first sample in the whole capture
+    const uint8_t* d_noise;    // the capture's first 2 * noise_samples bytes
+    size_t total_samples;      // of the whole capture
+    AmpTile* d_tiles;          // [own tiles] out
+    gj_amp_part* d_amp;        // out
+};
+
+static int stream_scan_impl(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
+                            float* d_power, float rssi_threshold, gj_amp_stats* d_amp, int noise_samples, int window,
+                            float factor, gj_onset* d_onset, const ScanPart* part) {
+    if (noise_samples <= 0 || window <= 0) return fail(ctx, GJ_ERR_INVALID, "noise_samples and window must be > 0");
+    if (window > kOnsetMaxWin) return fail(ctx, GJ_ERR_UNSUPPORTED, "window > %d", kOnsetMaxWin);
+    const size_t halo = part ? part->halo_bytes : 0;
+    const size_t own_bytes = nbytes - halo;
+    const size_t nsamples = nbytes / 2;                         // of the buffer (halo + own)
+    const size_t own_samples = own_bytes / 2;
+    const size_t ntiles = (2 * nsamples + kScanTile - 1) / kScanTile;
+    const size_t skip = halo / kScanTile;
+    const size_t own_tiles = ntiles - skip;
+    const size_t nchunks = gj_chunk_count(own_bytes, chunk_bytes);
+    const size_t tpc = chunk_bytes / kScanTile;
+    const size_t nblk = (nsamples + 511) / 512;
+    if (ntiles > 0x7fffffffull) return fail(ctx, GJ_ERR_UNSUPPORTED, "capture too long");
+    // workspace: [OnsetScratch][AmpTile x own tiles (whole capture only)][acc u64 x 2 x nchunks][c512 u32 x nblk]
+    const size_t off_tiles = 256;
+    const size_t off_acc = off_tiles + (part ? 0 : align_up((own_tiles + 1) * sizeof(AmpTile), 256));
+    const size_t off_blk = off_acc + align_up(nchunks * 16, 256);
+    int rc = ensure_workspace(ctx, off_blk + (nblk + 16) * sizeof(unsigned));
+    if (rc) return rc;
+    OnsetScratch* sc = reinterpret_cast<OnsetScratch*>(ctx->ws);
+    AmpTile* tiles = part ? part->d_tiles : reinterpret_cast<AmpTile*>(ctx->ws + off_tiles);
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(ctx->ws + off_acc);
+    unsigned* cblk = reinterpret_cast<unsigned*>(ctx->ws + off_blk);
+    GJ_HIP(ctx, hipMemsetAsync(sc, 0, sizeof(OnsetScratch), ctx->stream));
+    if (tpc > 1) GJ_HIP(ctx, hipMemsetAsync(acc, 0, nchunks * 16, ctx->stream));
+    // triangulateTDOA.py:39 speaks of the whole capture; a part must itself hold at least one window
+    const size_t total_samples = part ? part->total_samples : nsamples;
+    const int valid = total_samples >= (size_t)noise_samples + (size_t)window && nsamples >= (size_t)window;
+    // the K4 noise span rides along in the same pass when the buffer starts with it and it ends on a 16-byte boundary
+    const size_t noise_bytes = (size_t)2 * noise_samples;
+    const bool noise_here = !part || (part->buf_sample0 == 0 && noise_bytes <= nbytes);
+    const bool noise_fused = valid && noise_here && (noise_bytes % 16 == 0);
+    // When the offset is a half-integer (off2 odd) no component of 2u - off2 is zero, so every amplitude is at
+    // least sqrt(2) * half_scale (0.0055 for the default unpack): a threshold below that makes every sample a hit
+    // and the first index needs no tracking.  With an integer offset (gj_set_unpack(128, ...)) amplitudes can be
+    // zero and the shortcut never applies.  Same float expression as the kernels' `a > thr`.
+    const Unpack upk = unpack_of(ctx);
+    const bool all_hit = (ctx->off2 & 1) && (sqrtf(2.0f) * upk.half_scale > rssi_threshold);
+    const bool track = !all_hit;
+    if (track)
+        hipLaunchKernelGGL(stream_scan_kernel<true>, dim3((unsigned)ntiles), dim3(kScanThreads), 0, ctx->stream, d_iq,
+                           nsamples, own_bytes, chunk_bytes, (unsigned)tpc, eps, flags, d_power, acc, rssi_threshold, tiles,
+                           cblk, noise_fused ? noise_bytes : (size_t)0, sc, upk, (unsigned)skip);
+    else
+        hipLaunchKernelGGL(stream_scan_kernel<false>, dim3((unsigned)ntiles), dim3(kScanThreads), 0, ctx->stream, d_iq,
+                           nsamples, own_bytes, chunk_bytes, (unsigned)tpc, eps, flags, d_power, acc, rssi_threshold, tiles,
+                           cblk, noise_fused ? noise_bytes : (size_t)0, sc, upk, (unsigned)skip);
+    GJ_LAUNCH_CHECK(ctx);
+    if (tpc > 1) {
+        hipLaunchKernelGGL(chunk_power_finalize_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0,
+                           ctx->stream, acc, nchunks, own_bytes, chunk_bytes, eps, flags, d_power, ctx->off2, true);
+        GJ_LAUNCH_CHECK(ctx);
+    }
+    // amplitude totals + the chunk-power edge cases (last chunk odd / without a complete pair)
+    if (part)
+        hipLaunchKernelGGL(amp_part_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, d_iq + halo, own_samples, tiles,
+                           own_tiles, part->buf_sample0 + (long long)(halo / 2), part->d_amp, upk, d_power, nchunks, own_bytes,
+                           chunk_bytes, flags);
+    else
+        hipLaunchKernelGGL(amp_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, d_iq, nsamples, tiles, ntiles, d_amp,
+                           upk, d_power, nchunks, nbytes, chunk_bytes, flags);
+    GJ_LAUNCH_CHECK(ctx);
+    if (valid) {
+        if (!noise_fused) {
+            hipLaunchKernelGGL(onset_noise_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream,
+                               noise_here ? d_iq : part->d_noise, noise_samples, sc, ctx->off2);
+            GJ_LAUNCH_CHECK(ctx);
+        }
+        const size_t nout = nsamples - window + 1;
+        const size_t nct = ((nout + 511) / 512 + kCoarseBlocks - 1) / kCoarseBlocks;
+        hipLaunchKernelGGL(onset_coarse_kernel<512>, dim3((unsigned)nct), dim3(kScanThreads), 0, ctx->stream, d_iq,
+                           (const unsigned*)cblk, nsamples, window, noise_samples, factor, sc, ctx->off2);
+        GJ_LAUNCH_CHECK(ctx);
+        const size_t nt = (nout + kOnsetOut - 1) / kOnsetOut;
+        hipLaunchKernelGGL(onset_scan_kernel, dim3((unsigned)(nt < 256 ? nt : 256)), dim3(kScanThreads), 0, ctx->stream,
+                           d_iq, nsamples, window, sc, ctx->off2);
+        GJ_LAUNCH_CHECK(ctx);
+    }
+    hipLaunchKernelGGL(onset_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, d_iq, sc, window, valid, d_onset, ctx->off2,
+                       part ? part->buf_sample0 : 0ll);
+    GJ_LAUNCH_CHECK(ctx);
+    return GJ_OK;
 }
 
 int launch_stream_scan(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
@@ -1027,73 +1210,47 @@ int launch_stream_scan(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t c
         if (!rc) rc = launch_onset(ctx, d_iq, nbytes, noise_samples, window, factor, d_onset);
         return rc;
     }
-    if (noise_samples <= 0 || window <= 0) return fail(ctx, GJ_ERR_INVALID, "noise_samples and window must be > 0");
-    if (window > kOnsetMaxWin) return fail(ctx, GJ_ERR_UNSUPPORTED, "window > %d", kOnsetMaxWin);
-    const size_t nsamples = nbytes / 2;
-    const size_t ntiles = (2 * nsamples + kScanTile - 1) / kScanTile;
-    const size_t nchunks = gj_chunk_count(nbytes, chunk_bytes);
-    const size_t tpc = chunk_bytes / kScanTile;
-    const size_t nblk = (nsamples + 511) / 512;
-    if (ntiles > 0x7fffffffull) return fail(ctx, GJ_ERR_UNSUPPORTED, "capture too long");
-    // workspace: [OnsetScratch][AmpTile x ntiles][acc u64 x 2 x nchunks][c512 u32 x nblk]
-    const size_t off_tiles = 256;
-    const size_t off_acc = off_tiles + align_up((ntiles + 1) * sizeof(AmpTile), 256);
-    const size_t off_blk = off_acc + align_up(nchunks * 16, 256);
-    int rc = ensure_workspace(ctx, off_blk + (nblk + 16) * sizeof(unsigned));
-    if (rc) return rc;
-    OnsetScratch* sc = reinterpret_cast<OnsetScratch*>(ctx->ws);
-    AmpTile* tiles = reinterpret_cast<AmpTile*>(ctx->ws + off_tiles);
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(ctx->ws + off_acc);
-    unsigned* cblk = reinterpret_cast<unsigned*>(ctx->ws + off_blk);
-    GJ_HIP(ctx, hipMemsetAsync(sc, 0, sizeof(OnsetScratch), ctx->stream));
-    if (tpc > 1) GJ_HIP(ctx, hipMemsetAsync(acc, 0, nchunks * 16, ctx->stream));
-    const int valid = nsamples >= (size_t)noise_samples + (size_t)window;
-    // the K4 noise span rides along in the same pass when it ends on a 16-byte boundary
-    const size_t noise_bytes = (size_t)2 * noise_samples;
-    const bool noise_fused = valid && (noise_bytes % 16 == 0);
-    // When the offset is a half-integer (off2 odd) no component of 2u - off2 is zero, so every amplitude is at
-    // least sqrt(2) * half_scale (0.0055 for the default unpack): a threshold below that makes every sample a hit
-    // and the first index needs no tracking.  With an integer offset (gj_set_unpack(128, ...)) amplitudes can be
-    // zero and the shortcut never applies.  Same float expression as the kernels' `a > thr`.
-    const Unpack upk = unpack_of(ctx);
-    const bool all_hit = (ctx->off2 & 1) && (sqrtf(2.0f) * upk.half_scale > rssi_threshold);
-    const bool track = !all_hit;
-    // experiment knob: dynamic LDS the scan workgroups declare but never touch (residency limiter)
-    static const unsigned lds_pad = getenv("GPSJAM_SCAN_LDS_PAD") ? (unsigned)atoi(getenv("GPSJAM_SCAN_LDS_PAD")) : 0u;
-    if (track)
-        hipLaunchKernelGGL(stream_scan_kernel<true>, dim3((unsigned)ntiles), dim3(kScanThreads), lds_pad, ctx->stream, d_iq,
-                           nsamples, nbytes, chunk_bytes, (unsigned)tpc, eps, flags, d_power, acc, rssi_threshold, tiles,
-                           cblk, noise_fused ? noise_bytes : (size_t)0, sc, unpack_of(ctx));
-    else
-        hipLaunchKernelGGL(stream_scan_kernel<false>, dim3((unsigned)ntiles), dim3(kScanThreads), lds_pad, ctx->stream, d_iq,
-                           nsamples, nbytes, chunk_bytes, (unsigned)tpc, eps, flags, d_power, acc, rssi_threshold, tiles,
-                           cblk, noise_fused ? noise_bytes : (size_t)0, sc, unpack_of(ctx));
-    GJ_LAUNCH_CHECK(ctx);
-    if (tpc > 1) {
-        hipLaunchKernelGGL(chunk_power_finalize_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0,
-                           ctx->stream, acc, nchunks, nbytes, chunk_bytes, eps, flags, d_power, ctx->off2, true);
-        GJ_LAUNCH_CHECK(ctx);
-    }
-    // amplitude totals + the chunk-power edge cases (last chunk odd / without a complete pair)
-    hipLaunchKernelGGL(amp_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, d_iq, nsamples, tiles, ntiles, d_amp,
-                       unpack_of(ctx), d_power, nchunks, nbytes, chunk_bytes, flags);
-    GJ_LAUNCH_CHECK(ctx);
-    if (valid) {
-        if (!noise_fused) {
-            hipLaunchKernelGGL(onset_noise_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_iq, noise_samples, sc, ctx->off2);
-            GJ_LAUNCH_CHECK(ctx);
-        }
-        const size_t nout = nsamples - window + 1;
-        const size_t nct = ((nout + 511) / 512 + kCoarseBlocks - 1) / kCoarseBlocks;
-        hipLaunchKernelGGL(onset_coarse_kernel<512>, dim3((unsigned)nct), dim3(kScanThreads), 0, ctx->stream, d_iq,
-                           (const unsigned*)cblk, nsamples, window, noise_samples, factor, sc, ctx->off2);
-        GJ_LAUNCH_CHECK(ctx);
-        const size_t nt = (nout + kOnsetOut - 1) / kOnsetOut;
-        hipLaunchKernelGGL(onset_scan_kernel, dim3((unsigned)(nt < 256 ? nt : 256)), dim3(kScanThreads), 0, ctx->stream,
-                           d_iq, nsamples, window, sc, ctx->off2);
-        GJ_LAUNCH_CHECK(ctx);
-    }
-    hipLaunchKernelGGL(onset_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, d_iq, sc, window, valid, d_onset, ctx->off2);
+    return stream_scan_impl(ctx, d_iq, nbytes, chunk_bytes, eps, flags, d_power, rssi_threshold, d_amp, noise_samples,
+                            window, factor, d_onset, nullptr);
+}
+
+// One part of a capture split over GPUs (include/gpsjam.h, gj_part_scan_dev).
+int launch_part_scan(gj_ctx* ctx, const gj_part_view& v, size_t chunk_bytes, float eps, int flags, float* d_power,
+                     float rssi_threshold, void* d_tiles, gj_amp_part* d_amp, int noise_samples, int window, float factor,
+                     gj_onset* d_onset) {
+    if (v.own_first_byte < v.buf_first_byte || v.own_first_byte + v.own_bytes > v.buf_first_byte + v.buf_bytes ||
+        v.own_first_byte + v.own_bytes > v.total_bytes)
+        return fail(ctx, GJ_ERR_INVALID, "the own range does not lie inside the buffer / the capture");
+    const size_t halo = v.own_first_byte - v.buf_first_byte;
+    if (chunk_bytes < kScanTile || chunk_bytes % kScanTile || (reinterpret_cast<uintptr_t>(v.d_buf) & 15) || halo % kScanTile ||
+        v.own_first_byte % chunk_bytes || (v.buf_first_byte & 1) || v.own_bytes < 2)
+        return fail(ctx, GJ_ERR_UNSUPPORTED, "a part needs chunk_bytes and a halo that are multiples of 65536, an own range that "
+                                             "starts on a chunk boundary and a 16-byte aligned buffer");
+    if (v.own_first_byte + v.own_bytes != v.total_bytes && v.own_bytes % chunk_bytes)
+        return fail(ctx, GJ_ERR_UNSUPPORTED, "only the capture's last part may end inside a chunk");
+    if (v.own_first_byte != 0 && halo / 2 + 1 < (size_t)window)
+        return fail(ctx, GJ_ERR_INVALID, "the halo must hold at least window - 1 samples");
+    if (v.buf_first_byte != 0 && !v.d_noise) return fail(ctx, GJ_ERR_INVALID, "d_noise is needed by every part but the first");
+    ScanPart p;
+    p.halo_bytes = halo;
+    p.buf_sample0 = (long long)(v.buf_first_byte / 2);
+    p.d_noise = v.d_noise;
+    p.total_samples = v.total_bytes / 2;
+    p.d_tiles = static_cast<AmpTile*>(d_tiles);
+    p.d_amp = d_amp;
+    // the scan covers [halo][own]; what lies behind the own range in the buffer (the slice tail) is not scanned
+    return stream_scan_impl(ctx, v.d_buf, halo + v.own_bytes, chunk_bytes, eps, flags, d_power, rssi_threshold, nullptr,
+                            noise_samples, window, factor, d_onset, &p);
+}
+
+size_t amp_tile_count(size_t nbytes) { return (nbytes / 2 * 2 + kScanTile - 1) / kScanTile; }
+
+int launch_amp_combine(gj_ctx* ctx, const void* d_tiles, size_t ntiles, const gj_amp_part* d_parts, int n_parts,
+                       size_t total_bytes, gj_amp_stats* d_out) {
+    if (n_parts < 1) return fail(ctx, GJ_ERR_INVALID, "n_parts must be >= 1");
+    if (ntiles != amp_tile_count(total_bytes)) return fail(ctx, GJ_ERR_INVALID, "a capture of %zu bytes has %zu tiles, not %zu", total_bytes, amp_tile_count(total_bytes), ntiles);
+    hipLaunchKernelGGL(amp_combine_kernel, dim3(1), dim3(256), 0, ctx->stream, static_cast<const AmpTile*>(d_tiles), ntiles,
+                       d_parts, n_parts, total_bytes / 2, d_out);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
 }

@@ -125,6 +125,10 @@ __global__ __launch_bounds__(1024) void pack_result_kernel(size_t n_chunks, cons
                 case 20: v = (double)rank; break;           // antenna: the stream's own capture
                 case 22: v = 1.0; break;                    // parts: the whole capture
                 case 26: v = amp->sum; break;
+                case 32: case 33: case 34: case 35:         // the gj_onset record as it is (32 bytes)
+                    v = reinterpret_cast<const double*>(onset)[i - 32]; break;
+                case 36: case 37: case 38: case 39:         // the gj_amp_stats record as it is (32 bytes)
+                    v = reinterpret_cast<const double*>(amp)[i - 36]; break;
                 default: v = 0.0;
             }
         } else if (i < head) {
@@ -157,6 +161,118 @@ int launch_pack_result(gj_ctx* ctx, size_t n_chunks, const float* d_power, const
     hipLaunchKernelGGL(pack_result_kernel, dim3(spec_blocks + (unsigned)copy_blocks), dim3(1024), 0, ctx->stream, n_chunks,
                        d_power, d_stats, d_amp, d_onset, d_psd, rows, nperseg, rank, n_pairs, pair_cap, d_pairs, d_lags,
                        d_peaks, d_margins, d_out);
+    GJ_LAUNCH_CHECK(ctx);
+    return GJ_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// result vector of ONE PART of a capture split over GPUs (gj_pack_part_dev): the same header, then what the
+// combining rank needs to rebuild the capture's arrays -- own chunk powers, own amplitude tiles, solved pairs, own
+// PSD rows (float32, two per double slot)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_part_kernel(gj_part_pack a, double* __restrict__ out) {
+    const size_t o_power = GJ_RESULT_HEADER;
+    const size_t o_tiles = o_power + a.chunk_cap;
+    const size_t o_pairs = o_tiles + 2 * a.tile_cap;
+    const size_t o_rows = o_pairs + (size_t)GJ_RESULT_PAIR_FIELDS * a.pair_cap;
+    const size_t n_front = o_rows;
+    const size_t row_floats = a.rows_cap * (size_t)a.nperseg;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (size_t i = gid; i < n_front; i += stride) {
+        double v = 0.0;
+        if (i < GJ_RESULT_HEADER) {
+            switch (i) {
+                case 0: v = (double)a.n_chunks; break;
+                case 4: v = (double)a.d_amp->first_index; break;
+                case 5: v = (double)a.d_amp->count; break;
+                case 7: v = (double)a.d_onset->start_index; break;
+                case 8: v = (double)GJ_LAG_INVALID; break;
+                case 10: v = a.d_onset->noise_power; break;
+                case 11: v = (double)a.rows; break;
+                case 12: v = (double)a.nperseg; break;
+                case 13: v = (double)a.rank; break;
+                case 14: v = (double)a.n_pairs; break;
+                case 15: v = (double)a.pair_cap; break;
+                case 16: v = a.d_onset->margin_hit; break;
+                case 17: v = a.d_onset->margin_before; break;
+                case 18: v = (double)a.d_onset->guard_index; break;
+                case 19: v = a.d_onset->threshold; break;
+                case 20: v = (double)a.antenna; break;
+                case 21: v = (double)a.part; break;
+                case 22: v = (double)a.parts; break;
+                case 23: v = (double)a.first_chunk; break;
+                case 24: v = (double)a.first_row; break;
+                case 25: v = (double)a.first_sample; break;
+                case 26: v = a.d_amp->sum; break;
+                case 27: v = a.d_amp->tail; break;
+                case 28: v = (double)a.n_tiles; break;
+                case 29: v = (double)a.first_tile; break;
+                case 32: case 33: case 34: case 35: v = reinterpret_cast<const double*>(a.d_onset)[i - 32]; break;
+                case 36: case 37: case 38: case 39: v = reinterpret_cast<const double*>(a.d_amp)[i - 36]; break;
+                default: v = 0.0;
+            }
+        } else if (i < o_tiles) {
+            const size_t c = i - o_power;
+            v = c < a.n_chunks ? (double)a.d_power[c] : 0.0;
+        } else if (i < o_pairs) {
+            const size_t q = i - o_tiles;                       // (sum, first) of tile q / 2: the 16-byte record as it is
+            v = (q / 2 < a.n_tiles) ? reinterpret_cast<const double*>(a.d_tiles)[q] : 0.0;
+        } else {
+            const size_t q = i - o_pairs;
+            const int pr = (int)(q / GJ_RESULT_PAIR_FIELDS), fld = (int)(q % GJ_RESULT_PAIR_FIELDS);
+            if (pr < a.n_pairs) {
+                switch (fld) {
+                    case 0: v = (double)a.d_pairs[2 * pr]; break;
+                    case 1: v = (double)a.d_pairs[2 * pr + 1]; break;
+                    case 2: v = (double)a.d_lags[pr]; break;
+                    case 3: v = a.d_peaks[pr]; break;
+                    default: v = a.d_margins[pr];
+                }
+            }
+        }
+        out[i] = v;
+    }
+    float* rows_out = reinterpret_cast<float*>(out + o_rows);
+    const size_t have = a.rows * (size_t)a.nperseg;
+    for (size_t i = gid; i < row_floats + (row_floats & 1); i += stride) rows_out[i] = i < have ? a.d_psd[i] : 0.f;
+}
+
+int launch_pack_part(gj_ctx* ctx, const gj_part_pack& a, double* d_out) {
+    const size_t n = GJ_RESULT_HEADER + a.chunk_cap + 2 * a.tile_cap + (size_t)GJ_RESULT_PAIR_FIELDS * a.pair_cap +
+                     a.rows_cap * (size_t)a.nperseg;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(pack_part_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a, d_out);
+    GJ_LAUNCH_CHECK(ctx);
+    return GJ_OK;
+}
+
+// The capture's onset from its parts' (each already in capture coordinates): the part with the smallest start >= 0
+// decides index and margin_hit; guard = smallest guard >= 0; margin_before = the smallest reported by the parts up to
+// and including that one (all of them when nothing crossed); noise and threshold are the same on every part.
+__global__ void onset_combine_kernel(const gj_onset* __restrict__ parts, int n, gj_onset* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int best = -1;
+    for (int k = 0; k < n; ++k)
+        if (parts[k].start_index >= 0 && (best < 0 || parts[k].start_index < parts[best].start_index)) best = k;
+    long long guard = -1;
+    float mb = parts[0].margin_before;
+    for (int k = 0; k < n; ++k) {
+        if (parts[k].guard_index >= 0 && (guard < 0 || parts[k].guard_index < guard)) guard = parts[k].guard_index;
+        if ((best < 0 || k <= best) && parts[k].margin_before < mb) mb = parts[k].margin_before;
+    }
+    gj_onset o = parts[0];
+    o.start_index = best >= 0 ? parts[best].start_index : -1;
+    o.margin_hit = best >= 0 ? parts[best].margin_hit : 0.f;
+    o.margin_before = mb;
+    o.guard_index = guard;
+    *out = o;
+}
+
+int launch_onset_combine(gj_ctx* ctx, const gj_onset* d_parts, int n_parts, gj_onset* d_out) {
+    if (n_parts < 1) return fail(ctx, GJ_ERR_INVALID, "n_parts must be >= 1");
+    hipLaunchKernelGGL(onset_combine_kernel, dim3(1), dim3(64), 0, ctx->stream, d_parts, n_parts, d_out);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
 }

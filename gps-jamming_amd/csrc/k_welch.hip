@@ -448,7 +448,11 @@ struct WelchPlan {
     double scale_full, scale_last;
 };
 
-static bool welch_plan(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int nperseg, double fs, WelchPlan& pl) {
+// plan_bytes (a part of a split capture): the workgroups-per-chunk split is chosen as for a capture of plan_bytes,
+// so that a chunk's partial spectra -- and with them the float sum behind its PSD row -- are cut the same way
+// whether the chunk is processed as part of the whole capture or as part of a piece of it.
+static bool welch_plan(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int nperseg, double fs, WelchPlan& pl,
+                       size_t plan_bytes = 0) {
     if (nperseg < 16 || nperseg > 4096 || (nperseg & (nperseg - 1))) return false;
     if (chunk_samples < (size_t)nperseg) return false;
     // the kernel addresses a chunk with 32-bit byte offsets from a 64-bit chunk base
@@ -477,8 +481,9 @@ static bool welch_plan(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int npe
     if (cap > 256) cap = 256;
     size_t want = 1;
     double best = 1e300;
+    const size_t plan_rows = plan_bytes ? gj_welch_rows(plan_bytes, chunk_samples, nperseg) : pl.rows;
     for (size_t sp = 1; sp <= cap; ++sp) {
-        const size_t wgs = (pl.rows ? pl.rows : 1) * sp;
+        const size_t wgs = (plan_rows ? plan_rows : 1) * sp;
         const double rounds = (double)((wgs + slots - 1) / slots);
         const double steps = (double)pl.g.nseg_full / (double)(sp * pl.batch) + 1.5;   // 1.5: twiddle/window set-up
         const double cost = rounds * steps;
@@ -504,9 +509,9 @@ extern "C" int gj_debug_welch_stamps(unsigned long long* out, int reset) {
 }
 #endif
 
-size_t welch_workspace(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int nperseg) {
+size_t welch_workspace(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int nperseg, size_t plan_bytes) {
     WelchPlan pl;
-    if (!welch_plan(ctx, nbytes, chunk_samples, nperseg, 1.0, pl)) return 0;
+    if (!welch_plan(ctx, nbytes, chunk_samples, nperseg, 1.0, pl, plan_bytes)) return 0;
     return pl.ws_bytes;
 }
 
@@ -519,10 +524,10 @@ static void welch_launch(gj_ctx* ctx, const uint8_t* d_iq, const WelchPlan& pl, 
 }
 
 int launch_welch(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_samples, int nperseg, double fs,
-                 int flags, float* d_psd, float* d_psd_db) {
+                 int flags, float* d_psd, float* d_psd_db, size_t plan_bytes) {
     WelchPlan pl;
     if (!(fs > 0.0)) return fail(ctx, GJ_ERR_INVALID, "fs must be > 0");
-    if (!welch_plan(ctx, nbytes, chunk_samples, nperseg, fs, pl))
+    if (!welch_plan(ctx, nbytes, chunk_samples, nperseg, fs, pl, plan_bytes))
         return fail(ctx, GJ_ERR_UNSUPPORTED, "nperseg must be a power of two in [16, 4096] and <= chunk_samples, chunk_samples < 2^31 - nperseg");
     if ((reinterpret_cast<uintptr_t>(d_iq) & 1) != 0) return fail(ctx, GJ_ERR_INVALID, "capture must be 2-byte aligned");
     if (pl.rows == 0) return GJ_OK;

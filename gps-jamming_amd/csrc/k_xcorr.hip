@@ -377,17 +377,22 @@ int launch_xcorr(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, 
 // [int64 flag: 0 = valid, -1 = invalid][int64 start sample in the sender's capture][2 n bytes of I/Q]
 __device__ __forceinline__ size_t align_up_dev(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// `sample0` / `total`: iq[0] is sample `sample0` of a capture of `total` samples (0 / nsamples for a whole capture).
+// The slice is valid when it lies inside the CAPTURE (the reference's rule); a part whose buffer does not hold a
+// valid slice says so with flag -2 (a sizing error of the caller, never silently wrong data).
 __global__ __launch_bounds__(256) void tdoa_slot_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
                                                         const long long* __restrict__ start, size_t n,
-                                                        uint8_t* __restrict__ slot) {
+                                                        uint8_t* __restrict__ slot, long long sample0, size_t total) {
     const long long s = *start;
-    const bool ok = s >= 0 && (unsigned long long)s + n <= nsamples;
+    const bool in_capture = s >= 0 && (unsigned long long)s + n <= total;
+    const bool held = s >= sample0 && (unsigned long long)(s - sample0) + n <= nsamples;
+    const bool ok = in_capture && held;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         long long* h = reinterpret_cast<long long*>(slot);
-        h[0] = ok ? 0 : -1;
+        h[0] = ok ? 0 : (in_capture ? -2 : -1);
         h[1] = s;
     }
-    const uint16_t* src = reinterpret_cast<const uint16_t*>(iq) + (ok ? s : 0);
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(iq) + (ok ? s - sample0 : 0);
     uint4* dst = reinterpret_cast<uint4*>(slot + GJ_SLOT_HEADER);
     // the slot is padded to a multiple of 256 bytes: the padding is written too (zeros), so that a
     // slot is a fully defined message
@@ -407,14 +412,54 @@ __global__ __launch_bounds__(256) void tdoa_slot_kernel(const uint8_t* __restric
 }
 
 int launch_tdoa_slot(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, const int64_t* d_start, size_t n_samples,
-                     uint8_t* d_slot) {
+                     uint8_t* d_slot, long long sample0, size_t total_samples) {
+    if (total_samples == 0 && sample0 == 0) total_samples = nbytes / 2;   // a whole capture
     if (n_samples < 1) return fail(ctx, GJ_ERR_INVALID, "n_samples must be >= 1");
     if ((reinterpret_cast<uintptr_t>(d_iq) & 1) != 0) return fail(ctx, GJ_ERR_INVALID, "capture must be 2-byte aligned");
     if ((reinterpret_cast<uintptr_t>(d_slot) & 15) != 0) return fail(ctx, GJ_ERR_INVALID, "slot must be 16-byte aligned");
     size_t blocks = ((n_samples + 7) / 8 + 16 + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(tdoa_slot_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_iq, nbytes / 2,
-                       (const long long*)d_start, n_samples, d_slot);
+                       (const long long*)d_start, n_samples, d_slot, sample0, total_samples);
+    GJ_LAUNCH_CHECK(ctx);
+    return GJ_OK;
+}
+
+// A capture split over GPUs contributes one slot per part; the capture's slot is the one cut at the SMALLEST
+// onset >= 0 among its parts (the whole capture's first crossing), whatever its flag says -- exactly the slot the
+// unsplit capture would have produced.  No part found an onset: an invalid slot with start -1.
+// grid (copy blocks, groups); group g = the slots members[offsets[g]] .. members[offsets[g + 1] - 1].
+__global__ __launch_bounds__(256) void slots_pick_kernel(const uint8_t* __restrict__ slots, size_t stride,
+                                                         const int* __restrict__ offsets, const int* __restrict__ members,
+                                                         uint8_t* __restrict__ out) {
+    const int g = blockIdx.y;
+    int best = -1;
+    long long best_s = 0x7fffffffffffffffll;
+    for (int k = offsets[g]; k < offsets[g + 1]; ++k) {
+        const long long* h = reinterpret_cast<const long long*>(slots + (size_t)members[k] * stride);
+        const long long st = h[1];
+        if (st >= 0 && st < best_s) { best_s = st; best = members[k]; }
+    }
+    uint4* dst = reinterpret_cast<uint4*>(out + (size_t)g * stride);
+    const size_t ngroups = stride / 16;
+    if (best < 0) {
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < ngroups; i += (size_t)gridDim.x * blockDim.x)
+            dst[i] = (i == 0) ? uint4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu} : uint4{0u, 0u, 0u, 0u};
+        return;
+    }
+    const uint4* src = reinterpret_cast<const uint4*>(slots + (size_t)best * stride);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < ngroups; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+int launch_slots_pick(gj_ctx* ctx, const uint8_t* d_slots, size_t stride, const int* d_offsets, const int* d_members, int n_groups,
+                      uint8_t* d_out) {
+    if (n_groups < 1) return fail(ctx, GJ_ERR_INVALID, "n_groups must be >= 1");
+    if ((stride & 15) || ((reinterpret_cast<uintptr_t>(d_slots) | reinterpret_cast<uintptr_t>(d_out)) & 15))
+        return fail(ctx, GJ_ERR_INVALID, "slots must be 16-byte aligned");
+    size_t blocks = (stride / 16 + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(slots_pick_kernel, dim3((unsigned)blocks, (unsigned)n_groups), dim3(256), 0, ctx->stream, d_slots,
+                       stride, d_offsets, d_members, d_out);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
 }

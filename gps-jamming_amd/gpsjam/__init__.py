@@ -497,6 +497,44 @@ class Device:
                                                  _ptr(d_pairs) or None, _ptr(d_lags) or None, _ptr(d_peaks) or None,
                                                  _ptr(d_margins) or None, _ptr(d_out)))
 
+    # ------------------------------------------------------------------ one capture over several GPUs
+    def amp_tile_count(self, nbytes: int) -> int:
+        return self._lib.gj_amp_tile_count(int(nbytes))
+
+    def part_scan_dev(self, view, chunk_bytes, d_power, rssi_threshold, d_tiles, d_amp, noise_samples, window, factor,
+                      d_onset, eps=1e-10, flags=0):
+        """K1 + K3 + K4 of one part (gj_part_scan_dev); ``view`` is a _ffi.PartView."""
+        self._check(self._lib.gj_part_scan_dev(self._ctx, C.byref(view), chunk_bytes, eps, flags, _ptr(d_power),
+                                               rssi_threshold, _ptr(d_tiles), _ptr(d_amp), noise_samples, window, factor,
+                                               _ptr(d_onset)))
+
+    def part_welch_dev(self, view, chunk_samples, nperseg, fs, d_psd, d_psd_db=None, shift=True):
+        self._check(self._lib.gj_part_welch_dev(self._ctx, C.byref(view), chunk_samples, nperseg, fs,
+                                                _ffi.GJ_WELCH_SHIFT if shift else 0, _ptr(d_psd), _ptr(d_psd_db) or None))
+
+    def part_welch_workspace(self, view, chunk_samples, nperseg) -> int:
+        return self._lib.gj_part_welch_workspace(self._ctx, C.byref(view), chunk_samples, nperseg)
+
+    def part_slot_dev(self, view, d_start, n_samples, d_slot):
+        self._check(self._lib.gj_part_slot_dev(self._ctx, C.byref(view), _ptr(d_start), n_samples, _ptr(d_slot)))
+
+    def slots_pick_dev(self, d_slots, slot_stride, d_offsets, d_members, n_groups, d_out):
+        self._check(self._lib.gj_slots_pick_dev(self._ctx, _ptr(d_slots), slot_stride, _ptr(d_offsets), _ptr(d_members),
+                                                n_groups, _ptr(d_out)))
+
+    def amp_combine_dev(self, d_tiles, n_tiles, d_parts, n_parts, total_bytes, d_out):
+        self._check(self._lib.gj_amp_combine_dev(self._ctx, _ptr(d_tiles), n_tiles, _ptr(d_parts), n_parts, total_bytes,
+                                                 _ptr(d_out)))
+
+    def onset_combine_dev(self, d_parts, n_parts, d_out):
+        self._check(self._lib.gj_onset_combine_dev(self._ctx, _ptr(d_parts), n_parts, _ptr(d_out)))
+
+    def part_result_len(self, chunk_cap, tile_cap, rows_cap, nperseg, pair_cap) -> int:
+        return self._lib.gj_part_result_len(chunk_cap, tile_cap, rows_cap, nperseg, pair_cap)
+
+    def pack_part_dev(self, args, d_out):
+        self._check(self._lib.gj_pack_part_dev(self._ctx, C.byref(args), _ptr(d_out)))
+
     def synth_dev(self, spec, n_samples: int, d_out, first_sample: int = 0):
         """Fill d_out[2*n_samples] with the capture described by a synth.StreamSpec."""
         p = SynthParams(spec.key_noise, spec.key_common, spec.delay, spec.jam_start,

@@ -52,6 +52,29 @@ class Onset(C.Structure):
         return self.start_index >= 0 and self.margin_hit < self.NEAR_TIE
 
 
+class PartView(C.Structure):
+    """gj_part_view: one part of a capture split over GPUs (include/gpsjam.h)."""
+    _fields_ = [("d_buf", C.c_void_p), ("buf_bytes", C.c_size_t), ("buf_first_byte", C.c_size_t),
+                ("own_first_byte", C.c_size_t), ("own_bytes", C.c_size_t), ("total_bytes", C.c_size_t),
+                ("d_noise", C.c_void_p)]
+
+
+class AmpPart(C.Structure):
+    _fields_ = [("first_index", C.c_int64), ("count", C.c_uint64), ("sum", C.c_double), ("tail", C.c_double)]
+
+
+class PartPack(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("antenna", C.c_int32), ("part", C.c_int32), ("parts", C.c_int32),
+                ("first_chunk", C.c_uint64), ("n_chunks", C.c_uint64), ("chunk_cap", C.c_uint64),
+                ("first_row", C.c_uint64), ("rows", C.c_uint64), ("rows_cap", C.c_uint64),
+                ("first_tile", C.c_uint64), ("n_tiles", C.c_uint64), ("tile_cap", C.c_uint64),
+                ("first_sample", C.c_int64),
+                ("nperseg", C.c_int32), ("n_pairs", C.c_int32), ("pair_cap", C.c_int32), ("reserved", C.c_int32),
+                ("d_power", C.c_void_p), ("d_amp", C.c_void_p), ("d_onset", C.c_void_p), ("d_tiles", C.c_void_p),
+                ("d_psd", C.c_void_p), ("d_pairs", C.c_void_p), ("d_lags", C.c_void_p), ("d_peaks", C.c_void_p),
+                ("d_margins", C.c_void_p)]
+
+
 class SynthParams(C.Structure):
     _fields_ = [("key_noise", C.c_uint64), ("key_common", C.c_uint64), ("delay", C.c_int64),
                 ("jam_start", C.c_int64), ("jam_end", C.c_int64), ("noise_k", C.c_int32),
@@ -114,6 +137,16 @@ SIGNATURES = {
     "gj_tdoa_slot_bytes": (_sz, [_sz]),
     "gj_tdoa_slot_dev": (_i, [_vp, _vp, _sz, _vp, _sz, _vp]),
     "gj_xcorr_slots_dev": (_i, [_vp, _vp, _sz, _i, _sz, C.POINTER(C.c_int32), _i, _vp, _vp, _vp]),
+    "gj_amp_tile_count": (_sz, [_sz]),
+    "gj_part_scan_dev": (_i, [_vp, C.POINTER(PartView), _sz, _f, _i, _vp, _f, _vp, _vp, _i, _i, _f, _vp]),
+    "gj_part_welch_dev": (_i, [_vp, C.POINTER(PartView), _sz, _i, _d, _i, _vp, _vp]),
+    "gj_part_welch_workspace": (_sz, [_vp, C.POINTER(PartView), _sz, _i]),
+    "gj_part_slot_dev": (_i, [_vp, C.POINTER(PartView), _vp, _sz, _vp]),
+    "gj_slots_pick_dev": (_i, [_vp, _vp, _sz, _vp, _vp, _i, _vp]),
+    "gj_amp_combine_dev": (_i, [_vp, _vp, _sz, _vp, _i, _sz, _vp]),
+    "gj_onset_combine_dev": (_i, [_vp, _vp, _i, _vp]),
+    "gj_part_result_len": (_sz, [_sz, _sz, _sz, _i, _i]),
+    "gj_pack_part_dev": (_i, [_vp, C.POINTER(PartPack), _vp]),
     "gj_acq_search_dev": (_i, [_vp, _vp, _sz, _sz, _i, _i, _vp, _i, _vp, _i, _i, _d, _f, _vp, _vp]),
     "gj_acq_workspace": (_sz, [_vp, _i, _i, _i, _i, _i]),
     "gj_comm_unique_id": (_i, [_vp]),

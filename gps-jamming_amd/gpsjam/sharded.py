@@ -34,13 +34,15 @@ import torch
 
 _log = logging.getLogger("gpsjam.sharded")
 
-HEADER = 32          # GJ_RESULT_HEADER: scalars in front of the vectors, see RESULT_FIELDS
+HEADER = 40          # GJ_RESULT_HEADER: scalars in front of the vectors, see RESULT_FIELDS
 RESULT_FIELDS = ("n_chunks", "baseline", "threshold", "n_above", "amp_first", "amp_count",
                  "amp_mean", "onset", "lag", "peak", "noise_power", "n_rows", "nperseg",
                  "rank", "n_pairs", "pair_capacity", "onset_margin_hit", "onset_margin_before",
                  "onset_guard", "onset_threshold", "antenna", "part", "parts", "first_chunk",
-                 "first_row", "first_sample", "amp_sum", "amp_tail", "tiles",
-                 "reserved0", "reserved1", "reserved2")
+                 "first_row", "first_sample", "amp_sum", "amp_tail", "tiles", "first_tile",
+                 "reserved0", "reserved1",
+                 "onset_record0", "onset_record1", "onset_record2", "onset_record3",      # gj_onset as it is (32 bytes)
+                 "amp_record0", "amp_record1", "amp_record2", "amp_record3")              # gj_amp_stats / gj_amp_part
 ONSET_NEAR_TIE = 1e-6     # gj_onset: the rounding band of K4's decision (include/gpsjam.h)
 LAG_NEAR_TIE = 2e-5       # K5: 1 - runner-up/peak below the rounding of a complex64 FFT
 SLOT_HEADER = 16     # GJ_SLOT_HEADER: int64 flag (0 valid / -1 invalid), int64 start sample
@@ -90,6 +92,19 @@ def canonical_pair(i: int, j: int, lag: int):
     return j, i, (lag if lag == LAG_INVALID else -lag)
 
 
+def pack_stream_reference(st) -> torch.Tensor:
+    """The result vector of an AntennaStream rebuilt with torch ops from the device outputs its kernels left
+    (tests: gj_pack_result_dev against this packer)."""
+    amp_mean = st.amp[3:4].view(torch.float32)[0]
+    f = st.onset[1:3].view(torch.float32)            # noise_power, threshold, margin_hit, margin_before
+    return pack_results(st.n_chunks, st.nperseg, st.power, st.stats, st.amp[0], st.amp[1], amp_mean, st.onset[0],
+                        torch.tensor(0 if st.rank == 0 else LAG_INVALID), torch.tensor(0.0), f[0],
+                        st.psd[:st.rows].mean(dim=0), st.rows, st.rank, pairs=st.pairs, pair_lags=st.lags,
+                        pair_peaks=st.peaks, pair_margins=st.margins, capacity=st.pair_cap,
+                        onset_margins=(float(f[2]), float(f[3])), onset_guard=st.onset[3], onset_threshold=float(f[1]),
+                        amp_sum=float(st.amp[2:3].view(torch.float64)[0]), onset_record=st.onset, amp_record=st.amp)
+
+
 def pack_results(n_chunks: int, nperseg: int, power_map: torch.Tensor, stats: torch.Tensor,
                  amp_first: torch.Tensor, amp_count: torch.Tensor, amp_mean: torch.Tensor,
                  onset: torch.Tensor, lag: torch.Tensor, peak: torch.Tensor,
@@ -97,7 +112,8 @@ def pack_results(n_chunks: int, nperseg: int, power_map: torch.Tensor, stats: to
                  rank: int, pairs: Sequence[Tuple[int, int]] = (), pair_lags: Optional[torch.Tensor] = None,
                  pair_peaks: Optional[torch.Tensor] = None, pair_margins: Optional[torch.Tensor] = None,
                  capacity: int = 0, onset_margins: Sequence[float] = (1.0, 1.0), onset_guard: Optional[torch.Tensor] = None,
-                 onset_threshold: float = 0.0, amp_sum: float = 0.0) -> torch.Tensor:
+                 onset_threshold: float = 0.0, amp_sum: float = 0.0, onset_record: Optional[torch.Tensor] = None,
+                 amp_record: Optional[torch.Tensor] = None) -> torch.Tensor:
     """float64 vector [HEADER + n_chunks + nperseg + 5 capacity] (the layout of gj_pack_result_dev) built
     with device-side ops only (no host synchronisation).  int64 scalars are exact in float64 up to 2^53."""
     dev = power_map.device
@@ -122,6 +138,10 @@ def pack_results(n_chunks: int, nperseg: int, power_map: torch.Tensor, stats: to
     head[20] = rank
     head[22] = 1
     head[26] = float(amp_sum)
+    if onset_record is not None:          # the 32-byte device records as they are (int64[4] views)
+        head[32:36] = onset_record.view(torch.float64)
+    if amp_record is not None:
+        head[36:40] = amp_record.view(torch.float64)
     block = torch.zeros((capacity, PAIR_FIELDS), dtype=torch.float64, device=dev)
     if len(pairs):
         block[:len(pairs), 0:2] = torch.tensor(list(pairs), dtype=torch.float64, device=dev)

@@ -1,0 +1,392 @@
+"""One capture over several GPUs ("fewer files than GPUs => split one file into
+contiguous chunk ranges aligned to 65 536 B / 1-s chunks").
+
+The reference's deployment has THREE antennas (GpsJammerApp/app/worker.py:97-101,586-600;
+skrypty/triangulateRSSI.py:147-154).  With one capture per GPU an 8-GPU node leaves five GPUs idle and the
+per-file latency where it was; here the captures are laid end to end, cut into ``world`` contiguous runs of
+*units* (a unit = lcm(power chunk, PSD chunk) = 8 192 000 bytes = 2 s of capture) and every rank works on its
+run -- at most one part of two neighbouring captures each.  Per-rank work falls as 1/world: strong scaling.
+
+What a part computes, and why the combined result is bit-identical to the unsplit run (tests pin it):
+  K1 chunk powers, K2 PSD rows   per-chunk quantities; parts start on chunk boundaries; the Welch workgroup
+                                 split is planned for the whole capture (gj_part_welch_dev)
+  K3 amplitude statistics        per-64-KiB-tile sums travel as they are; the combining rank adds them with the
+                                 same code in the same order (gj_amp_combine_dev); the first hit and the tail
+                                 of its tile come from the part that holds the bytes
+  K4 onset                       exact integer window sums; every part brings a halo of one tile in front of
+                                 its range and the capture's noise span (each rank reads those 400 KB itself
+                                 -- no collective), so the parts' moving-average positions tile the capture;
+                                 the smallest index wins (gj_onset_combine_dev)
+  TDOA slot                      cut by every part that found an onset in its positions (the buffer has a tail
+                                 of one slice behind the own range); gj_slots_pick_dev keeps, per capture, the
+                                 slot cut at the smallest onset: the bytes the unsplit capture would have cut
+Exchange: ONE all-gather of the parts' slots, then every rank solves its share of the antenna pairs; ONE
+gather of the part vectors to rank 0, which rebuilds each capture's arrays in HBM and runs the same tail
+kernels (threshold, mean spectrum, packing) as a single-GPU stream.  ``StepResults`` comes out as from
+``gpsjam.sharded.AntennaStream``: one result vector per ANTENNA.
+"""
+from __future__ import annotations
+
+import contextlib
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _ffi
+from .sharded import (HEADER, LAG_INVALID, PAIR_FIELDS, StepResults, all_pairs, allgather_rows, gather_rows,
+                      result_len, slot_bytes)
+
+TILE = 65536
+
+
+def unit_bytes(chunk_bytes: int = 65536, chunk_samples: int = 2048000) -> int:
+    """Smallest run of capture bytes that is a whole number of power chunks AND of PSD chunks."""
+    return math.lcm(int(chunk_bytes), 2 * int(chunk_samples))
+
+
+@dataclass(frozen=True)
+class Part:
+    antenna: int
+    part: int            # index among the parts of its capture
+    parts: int           # parts of its capture
+    first_byte: int      # own range [first_byte, first_byte + own_bytes) of the capture
+    own_bytes: int
+    total_bytes: int     # of the capture
+    rank: int
+    local: int           # index among the parts of its rank
+
+    @property
+    def is_last(self) -> bool:
+        return self.first_byte + self.own_bytes == self.total_bytes
+
+
+def plan_parts(capture_bytes: Sequence[int], world: int, unit: int) -> List[Part]:
+    """Lay the captures end to end in units and cut the line into ``world`` contiguous runs of (almost) equal
+    length; a run that crosses the boundary between two captures gives its rank one part of each.  The ragged
+    end of a capture belongs to its last unit.  Ranks beyond the number of units get nothing."""
+    units = [max(1, -(-int(b) // unit)) for b in capture_bytes]
+    total = sum(units)
+    bounds = [(r * total) // world for r in range(world + 1)]
+    start_of = [sum(units[:a]) for a in range(len(units))]
+    raw = []
+    for r in range(world):
+        lo, hi = bounds[r], bounds[r + 1]
+        for a, (s0, n) in enumerate(zip(start_of, units)):
+            u0, u1 = max(lo, s0), min(hi, s0 + n)
+            if u0 < u1:
+                first = (u0 - s0) * unit
+                end = min((u1 - s0) * unit, int(capture_bytes[a])) if u1 - s0 < n else int(capture_bytes[a])
+                raw.append((a, first, end - first, r))
+    out, per_rank = [], {}
+    for a in range(len(units)):
+        mine = [x for x in raw if x[0] == a]
+        for g, (_, first, own, r) in enumerate(mine):
+            out.append((a, g, len(mine), first, own, int(capture_bytes[a]), r))
+    out.sort(key=lambda x: (x[6], x[0], x[1]))
+    parts = []
+    for a, g, G, first, own, tot, r in out:
+        j = per_rank.get(r, 0)
+        per_rank[r] = j + 1
+        parts.append(Part(a, g, G, first, own, tot, r, j))
+    return parts
+
+
+def halo_bytes(part: Part, window: int) -> int:
+    """Whole tiles in front of the own range holding at least window - 1 samples (none for a capture's first part)."""
+    if part.first_byte == 0:
+        return 0
+    return -(-2 * (window - 1) // TILE) * TILE
+
+
+def buffer_range(part: Part, window: int, slice_samples: int) -> Tuple[int, int]:
+    """Capture bytes [b0, b1) a rank keeps in HBM for a part: halo + own range + one TDOA slice of tail."""
+    b0 = part.first_byte - halo_bytes(part, window)
+    tail = -(-2 * slice_samples // TILE) * TILE
+    return b0, min(part.total_bytes, part.first_byte + part.own_bytes + tail)
+
+
+def deal_pairs(n_ant: int, ranks_with_parts: Sequence[int]) -> dict:
+    """Every antenna pair once, dealt round-robin over the ranks that hold a part."""
+    deal = {r: [] for r in ranks_with_parts}
+    order = sorted(ranks_with_parts)
+    for k, p in enumerate(all_pairs(n_ant)):
+        deal[order[k % len(order)]].append(p)
+    return deal
+
+
+class PartStream:
+    """One part on this GPU: its buffers and the three per-part kernels (no host synchronisation anywhere)."""
+
+    def __init__(self, dev, dev_side, part: Part, buf: torch.Tensor, noise: Optional[torch.Tensor], *, chunk_bytes,
+                 chunk_samples, nperseg, fs, slice_samples, noise_samples, window, factor, rssi_threshold):
+        b0, b1 = buffer_range(part, window, slice_samples)
+        assert buf.dtype == torch.uint8 and buf.is_contiguous() and buf.numel() == b1 - b0, (buf.numel(), b1 - b0)
+        if part.first_byte:
+            assert noise is not None and noise.numel() >= 2 * noise_samples
+        self.part, self.dev, self.dev_side, self.buf, self.noise = part, dev, dev_side, buf, noise
+        self.chunk_bytes, self.chunk_samples, self.nperseg, self.fs = chunk_bytes, chunk_samples, nperseg, fs
+        self.slice_samples, self.noise_samples, self.window, self.factor = slice_samples, noise_samples, window, factor
+        self.rssi_threshold = rssi_threshold
+        self.view = _ffi.PartView(buf.data_ptr(), buf.numel(), b0, part.first_byte, part.own_bytes, part.total_bytes,
+                                  noise.data_ptr() if noise is not None else None)
+        d = buf.device
+        self.n_chunks = dev.chunk_count(part.own_bytes, chunk_bytes)
+        self.rows = dev.welch_rows(part.own_bytes, chunk_samples, nperseg)
+        self.n_tiles = dev.amp_tile_count(part.own_bytes)
+        self.first_chunk = part.first_byte // chunk_bytes
+        self.first_row = part.first_byte // (2 * chunk_samples)
+        self.first_tile = part.first_byte // TILE
+        self.power = torch.empty(max(self.n_chunks, 1), dtype=torch.float32, device=d)
+        self.tiles = torch.zeros(2 * max(self.n_tiles, 1), dtype=torch.float64, device=d)   # (sum, first) records
+        self.amp = torch.zeros(4, dtype=torch.int64, device=d)                                 # gj_amp_part
+        self.onset = torch.zeros(4, dtype=torch.int64, device=d)                               # gj_onset
+        self.psd = torch.empty((max(self.rows, 1), nperseg), dtype=torch.float32, device=d)
+
+    def scan(self):
+        self.dev_side.part_scan_dev(self.view, self.chunk_bytes, self.power, self.rssi_threshold, self.tiles, self.amp,
+                                    self.noise_samples, self.window, self.factor, self.onset)
+
+    def welch(self):
+        self.dev.part_welch_dev(self.view, self.chunk_samples, self.nperseg, self.fs, self.psd)
+
+    def slot(self, out: torch.Tensor):
+        self.dev_side.part_slot_dev(self.view, self.onset, self.slice_samples, out)
+
+
+class SplitStreams:
+    """This rank's share of ``capture_bytes`` (one entry per antenna) cut by ``plan_parts``.
+
+    ``make_buffer(part, b0, b1)`` returns the uint8 device tensor holding capture bytes [b0, b1) of the part's
+    antenna; ``make_noise(antenna, nbytes)`` the capture's first ``nbytes`` bytes (asked for every part that does
+    not start its capture).  Both are called at construction, for this rank's parts only."""
+
+    def __init__(self, dev, capture_bytes: Sequence[int], make_buffer, make_noise, *, rank: int = 0, world_size: int = 1,
+                 chunk_bytes: int = 65536, chunk_samples: int = 2048000, nperseg: int = 4096, fs: float = 2.048e6,
+                 slice_samples: int = 1 << 19, noise_samples: int = 200000, window: int = 1000, factor: float = 50.0,
+                 rssi_threshold: float = 0.0, overlap: Optional[bool] = None, device=None):
+        self.dev, self.rank, self.world = dev, rank, world_size
+        self.capture_bytes = [int(b) for b in capture_bytes]
+        self.n_ant = len(self.capture_bytes)
+        self.chunk_bytes, self.chunk_samples, self.nperseg, self.fs = chunk_bytes, chunk_samples, nperseg, fs
+        self.slice_samples, self.noise_samples, self.window, self.factor = slice_samples, noise_samples, window, factor
+        self.unit = unit_bytes(chunk_bytes, chunk_samples)
+        self.parts = plan_parts(self.capture_bytes, world_size, self.unit)
+        self.mine = [p for p in self.parts if p.rank == rank]
+        self.pmax = max(1, max((p.local for p in self.parts), default=0) + 1)
+        d = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.device = d
+        self.is_root = rank == 0
+        self.overlap = bool(d.type == "cuda" if overlap is None else overlap)
+        self.dev_side = dev
+        self._main = torch.cuda.current_stream(d) if d.type == "cuda" else None
+        if self._main is not None:
+            dev.set_stream(self._main.cuda_stream)
+        if self.overlap:
+            self.dev_side = type(dev)(dev.index)
+            self._side = torch.cuda.Stream(device=d)
+            self.dev_side.set_stream(self._side.cuda_stream)
+            self._ev_free, self._ev_side, self._ev_packed = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+            self._ev_free.record(self._main)
+        else:
+            self._side = self._main
+        kw = dict(chunk_bytes=chunk_bytes, chunk_samples=chunk_samples, nperseg=nperseg, fs=fs, slice_samples=slice_samples,
+                  noise_samples=noise_samples, window=window, factor=factor, rssi_threshold=rssi_threshold)
+        self.streams: List[PartStream] = []
+        for p in self.mine:
+            b0, b1 = buffer_range(p, window, slice_samples)
+            noise = make_noise(p.antenna, 2 * noise_samples) if p.first_byte else None
+            self.streams.append(PartStream(dev, self.dev_side, p, make_buffer(p, b0, b1), noise, **kw))
+        # capacities of a part vector: the largest part of the plan (every rank knows the whole plan)
+        self.chunk_cap = max(dev.chunk_count(p.own_bytes, chunk_bytes) for p in self.parts)
+        self.tile_cap = max(dev.amp_tile_count(p.own_bytes) for p in self.parts)
+        self.rows_cap = max(max(dev.welch_rows(p.own_bytes, chunk_samples, nperseg) for p in self.parts), 1)
+        ranks_with_parts = sorted({p.rank for p in self.parts})
+        self.deal = deal_pairs(self.n_ant, ranks_with_parts)
+        self.pairs = self.deal.get(rank, [])
+        self.pair_cap = max(1, max(len(v) for v in self.deal.values()))
+        self.part_len = dev.part_result_len(self.chunk_cap, self.tile_cap, self.rows_cap, nperseg, self.pair_cap)
+        self.o_tiles = HEADER + self.chunk_cap
+        self.o_pairs = self.o_tiles + 2 * self.tile_cap
+        self.o_rows = self.o_pairs + PAIR_FIELDS * self.pair_cap
+        # slots: this rank's (pmax of them, unused ones stay invalid), everybody's, one per antenna
+        self.slot_bytes = slot_bytes(slice_samples)
+        self.my_slots = torch.zeros((self.pmax, self.slot_bytes), dtype=torch.uint8, device=d)
+        self._invalidate(self.my_slots)
+        self.all_slots = torch.zeros((world_size * self.pmax, self.slot_bytes), dtype=torch.uint8, device=d)
+        self.ant_slots = torch.zeros((self.n_ant, self.slot_bytes), dtype=torch.uint8, device=d)
+        members, offsets = [], [0]
+        for a in range(self.n_ant):
+            members += [p.rank * self.pmax + p.local for p in self.parts if p.antenna == a]
+            offsets.append(len(members))
+        self.d_members = torch.tensor(members or [0], dtype=torch.int32, device=d)
+        self.d_offsets = torch.tensor(offsets, dtype=torch.int32, device=d)
+        npairs = max(len(self.pairs), 1)
+        self.d_pairs = torch.tensor([x for p in self.pairs for x in p] or [0, 0], dtype=torch.int32, device=d)
+        self.lags = torch.full((npairs,), LAG_INVALID, dtype=torch.int32, device=d)
+        self.peaks = torch.zeros(npairs, dtype=torch.float32, device=d)
+        self.margins = torch.zeros(npairs, dtype=torch.float32, device=d)
+        # vectors: this rank's parts (two sets, used alternately), everybody's on the root, one per antenna on the root
+        self._vecs = [torch.zeros((self.pmax, self.part_len), dtype=torch.float64, device=d) for _ in range(2)]
+        self._gathered = ([torch.zeros((world_size, self.pmax * self.part_len), dtype=torch.float64, device=d) for _ in range(2)]
+                          if self.is_root else [None, None])
+        self.n_chunks_of = [dev.chunk_count(b, chunk_bytes) for b in self.capture_bytes]
+        self.rows_of = [dev.welch_rows(b, chunk_samples, nperseg) for b in self.capture_bytes]
+        self.total_pairs = self.n_ant * (self.n_ant - 1) // 2
+        self.final_len = max(result_len(n, nperseg, self.total_pairs) for n in self.n_chunks_of)
+        self._final = ([torch.zeros((self.n_ant, self.final_len), dtype=torch.float64, device=d) for _ in range(2)]
+                       if self.is_root else [None, None])
+        self._done = [torch.cuda.Event() for _ in range(2)] if d.type == "cuda" else [None, None]
+        self._idx = 0
+        self.last_psd = [None] * self.n_ant     # rank 0: each capture's waterfall rows as rebuilt by the last combine
+        # workspaces
+        ws_main = max([dev.part_welch_workspace(s.view, chunk_samples, nperseg) for s in self.streams] + [1 << 20])
+        ants = len({a for p in self.pairs for a in p}) or 1
+        ws_side = max(dev.xcorr_workspace(ants, slice_samples, npairs),
+                      max([(s.buf.numel()) // 48 + (1 << 20) for s in self.streams] + [1 << 20]))
+        if self.overlap:
+            dev.reserve(ws_main)
+            self.dev_side.reserve(ws_side)
+        else:
+            dev.reserve(max(ws_main, ws_side))
+
+    @staticmethod
+    def _invalidate(slots: torch.Tensor):
+        """Slot headers -> (flag -1, start -1): an unused slot must never be picked."""
+        slots.view(torch.int64)[:, :2] = -1
+
+    def _on_side(self):
+        return torch.cuda.stream(self._side) if self.overlap else contextlib.nullcontext()
+
+    # ---------------------------------------------------------------- the step
+    def scan(self):
+        """K1 + K3 + K4 of every part of this rank (side stream), K2 of every part (main stream)."""
+        if self.overlap:
+            self._side.wait_event(self._ev_free)
+        for s in self.streams:
+            s.scan()
+        if self.overlap:
+            self._ev_side.record(self._side)
+        for s in self.streams:
+            s.welch()
+
+    def tdoa(self):
+        """Slots of this rank's parts -> ONE all-gather -> one slot per antenna -> this rank's pairs."""
+        with self._on_side():
+            for j, s in enumerate(self.streams):
+                s.slot(self.my_slots[j])
+            if self.world > 1:
+                allgather_rows(self.my_slots.view(-1), self.world, out=self.all_slots.view(self.world, -1))
+                slots = self.all_slots
+            else:
+                slots = self.my_slots
+            self.dev_side.slots_pick_dev(slots, self.slot_bytes, self.d_offsets, self.d_members, self.n_ant, self.ant_slots)
+            if self.pairs:
+                self.dev_side.xcorr_slots_dev(self.ant_slots, self.slot_bytes, self.n_ant, self.slice_samples, self.pairs,
+                                              self.lags, self.peaks, self.margins)
+            if self.overlap:
+                self._ev_side.record(self._side)
+
+    def pack(self) -> torch.Tensor:
+        if self.overlap:
+            self._main.wait_event(self._ev_side)
+        self._idx ^= 1
+        vec = self._vecs[self._idx]
+        for j, s in enumerate(self.streams):
+            p = s.part
+            carries = j == 0                      # the pairs this rank solved ride on its first part's vector
+            a = _ffi.PartPack(self.rank, p.antenna, p.part, p.parts, s.first_chunk, s.n_chunks, self.chunk_cap,
+                              s.first_row, s.rows, self.rows_cap, s.first_tile, s.n_tiles, self.tile_cap,
+                              p.first_byte // 2, self.nperseg, len(self.pairs) if carries else 0, self.pair_cap, 0,
+                              s.power.data_ptr(), s.amp.data_ptr(), s.onset.data_ptr(), s.tiles.data_ptr(),
+                              s.psd.data_ptr(), self.d_pairs.data_ptr(), self.lags.data_ptr(), self.peaks.data_ptr(),
+                              self.margins.data_ptr())
+            self.dev.pack_part_dev(a, vec[j])
+        if self.overlap:
+            self._ev_free.record(self._main)
+            self._ev_packed.record(self._main)
+        return vec
+
+    def exchange(self, dst: int = 0) -> Optional[StepResults]:
+        assert dst == 0
+        vec = self.pack()
+        k = self._idx
+        if self.world > 1:
+            if self.overlap:
+                self._side.wait_event(self._ev_packed)
+            with self._on_side():
+                rows = gather_rows(vec.view(-1), self.rank, self.world, 0, out=self._gathered[k])
+                if self.overlap:
+                    ev = torch.cuda.Event()
+                    ev.record(self._side)
+                    self._main.wait_event(ev)
+        else:
+            rows = vec.view(1, -1)
+        if not self.is_root:
+            return None
+        final = self._combine(rows, self._final[k])
+        if self._done[k] is not None:
+            self._done[k].record(self._main)
+        return StepResults(final, self._done[k], self.n_ant)
+
+    def step(self) -> Optional[StepResults]:
+        self.scan()
+        self.tdoa()
+        return self.exchange(0)
+
+    # ---------------------------------------------------------------- rank 0: parts -> captures
+    def _combine(self, rows: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """Rebuild each capture's device arrays from its parts' vectors and run the tail kernels a single-GPU stream
+        runs (threshold, amplitude totals, onset, mean spectrum, packing): main stream, no host synchronisation."""
+        dev, L = self.dev, self.part_len
+        vec = lambda p: rows[p.rank, p.local * L:(p.local + 1) * L]          # noqa: E731
+        # every solved pair, in rank order (which rank solved what is static)
+        lag_l, peak_l, marg_l, pair_l = [], [], [], []
+        for r in sorted(self.deal):
+            n = len(self.deal[r])
+            if n:
+                blk = rows[r, self.o_pairs:self.o_pairs + PAIR_FIELDS * n].view(n, PAIR_FIELDS)
+                lag_l.append(blk[:, 2].to(torch.int32))
+                peak_l.append(blk[:, 3].to(torch.float32))
+                marg_l.append(blk[:, 4].to(torch.float32))
+                pair_l += self.deal[r]
+        if pair_l:
+            d_pairs = torch.tensor([x for p in pair_l for x in p], dtype=torch.int32, device=rows.device)
+            lags, peaks, margs = torch.cat(lag_l), torch.cat(peak_l), torch.cat(marg_l)
+        out.zero_()
+        for a in range(self.n_ant):
+            parts = [p for p in self.parts if p.antenna == a]
+            power = torch.cat([vec(p)[HEADER:HEADER + dev.chunk_count(p.own_bytes, self.chunk_bytes)] for p in parts]).to(torch.float32)
+            tiles = torch.cat([vec(p)[self.o_tiles:self.o_tiles + 2 * dev.amp_tile_count(p.own_bytes)] for p in parts]).contiguous()
+            onset_parts = torch.stack([vec(p)[32:36] for p in parts]).contiguous()
+            amp_parts = torch.stack([vec(p)[36:40] for p in parts]).contiguous()
+            rows_l = []
+            for p in parts:
+                nr = dev.welch_rows(p.own_bytes, self.chunk_samples, self.nperseg)
+                if nr:
+                    rows_l.append(vec(p)[self.o_rows:].view(torch.float32)[:nr * self.nperseg])
+            n_rows = self.rows_of[a]
+            psd = torch.cat(rows_l).view(n_rows, self.nperseg) if rows_l else torch.zeros((1, self.nperseg), dtype=torch.float32, device=rows.device)
+            n_chunks = self.n_chunks_of[a]
+            assert power.numel() == n_chunks and tiles.numel() == 2 * dev.amp_tile_count(self.capture_bytes[a])
+            stats = torch.empty(3, dtype=torch.float32, device=rows.device)
+            amp = torch.empty(4, dtype=torch.int64, device=rows.device)
+            onset = torch.empty(4, dtype=torch.int64, device=rows.device)
+            dev.power_threshold_dev(power, n_chunks, stats)
+            dev.amp_combine_dev(tiles, tiles.numel() // 2, amp_parts, len(parts), self.capture_bytes[a], amp)
+            dev.onset_combine_dev(onset_parts, len(parts), onset)
+            carries = a == 0 and bool(pair_l)
+            dev.pack_result_dev(n_chunks, power, stats, amp, onset, psd, n_rows, self.nperseg, a,
+                                len(pair_l) if carries else 0, self.total_pairs,
+                                d_pairs if carries else None, lags if carries else None, peaks if carries else None,
+                                margs if carries else None, out[a])
+            self.last_psd[a] = psd[:n_rows]
+            if rows.is_cuda:                       # the temporaries above are read by kernels queued on the main stream
+                for t in (power, tiles, onset_parts, amp_parts, psd, stats, amp, onset):
+                    t.record_stream(self._main)
+        return out
+
+    def close(self):
+        if self.overlap and self.dev_side is not self.dev:
+            self.dev_side.close()

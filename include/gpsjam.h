@@ -262,7 +262,7 @@ int gj_xcorr_slots_dev(gj_ctx* ctx, const uint8_t* d_slots, size_t slot_stride, 
 
 /* ------------------------------------------------- per-stream result vector ---------- */
 /* What one rank sends to rank 0 (gpsjam/sharded.py):
- * double[32 + n_chunks + nperseg + 5*pair_capacity] =
+ * double[40 + n_chunks + nperseg + 5*pair_capacity] =
  * header {  0 n_chunks, 1 baseline, 2 threshold, 3 n_above, 4 amp.first_index, 5 amp.count, 6 amp.mean,
  *           7 onset.start_index, 8 lag vs antenna 0 (0 on rank 0, GJ_LAG_INVALID elsewhere: the receiver
  *           fills it in from the pair table), 9 0, 10 onset.noise_power, 11 rows, 12 nperseg, 13 rank,
@@ -271,17 +271,96 @@ int gj_xcorr_slots_dev(gj_ctx* ctx, const uint8_t* d_slots, size_t slot_stride, 
  *             decision margins of K4 travel with the result, so the receiver knows when an onset was
  *             decided inside the rounding band (skrypty/triangulateTDOA.py:37-49),
  *          20 antenna, 21 part, 22 parts (1 = the stream is a whole capture), 23 first chunk, 24 first row,
- *          25 first sample of the part, 26 amp.sum, 27 amp tail, 28 tiles, 29-31 reserved },
+ *          25 first sample of the part, 26 amp.sum, 27 amp tail, 28 tiles, 29 first tile, 30-31 reserved,
+ *          32-35 the gj_onset record as it is (32 bytes), 36-39 the gj_amp_stats (gj_amp_part for a
+ *          part) record as it is },
  * the float32 power map, the mean over the rows of the PSD waterfall, and the pairs THIS stream
  * solved as {i, j, lag, peak, margin} each (d_pairs = {i0,j0,i1,j1,...} and the outputs of
  * gj_xcorr_slots_dev, all DEVICE arrays), zero-padded to pair_capacity -- packed by one kernel
  * from device-resident outputs (no host synchronisation). */
-#define GJ_RESULT_HEADER 32
+#define GJ_RESULT_HEADER 40
 #define GJ_RESULT_PAIR_FIELDS 5
 int gj_pack_result_dev(gj_ctx* ctx, size_t n_chunks, const float* d_power, const float* d_stats,
                        const gj_amp_stats* d_amp, const gj_onset* d_onset, const float* d_psd, size_t rows,
                        int nperseg, int rank, int n_pairs, int pair_capacity, const int32_t* d_pairs,
                        const int32_t* d_lags, const float* d_peaks, const float* d_margins, double* d_out);
+
+/* ------------------------------------------------- one capture over several GPUs ------ */
+/* "fewer files than GPUs => split one file into contiguous chunk ranges aligned to
+ * 65 536 B / 1-s chunks".  The reference's deployment has THREE antennas (GpsJammerApp/app/worker.py:97-101,
+ * 586-600; skrypty/triangulateRSSI.py:147-154); on an 8-GPU node each capture is cut into parts, one per GPU.
+ * A part OWNS the capture bytes [own_first_byte, own_first_byte + own_bytes): a whole number of power chunks and
+ * of PSD chunks (only the capture's last part may end ragged).  Its device buffer additionally holds
+ *   - a HALO in front (whole 64-KiB tiles, >= window - 1 samples; none for the first part), so that K4 evaluates
+ *     every window that ends inside the own range: the parts' position ranges then tile the capture,
+ *   - a TAIL behind (>= the TDOA slice), so that a slice that starts in the own range can be cut here,
+ * and every part but the first brings the capture's first 2*noise_samples bytes (d_noise) for K4's threshold --
+ * each rank reads those few hundred KB itself, so K1-K4 need NO collective.  Results are in CAPTURE coordinates
+ * and bit-identical to the unsplit run by construction: chunk powers and PSD rows are per-chunk quantities (the
+ * Welch workgroup split is planned for the whole capture), amplitude sums travel as per-tile sums and are added
+ * by the same code in the same order (gj_amp_combine_dev), window sums are exact integers. */
+typedef struct gj_part_view {
+    const uint8_t* d_buf;  /* DEVICE: capture bytes [buf_first_byte, buf_first_byte + buf_bytes), 16-byte aligned */
+    size_t buf_bytes;
+    size_t buf_first_byte;
+    size_t own_first_byte; /* multiple of chunk_bytes and of 2*chunk_samples; own_first_byte - buf_first_byte = halo */
+    size_t own_bytes;
+    size_t total_bytes;    /* of the whole capture */
+    const uint8_t* d_noise; /* DEVICE: the capture's first 2*noise_samples bytes (may be NULL for the first part) */
+} gj_part_view;
+typedef struct gj_amp_part {
+    int64_t first_index; /* capture coordinates; -1: nothing above the threshold in this part */
+    uint64_t count;      /* own samples from first_index to the end of the own range */
+    double sum;          /* of the amplitudes over those samples (this part alone) */
+    double tail;         /* of the amplitudes from first_index to the end of ITS 64-KiB tile */
+} gj_amp_part;
+/* 64-KiB amplitude tiles of a range of nbytes (16 bytes each: double sum, int64 first) */
+size_t gj_amp_tile_count(size_t nbytes);
+/* K1 + K3 + K4 of one part in one pass (gj_stream_scan_dev for a part): d_power[own chunks], d_tiles[own tiles],
+ * *d_amp, *d_onset (capture coordinates; duplicates of a crossing inside the halo are harmless: the combining
+ * rank takes the smallest index). */
+int gj_part_scan_dev(gj_ctx* ctx, const gj_part_view* part, size_t chunk_bytes, float eps, int flags, float* d_power,
+                     float rssi_threshold, void* d_tiles, gj_amp_part* d_amp, int noise_samples, int window,
+                     float factor, gj_onset* d_onset);
+/* K2 of the own range: rows [own_first_byte / (2 chunk_samples), ...) of the capture's waterfall */
+int gj_part_welch_dev(gj_ctx* ctx, const gj_part_view* part, size_t chunk_samples, int nperseg, double fs, int flags,
+                      float* d_psd, float* d_psd_db);
+size_t gj_part_welch_workspace(gj_ctx* ctx, const gj_part_view* part, size_t chunk_samples, int nperseg);
+/* TDOA slot cut from a part's buffer at the CAPTURE index *d_start (flag -2: valid in the capture but not held here) */
+int gj_part_slot_dev(gj_ctx* ctx, const gj_part_view* part, const int64_t* d_start, size_t n_samples, uint8_t* d_slot);
+/* Slots of the parts -> one slot per capture: group g = the slots d_members[d_offsets[g]] ...
+ * d_members[d_offsets[g+1] - 1] (DEVICE int arrays, d_offsets has n_groups + 1 entries); its slot is the one cut
+ * at the smallest start >= 0 (none: an invalid slot with start -1). */
+int gj_slots_pick_dev(gj_ctx* ctx, const uint8_t* d_slots, size_t slot_stride, const int32_t* d_offsets,
+                      const int32_t* d_members, int n_groups, uint8_t* d_out);
+/* On the combining rank: the capture's amplitude statistics from ALL its tile sums (in tile order) and the parts'
+ * first hits; its onset from the parts' onsets. */
+int gj_amp_combine_dev(gj_ctx* ctx, const void* d_tiles, size_t n_tiles, const gj_amp_part* d_parts, int n_parts,
+                       size_t total_bytes, gj_amp_stats* d_out);
+int gj_onset_combine_dev(gj_ctx* ctx, const gj_onset* d_parts, int n_parts, gj_onset* d_out);
+/* What a part sends to the combining rank: double[gj_part_result_len] = the 40-field header of
+ * gj_pack_result_dev (part fields filled, records 32-39 = gj_onset, gj_amp_part), chunk_cap chunk powers,
+ * tile_cap x (sum, first) tile records, pair_cap x {i, j, lag, peak, margin}, rows_cap x nperseg PSD values as
+ * float32 (two per double slot).  The capacities are the largest over all parts, so every vector has one length. */
+typedef struct gj_part_pack {
+    int32_t rank, antenna, part, parts;
+    uint64_t first_chunk, n_chunks, chunk_cap;
+    uint64_t first_row, rows, rows_cap;
+    uint64_t first_tile, n_tiles, tile_cap;
+    int64_t first_sample;
+    int32_t nperseg, n_pairs, pair_cap, reserved;
+    const float* d_power;
+    const gj_amp_part* d_amp;
+    const gj_onset* d_onset;
+    const void* d_tiles;
+    const float* d_psd;
+    const int32_t* d_pairs;
+    const int32_t* d_lags;
+    const float* d_peaks;
+    const float* d_margins;
+} gj_part_pack;
+size_t gj_part_result_len(size_t chunk_cap, size_t tile_cap, size_t rows_cap, int nperseg, int pair_cap);
+int gj_pack_part_dev(gj_ctx* ctx, const gj_part_pack* args, double* d_out);
 
 /* ------------------------------------------------- GNSS acquisition search ----------- */
 /* the reference receiver's parallel code-phase search, batched over every

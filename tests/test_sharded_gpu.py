@@ -27,14 +27,7 @@ def test_antenna_stream_single_gpu():
     torch.cuda.synchronize()
     assert len(got) == 1
     # the kernel-packed vector equals the torch-packed one
-    amp_mean = st.amp[3:4].view(torch.float32)[0]
-    noise = st.onset[1:2].view(torch.float32)[0]
-    margins = st.onset[2:3].view(torch.float32).tolist()           # gj_onset: margin_hit, margin_before
-    ref = sharded.pack_results(st.n_chunks, st.nperseg, st.power, st.stats, st.amp[0], st.amp[1], amp_mean,
-                               st.onset[0], torch.tensor(0), torch.tensor(0.0), noise, st.psd[:st.rows].mean(dim=0),
-                               st.rows, 0, onset_margins=margins, onset_guard=st.onset[3],
-                               onset_threshold=float(st.onset[1:2].view(torch.float32)[1]),
-                               amp_sum=float(st.amp[2:3].view(torch.float64)[0]))
+    ref = sharded.pack_stream_reference(st)
     np.testing.assert_allclose(got[0].cpu().numpy(), ref.cpu().numpy(), rtol=1e-6)
     np.testing.assert_array_equal(got[0][:sharded.HEADER + st.n_chunks].cpu().numpy(),
                                   ref[:sharded.HEADER + st.n_chunks].cpu().numpy())
@@ -144,12 +137,7 @@ def test_antenna_stream_three_antennas_one_gpu(overlap):
     assert all(m > 0.5 for m in td.margins)                # one clean peak per pair
     assert results[0].onset == onsets[0] and results[0].lag == 0
     # the kernel-packed vector (pair block included) equals the torch-packed one
-    amp_mean = st.amp[3:4].view(torch.float32)[0]
-    noise = st.onset[1:2].view(torch.float32)[0]
-    ref = sharded.pack_results(st.n_chunks, st.nperseg, st.power, st.stats, st.amp[0], st.amp[1], amp_mean, st.onset[0],
-                               torch.tensor(0), torch.tensor(0.0), noise, st.psd[:st.rows].mean(dim=0), st.rows, 0,
-                               pairs=st.pairs, pair_lags=st.lags, pair_peaks=st.peaks, pair_margins=st.margins,
-                               capacity=st.pair_cap)
+    ref = sharded.pack_stream_reference(st)
     got = outs[-1][0]
     assert got.numel() == sharded.result_len(st.n_chunks, st.nperseg, 3) == ref.numel()
     np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-6)

@@ -1,0 +1,230 @@
+"""One capture over several GPUs (gpsjam/split.py) rehearsed on ONE GPU: 2 and 4 fresh processes share
+cuda:0, talk over gloo and each runs the REAL part kernels on its run of the captures.  Rank 0's combined results must
+be BIT-IDENTICAL to what the single-GPU pipeline (gpsjam.sharded.AntennaStream) gives on the whole captures -- power
+map, threshold statistics, PSD rows, mean spectrum, amplitude statistics, onset, guard index, TDOA slots' lags -- on
+the golden inputs G1-G4 and on synthetic three-antenna captures, and must agree with the golden vectors."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+for p in (os.path.join(REPO, "gps-jamming_amd"), REPO, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def scenarios(big=False):
+    """name -> (captures, parameters).  chunk_samples are chosen so that a unit (lcm of the power chunk and the PSD
+    chunk) is small against the captures; G2 keeps the reference's 1-s chunk and therefore cannot be cut (one part,
+    the other ranks idle: the empty-rank path)."""
+    from golden import golden_inputs as gi
+    from gpsjam.synth import StreamSpec, generate
+    out = {}
+    out["g1"] = ([gi.g1_stream()], dict(chunk_samples=32768, nperseg=256, slice_samples=1 << 12, rssi_threshold=0.0))
+    out["g2"] = ([gi.g2_stream()], dict(chunk_samples=2048000, nperseg=4096, slice_samples=1 << 12, rssi_threshold=0.0))
+    out["g3"] = (gi.g3_streams(), dict(chunk_samples=32768, nperseg=1024, slice_samples=1 << 12, rssi_threshold=0.1,
+                                        noise_samples=20000))
+    out["g4"] = (gi.g4_streams(), dict(chunk_samples=32768, nperseg=1024, slice_samples=1 << 19, rssi_threshold=0.0))
+    n = 1_700_000
+    syn = [generate(StreamSpec(seed=29, antenna=a, delay=d, jam_start=1_150_000, jam_end=1_600_000, jam_sigma=s), n)
+           for a, (d, s) in enumerate(((0, 60.0), (5, 50.0), (-3, 55.0)))]
+    syn[1] = syn[1][:-12345]                                       # captures of unequal, ragged length
+    out["syn3"] = (syn, dict(chunk_samples=131072, nperseg=4096, slice_samples=1 << 15, rssi_threshold=0.05))
+    if big:                                                         # 256 MiB, the reference's chunk sizes; made on the GPU
+        spec = StreamSpec(seed=31, antenna=0, jam_start=70_000_000, jam_end=100_000_000, jam_sigma=60.0)
+        out["big"] = ([(spec, 1 << 28)], dict(chunk_samples=2048000, nperseg=4096, slice_samples=1 << 19,
+                                              rssi_threshold=0.0))
+    return out
+
+
+def _nbytes(src):
+    return src[1] if isinstance(src, tuple) else int(src.size)
+
+
+def _device_range(dev, src, b0, b1):
+    """Capture bytes [b0, b1) in HBM: from a host array, or generated in place (bit-identical integer generator)."""
+    import torch
+    if isinstance(src, tuple):
+        t = torch.zeros(b1 - b0, dtype=torch.uint8, device="cuda")
+        dev.synth_dev(src[0], (b1 - b0) // 2, t, first_sample=b0 // 2)
+        return t
+    return torch.from_numpy(np.ascontiguousarray(src[b0:b1])).cuda()
+
+
+def _collect(res, td, psd_rows):
+    return dict(
+        streams=[dict(power_map=r.power_map, baseline=r.baseline, threshold=r.threshold, n_above=r.n_above,
+                      amp_first=r.amp_first, amp_count=r.amp_count, amp_mean=r.amp_mean, onset=r.onset,
+                      onset_guard=r.onset_guard, onset_margin_hit=r.onset_margin_hit, noise_power=r.noise_power,
+                      spec=r.mean_spectrum, psd=psd_rows[k]) for k, r in enumerate(res)],
+        pairs=list(td.pairs), lags=list(td.lags), peaks=list(td.peaks), margins=list(td.margins))
+
+
+def _worker(rank, world, port, names, big, q):
+    for p in (os.path.join(REPO, "gps-jamming_amd"), REPO, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gpsjam
+        from gpsjam import split
+
+        torch.cuda.set_device(0)
+        dev = gpsjam.Device(0)
+        work = torch.cuda.Stream()
+        torch.cuda.set_stream(work)
+        dev.set_stream(work.cuda_stream)
+        sc = scenarios(big)
+        out = {}
+        for name in names:
+            caps, kw = sc[name]
+
+            def make_buffer(part, b0, b1, caps=caps):
+                return _device_range(dev, caps[part.antenna], b0, b1)
+
+            def make_noise(antenna, nbytes, caps=caps):
+                return _device_range(dev, caps[antenna], 0, nbytes)
+
+            st = split.SplitStreams(dev, [_nbytes(c) for c in caps], make_buffer, make_noise, rank=rank, world_size=world, **kw)
+            got = None
+            for _ in range(3):                                  # several steps back to back: buffers alternate
+                got = st.step()
+            if rank == 0:
+                res, td = got.unpack()
+                out[name] = _collect(res, td, [p.cpu().numpy().copy() for p in st.last_psd])
+                out[name]["parts"] = [(p.antenna, p.part, p.parts, p.first_byte, p.own_bytes, p.rank) for p in st.parts]
+            torch.cuda.synchronize()
+            dist.barrier()
+            st.close()
+        q.put(("root", out) if rank == 0 else ("other", rank))
+        dev.close()
+    except Exception as e:                                      # surface the failure in the parent
+        import traceback
+        q.put(("fail", rank, repr(e) + "\n" + traceback.format_exc()))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def _single_gpu(dev, caps, kw):
+    """The established single-GPU path on the whole captures: one AntennaStream per capture, then every pair over
+    the slots they cut."""
+    import torch
+    from gpsjam import sharded
+    res, slots, psd = [], [], []
+    sl = kw["slice_samples"]
+    for a, raw in enumerate(caps):
+        st = sharded.AntennaStream(dev, _device_range(dev, raw, 0, _nbytes(raw)), nperseg=kw["nperseg"], chunk_samples=kw["chunk_samples"],
+                                   slice_samples=sl, rssi_threshold=kw["rssi_threshold"],
+                                   noise_samples=kw.get("noise_samples", 200000), rank=0, world_size=1)
+        got = st.step()
+        r, _ = got.unpack()
+        res.append(r[0])
+        slots.append(st.slots[0].clone())
+        psd.append(st.psd[:st.rows].cpu().numpy().copy())
+        st.close()
+    pairs = sharded.all_pairs(len(caps))
+    lags = peaks = margins = []
+    if pairs:
+        all_slots = torch.stack(slots).contiguous()
+        d_l = torch.zeros(len(pairs), dtype=torch.int32, device="cuda")
+        d_p = torch.zeros(len(pairs), dtype=torch.float32, device="cuda")
+        d_m = torch.zeros(len(pairs), dtype=torch.float32, device="cuda")
+        dev.xcorr_slots_dev(all_slots, all_slots.shape[1], len(caps), sl, pairs, d_l, d_p, d_m)
+        torch.cuda.synchronize()
+        lags, peaks, margins = d_l.tolist(), d_p.tolist(), d_m.tolist()
+    td = type("TD", (), dict(pairs=pairs, lags=lags, peaks=peaks, margins=margins))
+    return _collect(res, td, psd)
+
+
+def _assert_identical(name, got, want):
+    assert len(got["streams"]) == len(want["streams"])
+    for a, (g, w) in enumerate(zip(got["streams"], want["streams"])):
+        where = f"{name} antenna {a}"
+        for key in ("power_map", "spec", "psd"):
+            assert g[key].shape == w[key].shape, (where, key, g[key].shape, w[key].shape)
+            assert g[key].tobytes() == w[key].tobytes(), (where, key, float(np.max(np.abs(g[key] - w[key]))))
+        for key in ("baseline", "threshold", "n_above", "amp_first", "amp_count", "amp_mean", "onset", "onset_guard",
+                    "onset_margin_hit", "noise_power"):
+            assert g[key] == w[key], (where, key, g[key], w[key])
+    assert got["pairs"] == want["pairs"] and got["lags"] == want["lags"], (name, got["lags"], want["lags"])
+    assert got["peaks"] == want["peaks"] and got["margins"] == want["margins"], name
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 4])
+def test_split_is_bit_identical_to_the_single_gpu_run(world, dev):
+    import torch
+    import torch.multiprocessing as mp
+    from oracle import gpsjam_oracle as orc
+
+    big = world == 2
+    names = ["g1", "g2", "g3", "g4", "syn3"] + (["big"] if big else [])
+    ctx = mp.get_context("spawn")                               # fresh children: no GPU state is inherited
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, names, big, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    msgs = [q.get(timeout=800) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(m[0] != "fail" for m in msgs), [m for m in msgs if m[0] == "fail"]
+    got = [m for m in msgs if m[0] == "root"][0][1]
+
+    sc = scenarios(big)
+    work = torch.cuda.Stream()
+    torch.cuda.set_stream(work)
+    dev.set_stream(work.cuda_stream)
+    try:
+        for name in names:
+            caps, kw = sc[name]
+            want = _single_gpu(dev, caps, kw)
+            _assert_identical(name, got[name], want)
+            n_parts = len(got[name]["parts"])
+            if name != "g2":
+                assert n_parts > len(caps), (name, got[name]["parts"])          # the captures really were cut
+                assert len({p[5] for p in got[name]["parts"]}) == world         # and every rank worked
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        dev.set_stream(None, external=False)
+
+    # against the golden vectors of the reference (tests/golden, made by the reference's own functions)
+    g1 = np.load(os.path.join(HERE, "golden", "g1_power.npz"))
+    np.testing.assert_allclose(got["g1"]["streams"][0]["power_map"], g1["power_map"], rtol=1e-6)
+    meta = json.load(open(os.path.join(HERE, "golden", "golden_meta.json")))
+    assert [s["onset"] for s in got["g4"]["streams"]] == meta["g4"]["onset"]
+    own = meta["g4"]["lags_own_start"]
+    assert got["g4"]["lags"] == [own["524288_01"], own["524288_02"], own["524288_12"]]
+    g2 = np.load(os.path.join(HERE, "golden", "g2_welch.npz"))
+    key = [k for k in g2.files if "4096" in k and "db" not in k.lower()]
+    from golden import golden_inputs as gi
+    lin, _, _ = orc.widmo_waterfall(gi.g2_stream(), nperseg=4096)
+    keep = lin > 1e-12
+    psd = got["g2"]["streams"][0]["psd"]
+    assert psd.shape == lin.shape and np.max(np.abs(psd[keep] - lin[keep]) / lin[keep]) < 1e-4, key
+    for a, raw in enumerate(gi.g3_streams()):
+        k, avg = orc.rssi_amp_stats(raw, 0.1)
+        s = got["g3"]["streams"][a]
+        assert s["amp_first"] == k and s["amp_count"] == raw.size // 2 - k
+        np.testing.assert_allclose(s["amp_mean"], avg, rtol=1e-6)

@@ -1,0 +1,66 @@
+"""Host logic of the capture split (gpsjam/split.py): the plan that cuts captures into parts."""
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(REPO, "gps-jamming_amd"), REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from gpsjam import split  # noqa: E402
+
+
+def test_unit_is_two_seconds_of_capture():
+    assert split.unit_bytes() == 8_192_000 == 125 * 65536 == 2 * 2 * 2048000
+    assert split.unit_bytes(65536, 32768) == 65536 and split.unit_bytes(131072, 131072) == 262144
+
+
+@pytest.mark.parametrize("sizes,world", [([1 << 30] * 3, 8), ([1 << 30], 8), ([1 << 30] * 3, 1), ([1 << 30] * 3, 2),
+                                          ([40_960_000] * 3, 8), ([1335411], 4), ([5_000_001, 9_999_999, 8_192_000], 5),
+                                          ([1 << 30] * 8, 8), ([100] * 3, 8)])
+def test_parts_tile_every_capture(sizes, world):
+    unit = split.unit_bytes()
+    parts = split.plan_parts(sizes, world, unit)
+    for a, total in enumerate(sizes):
+        mine = sorted((p for p in parts if p.antenna == a), key=lambda p: p.part)
+        assert [p.part for p in mine] == list(range(len(mine))) and all(p.parts == len(mine) for p in mine)
+        pos = 0
+        for p in mine:
+            assert p.first_byte == pos and p.first_byte % unit == 0 and p.own_bytes > 0 and p.total_bytes == total
+            if not p.is_last:
+                assert p.own_bytes % unit == 0
+            pos += p.own_bytes
+        assert pos == total
+        assert [p.rank for p in mine] == sorted(p.rank for p in mine)          # parts of a capture sit on rising ranks
+    for r in range(world):                                                       # local indices count up per rank
+        assert [p.local for p in parts if p.rank == r] == list(range(sum(p.rank == r for p in parts)))
+    # balance: no rank holds more than one unit above the mean
+    units = {r: sum(-(-p.own_bytes // unit) for p in parts if p.rank == r) for r in range(world)}
+    total_units = sum(max(1, -(-b // unit)) for b in sizes)
+    assert max(units.values()) <= -(-total_units // world)
+    assert sum(units.values()) == total_units
+
+
+def test_three_antennas_on_eight_gpus():
+    """The reference's deployment (worker.py:586-600: three files) on an 8-GPU node: every GPU works, no rank holds
+    more than two parts, 1/8 of the bytes each."""
+    parts = split.plan_parts([1 << 30] * 3, 8, split.unit_bytes())
+    assert {p.rank for p in parts} == set(range(8))
+    assert max(sum(p.rank == r for p in parts) for r in range(8)) == 2
+    share = [sum(p.own_bytes for p in parts if p.rank == r) for r in range(8)]
+    assert max(share) - min(share) <= 2 * split.unit_bytes()
+    assert sorted(len([p for p in parts if p.antenna == a]) for a in range(3)) == [3, 3, 4]
+
+
+def test_buffer_range_and_pairs():
+    parts = split.plan_parts([1 << 30] * 3, 8, split.unit_bytes())
+    for p in parts:
+        b0, b1 = split.buffer_range(p, 1000, 1 << 19)
+        assert b0 == (p.first_byte - 65536 if p.first_byte else 0) and b0 % 65536 == 0
+        assert b1 == min(p.total_bytes, p.first_byte + p.own_bytes + (1 << 20))
+    deal = split.deal_pairs(3, range(8))
+    assert sorted(x for v in deal.values() for x in v) == [(0, 1), (0, 2), (1, 2)] and max(len(v) for v in deal.values()) == 1
+    deal = split.deal_pairs(8, [0, 1, 2])
+    assert sorted(x for v in deal.values() for x in v) == [(i, j) for i in range(8) for j in range(i + 1, 8)]
