@@ -1147,6 +1147,8 @@ static int stream_scan_impl(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, siz
     const size_t noise_bytes = (size_t)2 * noise_samples;
     const bool noise_here = !part || (part->buf_sample0 == 0 && noise_bytes <= nbytes);
     const bool noise_fused = valid && noise_here && (noise_bytes % 16 == 0);
+    if (valid && !noise_here && !part->d_noise)
+        return fail(ctx, GJ_ERR_INVALID, "this part does not hold the capture's noise span (%zu bytes): d_noise is required", noise_bytes);
     // When the offset is a half-integer (off2 odd) no component of 2u - off2 is zero, so every amplitude is at
     // least sqrt(2) * half_scale (0.0055 for the default unpack): a threshold below that makes every sample a hit
     // and the first index needs no tracking.  With an integer offset (gj_set_unpack(128, ...)) amplitudes can be
@@ -1230,7 +1232,6 @@ int launch_part_scan(gj_ctx* ctx, const gj_part_view& v, size_t chunk_bytes, flo
         return fail(ctx, GJ_ERR_UNSUPPORTED, "only the capture's last part may end inside a chunk");
     if (v.own_first_byte != 0 && halo / 2 + 1 < (size_t)window)
         return fail(ctx, GJ_ERR_INVALID, "the halo must hold at least window - 1 samples");
-    if (v.buf_first_byte != 0 && !v.d_noise) return fail(ctx, GJ_ERR_INVALID, "d_noise is needed by every part but the first");
     ScanPart p;
     p.halo_bytes = halo;
     p.buf_sample0 = (long long)(v.buf_first_byte / 2);

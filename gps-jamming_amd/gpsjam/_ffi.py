@@ -164,6 +164,34 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  A PyTorch-ROCm wheel bundles its own libamdhip64.so / libhsa-runtime64.so (same
+    sonames as /opt/rocm's, which libgpsjam_hip.so is linked against).  If torch is imported FIRST the loader gives
+    this library torch's copy (soname match) and all is well; the other way round torch loads a second runtime by file
+    name and its device discovery fails ("no ROCm-capable device").  So when a torch with a bundled runtime is
+    installed, that runtime is loaded here -- without importing torch -- before the library is, whatever the import
+    order.  GPSJAM_SYSTEM_HIP=1 keeps /opt/rocm's (a process that never uses torch.cuda)."""
+    import importlib.util
+    import sys
+    if os.environ.get("GPSJAM_SYSTEM_HIP") == "1" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if not os.path.exists(path):
+            return
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            return
+
+
 def load():
     """Load (once) and return the ctypes handle with typed signatures."""
     global _lib
@@ -174,6 +202,7 @@ def load():
             f"{LIB_PATH} not found: build it with `make -C {os.path.dirname(LIB_PATH)}` "
             "(hipcc --offload-arch=gfx950) or `python -c 'import __graft_entry__ as g; g.build()'`. "
             "There is no CPU fallback.")
+    _share_torch_hip_runtime()
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:

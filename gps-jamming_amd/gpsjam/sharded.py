@@ -441,7 +441,6 @@ class AntennaStream:
         self._done = [torch.cuda.Event() for _ in range(2)] if capture.is_cuda else [None, None]
         self._idx = 0
         self.result = self._results[0]
-        self.cap16 = capture.view(torch.int16)
         # workspaces: K5 transforms at most the antennas this rank's pairs name
         ants = len({a for p in self.pairs for a in p}) or 1
         ws_side = max(dev.xcorr_workspace(ants, slice_samples, npairs), self.nbytes // 48 + (1 << 20))

@@ -123,8 +123,8 @@ class PartStream:
                  chunk_samples, nperseg, fs, slice_samples, noise_samples, window, factor, rssi_threshold):
         b0, b1 = buffer_range(part, window, slice_samples)
         assert buf.dtype == torch.uint8 and buf.is_contiguous() and buf.numel() == b1 - b0, (buf.numel(), b1 - b0)
-        if part.first_byte:
-            assert noise is not None and noise.numel() >= 2 * noise_samples
+        if part.first_byte or part.own_bytes < 2 * noise_samples:
+            assert noise is not None and noise.numel() >= min(2 * noise_samples, part.total_bytes)
         self.part, self.dev, self.dev_side, self.buf, self.noise = part, dev, dev_side, buf, noise
         self.chunk_bytes, self.chunk_samples, self.nperseg, self.fs = chunk_bytes, chunk_samples, nperseg, fs
         self.slice_samples, self.noise_samples, self.window, self.factor = slice_samples, noise_samples, window, factor
@@ -196,7 +196,10 @@ class SplitStreams:
         self.streams: List[PartStream] = []
         for p in self.mine:
             b0, b1 = buffer_range(p, window, slice_samples)
-            noise = make_noise(p.antenna, 2 * noise_samples) if p.first_byte else None
+            # K4's threshold needs the capture's first noise_samples samples: every part that does not hold them
+            # itself brings its own copy (a few hundred KB read by each rank -- no collective)
+            need_noise = p.first_byte or p.own_bytes < 2 * noise_samples
+            noise = make_noise(p.antenna, min(2 * noise_samples, p.total_bytes)) if need_noise else None
             self.streams.append(PartStream(dev, self.dev_side, p, make_buffer(p, b0, b1), noise, **kw))
         # capacities of a part vector: the largest part of the plan (every rank knows the whole plan)
         self.chunk_cap = max(dev.chunk_count(p.own_bytes, chunk_bytes) for p in self.parts)

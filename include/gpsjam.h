@@ -306,7 +306,8 @@ typedef struct gj_part_view {
     size_t own_first_byte; /* multiple of chunk_bytes and of 2*chunk_samples; own_first_byte - buf_first_byte = halo */
     size_t own_bytes;
     size_t total_bytes;    /* of the whole capture */
-    const uint8_t* d_noise; /* DEVICE: the capture's first 2*noise_samples bytes (may be NULL for the first part) */
+    const uint8_t* d_noise; /* DEVICE: the capture's first 2*noise_samples bytes (may be NULL for a first part
+                             * whose own range holds them) */
 } gj_part_view;
 typedef struct gj_amp_part {
     int64_t first_index; /* capture coordinates; -1: nothing above the threshold in this part */

@@ -81,9 +81,19 @@ def _worker(rank, world, port, names, big, q):
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    import datetime
     import torch
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # a rank that dies must end the others' collectives soon, not after gloo's 30 minutes
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    logdir = os.path.join(REPO, "gpurun_out")
+    log = open(os.path.join(logdir, f"split_w{world}_r{rank}.log"), "w") if os.path.isdir(logdir) else None
+
+    def note(msg):
+        if log:
+            log.write(msg + "\n")
+            log.flush()
+
     try:
         import gpsjam
         from gpsjam import split
@@ -97,6 +107,7 @@ def _worker(rank, world, port, names, big, q):
         out = {}
         for name in names:
             caps, kw = sc[name]
+            note(f"scenario {name}: start")
 
             def make_buffer(part, b0, b1, caps=caps):
                 return _device_range(dev, caps[part.antenna], b0, b1)
@@ -105,9 +116,12 @@ def _worker(rank, world, port, names, big, q):
                 return _device_range(dev, caps[antenna], 0, nbytes)
 
             st = split.SplitStreams(dev, [_nbytes(c) for c in caps], make_buffer, make_noise, rank=rank, world_size=world, **kw)
+            note(f"scenario {name}: {len(st.streams)} part(s) here: " + str([(p.antenna, p.part, p.first_byte, p.own_bytes) for p in st.mine]))
             got = None
-            for _ in range(3):                                  # several steps back to back: buffers alternate
+            for k in range(3):                                  # several steps back to back: buffers alternate
                 got = st.step()
+                torch.cuda.synchronize()
+                note(f"scenario {name}: step {k} done")
             if rank == 0:
                 res, td = got.unpack()
                 out[name] = _collect(res, td, [p.cpu().numpy().copy() for p in st.last_psd])
@@ -115,14 +129,40 @@ def _worker(rank, world, port, names, big, q):
             torch.cuda.synchronize()
             dist.barrier()
             st.close()
+            note(f"scenario {name}: closed")
         q.put(("root", out) if rank == 0 else ("other", rank))
         dev.close()
     except Exception as e:                                      # surface the failure in the parent
         import traceback
+        note("FAILED: " + repr(e) + "\n" + traceback.format_exc())
         q.put(("fail", rank, repr(e) + "\n" + traceback.format_exc()))
         raise
     finally:
         dist.destroy_process_group()
+
+
+def _collect_messages(q, procs, world, limit=300.0):
+    """One message per rank; a rank that reports a failure or dies without a word ends the wait at once (the others
+    are then stuck in a collective) instead of running into the suite's timeout."""
+    import queue
+    import time
+    msgs, t0 = [], time.monotonic()
+    while len(msgs) < world:
+        try:
+            msgs.append(q.get(timeout=2.0))
+        except queue.Empty:
+            pass
+        failed = [m for m in msgs if m[0] == "fail"]
+        dead = [p.pid for p in procs if p.exitcode not in (None, 0)]
+        if failed or (dead and len(msgs) < world) or time.monotonic() - t0 > limit:
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
+            for p in procs:
+                p.join(30)
+            raise AssertionError(f"ranks failed: {failed}; exit codes {[p.exitcode for p in procs]}; "
+                                 f"{len(msgs)} of {world} messages after {time.monotonic() - t0:.0f} s")
+    return msgs
 
 
 def _single_gpu(dev, caps, kw):
@@ -185,7 +225,7 @@ def test_split_is_bit_identical_to_the_single_gpu_run(world, dev):
     procs = [ctx.Process(target=_worker, args=(r, world, port, names, big, q)) for r in range(world)]
     for p in procs:
         p.start()
-    msgs = [q.get(timeout=800) for _ in range(world)]
+    msgs = _collect_messages(q, procs, world)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
