@@ -80,6 +80,11 @@ def main():
                     help="run the scan/TDOA kernels on the K2 stream instead of concurrently on a second one")
     ap.add_argument("--cpu-sample-chunks", type=int, default=None,
                     help="1-s chunks of the capture given to the CPU oracle (default 24 at N = 1, 8 per rank otherwise)")
+    ap.add_argument("--split", action="store_true",
+                    help="strong scaling (SURVEY 8(e)): --antennas captures of --capture-bytes each are cut into parts "
+                         "over the N GPUs (gpsjam.split) instead of one capture per GPU")
+    ap.add_argument("--antennas", type=int, default=3,
+                    help="captures in --split mode (the reference's deployment has three, worker.py:586-600)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="diagnostic: ranks only form the process group, all-reduce one number and print it")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
@@ -122,6 +127,13 @@ def main():
     work_stream = torch.cuda.Stream()
     torch.cuda.set_stream(work_stream)
     dev.set_stream(work_stream.cuda_stream)
+    if args.split:
+        run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        dev.close()
+        return
     nbytes = args.capture_bytes
     nsamp = nbytes // 2
     cap = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
@@ -326,6 +338,93 @@ def main():
         dist.destroy_process_group()
     stream.close()
     dev.close()
+
+
+def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
+    """--split: the SAME total work at every N (strong scaling) -- `antennas` captures laid end to end and cut into
+    N runs of 2-s units, one run per GPU (gpsjam.split): every GPU scans and transforms its run, one all-gather
+    carries the parts' TDOA slots, the antenna pairs are dealt over the ranks, one gather brings the part vectors to
+    rank 0, which rebuilds every capture's arrays and runs the tail kernels of a single-GPU stream.  Results are
+    bit-identical to the unsplit run (tests/test_split_gpu.py)."""
+    from gpsjam import split
+    from gpsjam.synth import StreamSpec
+    nbytes, A = args.capture_bytes, args.antennas
+    nsamp = nbytes // 2
+    specs = [stream_spec(StreamSpec, a, nsamp) for a in range(A)]
+
+    def make_buffer(part, b0, b1):
+        t = torch.zeros(b1 - b0, dtype=torch.uint8, device="cuda")
+        dev.synth_dev(specs[part.antenna], (b1 - b0) // 2, t, first_sample=b0 // 2)
+        return t
+
+    def make_noise(antenna, n):
+        t = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        dev.synth_dev(specs[antenna], n // 2, t, first_sample=0)
+        return t
+
+    st = split.SplitStreams(dev, [nbytes] * A, make_buffer, make_noise, rank=rank, world_size=world, nperseg=NPERSEG,
+                            chunk_samples=CHUNK_SAMPLES, slice_samples=SLICE, overlap=not args.no_overlap)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.precondition + args.warmup):
+        st.step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    got = None
+    for k in range(args.steps):
+        st.stream_scan()
+        ev[k][0].record()
+        st.welch()
+        ev[k][1].record()
+        st.tdoa()
+        got = st.exchange(0)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    welch_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+    own = sum(p.own_bytes for p in st.mine)
+    if rank == 0:
+        results, tdoa = got.unpack()
+        onsets = [r.onset for r in results]
+        total_samples = float(nsamp) * A * args.steps
+        achieved = (own / 1e9) / (welch_ms / 1e3) if welch_ms > 0 else 0.0
+        line = {
+            "metric": "Msamples/s uint8 I/Q through PSD+TDOA xcorr", "value": total_samples / elapsed / 1e6,
+            "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "precondition_steps": args.precondition, "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{A} antenna captures of {nbytes} bytes each (the reference's deployment: three files, "
+                                   "worker.py:586-600) through K1-K5, cut into contiguous runs of 8 192 000-byte units over "
+                                   f"{world} GPU(s) (SURVEY 8(e)); all {len(tdoa.pairs)} pairs solved; total work is the same at every N",
+                       "capture_bytes": nbytes, "antennas": A, "nperseg": NPERSEG, "chunk_samples": CHUNK_SAMPLES,
+                       "xcorr_slice": SLICE, "sharding": "captures split into parts (gpsjam.split)",
+                       "parts": [[p.antenna, p.part, p.parts, p.first_byte, p.own_bytes, p.rank] for p in st.parts],
+                       "backend": args.backend if world > 1 else None},
+            "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
+            "roofline": {"bound": "hbm", "kernel": "welch_kernel<4096> + welch_finalize_kernel over rank 0's parts",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_launch": own, "avg_launch_ms": welch_ms,
+                         "overlap": bool(st.overlap),
+                         "note": "K2 over the bytes rank 0 owns, as run beside the scan / TDOA kernels (DESIGN.md section 5)"},
+            "results": {"pairs": [list(p) for p in tdoa.pairs], "lags": tdoa.lags, "onsets": onsets,
+                        "amp_mean": [r.amp_mean for r in results], "baseline": [r.baseline for r in results]},
+            "self_check": self_check(results, tdoa, onsets, nsamp, A),
+            "host": host_info(),
+        }
+        print(json.dumps(line), flush=True)
+    st.close()
 
 
 def launch_ranks(n, argv, limit_s):

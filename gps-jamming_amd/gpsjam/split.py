@@ -263,16 +263,23 @@ class SplitStreams:
         return torch.cuda.stream(self._side) if self.overlap else contextlib.nullcontext()
 
     # ---------------------------------------------------------------- the step
-    def scan(self):
-        """K1 + K3 + K4 of every part of this rank (side stream), K2 of every part (main stream)."""
+    def stream_scan(self):
+        """K1 + K3 + K4 of every part of this rank, one fused pass each (side stream)."""
         if self.overlap:
             self._side.wait_event(self._ev_free)
         for s in self.streams:
             s.scan()
         if self.overlap:
             self._ev_side.record(self._side)
+
+    def welch(self):
+        """K2 of every part of this rank (main stream)."""
         for s in self.streams:
             s.welch()
+
+    def scan(self):
+        self.stream_scan()
+        self.welch()
 
     def tdoa(self):
         """Slots of this rank's parts -> ONE all-gather -> one slot per antenna -> this rank's pairs."""

@@ -67,3 +67,19 @@ def test_self_launch_two_ranks_share_gpu():
     assert line["self_check"]["passed"] is True, line["self_check"]
     assert line["self_check"]["pairs_checked"] == 1 and line["self_check"]["streams_checked"] == 2
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_split_bench_two_ranks_share_gpu():
+    """`python bench.py --gpus 2 --split`: three captures cut over two ranks (sharing cuda:0, gloo), strong scaling
+    line, self_check passed (known delays and burst spans come back through the split + combine)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--split", "--backend", "gloo", "--share-gpu", "--steps", "3",
+                        "--warmup", "1", "--precondition", "2", "--capture-bytes", str(1 << 28)],
+                       capture_output=True, text=True, env=_env(), timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["antennas"] == 3
+    assert line["self_check"]["passed"] is True, line["self_check"]
+    assert line["self_check"]["pairs_checked"] == 3 and line["self_check"]["streams_checked"] == 3
+    assert len({p[5] for p in line["config"]["parts"]}) == 2

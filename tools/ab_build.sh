@@ -8,7 +8,7 @@ mkdir -p ../../build_ab
 make -s -j8
 SRC=${3:-k_welch.hip}
 OBJS=""
-for o in api.o k_scan.o k_welch.o k_xcorr.o k_synth.o k_acq.o comm.o; do
+for o in api.o host_io.o k_scan.o k_welch.o k_xcorr.o k_synth.o k_acq.o comm.o; do
   if [ "$o" = "${SRC%.hip}.o" ]; then OBJS="$OBJS /tmp/ab_$1.o"; else OBJS="$OBJS $o"; fi
 done
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -I. $2 -c $SRC -o /tmp/ab_$1.o

@@ -52,36 +52,41 @@
 #ifndef GJ_W_HALFSUM
 #define GJ_W_HALFSUM 1   // 1: (one transform per workgroup) half-segment sums carried from step to step
 #endif
-#ifndef GJ_W_CARRY
-// 1: (one transform per workgroup, i.e. N = 4096) the unpacked second half of a segment is CARRIED in registers as
-// the first half of the next one (50 % overlap), and the periodic Hann window's symmetry w[n + N/2] = 1 - w[n]
-// halves the window registers that pays for it: per step 16 conversions, 8 offset FMAs and 8 loads fewer
-// (72 -> 48 front-end instructions per thread), same VGPR count.
-#define GJ_W_CARRY 1
-#endif
 #ifndef GJ_W_XPOSE
 #define GJ_W_XPOSE 1     // 1: N = 4096 uses the bank-conflict-free exchange schedule (fft_core.h X4096)
 #endif
+#ifndef GJ_W_PRIO
+// s_setprio level of K2's waves (0 = the hardware default).  The SIMD's instruction arbiter serves the
+// higher-priority wave first: K2 is bound by VALU issue, and the waves of the HBM-bound scan that the pipeline
+// runs beside it on the second stream otherwise take issue slots away from it one for one.
+#define GJ_W_PRIO 0
+#endif
+#ifndef GJ_W_RAWREUSE
+// 1: (one transform per workgroup) the raw samples of a segment's second half are kept as the next segment's first
+// half -- eight register moves instead of eight of the sixteen 2-byte loads per step
+#define GJ_W_RAWREUSE 0
+#endif
+#ifndef GJ_W_SCANSUMS
+// feasibility prototype (timing only, tools/ab_build.sh): per step also sum |z|^2 and |z| over the NEW half segment
+// (what K1 / K3 / K4 need), reduce per wave and store -- "K2 as the one reader of the capture", DESIGN section 4
+#define GJ_W_SCANSUMS 0
+#endif
+#define GJ_LOAD_RAW(x) (x)
+// GJ_STAMPS (diagnostic builds only, tools/ab_build.sh): s_memtime stamps around the phases of
+// a step, summed per wave and added to g_welch_stamps; read with gj_debug_welch_stamps().
+#ifdef GJ_STAMPS
+#define GJ_STAMP(var)                                                                        \
+    unsigned long long var;                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");              \
+    __builtin_amdgcn_sched_barrier(0)
+#define GJ_STAMP_ADD(slot, a, b) stamps[slot] += (b) - (a)
+#else
+#define GJ_STAMP(var)
+#define GJ_STAMP_ADD(slot, a, b)
+#endif
 
 namespace gj {
-
-// 2 f + k  (k wave-uniform, in SGPRs): the unpack (2u - off2) of two components at once
-__device__ __forceinline__ c2 twice_plus_k(c2 f, c2 k) {
-    c2 r;
-    asm("v_pk_fma_f32 %0, %1, 2.0, %2" : "=v"(r) : "v"(f), "s"(k));
-    return r;
-}
-// a - a * p.x  /  a - a * p.y : the second-half window 1 - w applied without forming it
-__device__ __forceinline__ c2 one_minus_lo(c2 a, c2 p) {
-    c2 r;
-    asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(p));
-    return r;
-}
-__device__ __forceinline__ c2 one_minus_hi(c2 a, c2 p) {
-    c2 r;
-    asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(p));
-    return r;
-}
 
 constexpr int welch_log2(int n) { return n <= 1 ? 0 : 1 + welch_log2(n / 2); }
 constexpr bool welch_occ3(int n) { return ((GJ_W_OCC3_MASK >> welch_log2(n)) & 1u) != 0; }
@@ -93,6 +98,10 @@ struct WelchCfg {
     static constexpr bool dbuf = (GJ_W_DBUF != 0) && !occ3;     // two LDS exchange buffers
     static constexpr bool win16 = occ3;                         // window as 16 floats instead of 16 pairs
 };
+
+#ifdef GJ_STAMPS
+__device__ unsigned long long g_welch_stamps[8];
+#endif
 
 struct WelchGeom {
     float neg_off;        // -offset of the unpack convention (default -127.5)
@@ -116,41 +125,66 @@ struct WelchBins {   // (thread, slot) that ends up holding bin k
 // exchange (between scatter and gather) is enough.
 template <int N, int PASS>
 __device__ __forceinline__ void welch_passes(c2 (&v)[16], cf* lds0, cf* lds1, unsigned it, int base, int jl,
-                                             const c2 (&tw)[3][15], const InnerTw& ktw) {
+                                             const c2 (&tw)[3][15], const InnerTw& ktw,
+                                             unsigned long long (&stamps)[8]) {
     constexpr int NP = fft_npass(N);
+    GJ_STAMP(t0);
     fft_pass<N, PASS, GJ_W_TWOSTEP != 0, GJ_W_FMA != 0>(v, tw[PASS], ktw);
+    GJ_STAMP(t1);
+    GJ_STAMP_ADD(0, t0, t1);   // butterflies
     if constexpr (PASS + 1 < NP) {
         // exchanges per segment: NP-1.  Even count -> parity of PASS; odd count -> parity of (it + PASS)
         const bool second = ((NP - 1) % 2 == 0) ? (PASS & 1) : ((it + PASS) & 1);
         cf* lds = (WelchCfg<N>::dbuf && second) ? lds1 : lds0;
         lds_scatter<N, PASS>(v, lds, base, jl);
+        GJ_STAMP(t2);
+        GJ_STAMP_ADD(1, t1, t2);   // scatter issued and landed (the stamp waits lgkmcnt(0))
         __syncthreads();
+        GJ_STAMP(t3);
+        GJ_STAMP_ADD(2, t2, t3);   // barrier wait
         lds_gather<N>(v, lds, base, jl);
+        GJ_STAMP(t4);
+        GJ_STAMP_ADD(3, t3, t4);   // gather
         if (!WelchCfg<N>::dbuf) __syncthreads();
-        welch_passes<N, PASS + 1>(v, lds0, lds1, it, base, jl, tw, ktw);
+        welch_passes<N, PASS + 1>(v, lds0, lds1, it, base, jl, tw, ktw, stamps);
     }
 }
 
 // N = 4096 with the conflict-free exchange schedule of fft_core.h (X4096): pass 0 in role
 // jl0 = tid, passes 1 and 2 in role jl1; buffer 0 carries exchange 0, buffer 1 exchange 1.
-// `after_scatter0()` runs where the fewest registers are live (the points are in LDS, the next pass has not
-// gathered them yet): the caller issues its prefetch loads there.
-template <typename Mid>
 __device__ __forceinline__ void welch_passes_x4096(c2 (&v)[16], cf* lds0, cf* lds1, int tid, const c2 (&tw)[3][15],
-                                                   const InnerTw& ktw, Mid&& after_scatter0) {
+                                                   const InnerTw& ktw, unsigned long long (&stamps)[8]) {
+    GJ_STAMP(t0);
     fft_pass<4096, 0, false, GJ_W_FMA != 0>(v, tw[0], ktw);
+    GJ_STAMP(t1);
+    GJ_STAMP_ADD(0, t0, t1);
     x4096_scatter<0>(v, lds0, tid);
-    after_scatter0();
+    GJ_STAMP(t2);
+    GJ_STAMP_ADD(1, t1, t2);
     __syncthreads();
+    GJ_STAMP(t3);
+    GJ_STAMP_ADD(2, t2, t3);
     x4096_gather<0>(v, lds0, tid);
     if (!WelchCfg<4096>::dbuf) __syncthreads();
+    GJ_STAMP(t4);
+    GJ_STAMP_ADD(3, t3, t4);
     fft_pass<4096, 1, GJ_W_TWOSTEP != 0, GJ_W_FMA != 0>(v, tw[1], ktw);
+    GJ_STAMP(t5);
+    GJ_STAMP_ADD(0, t4, t5);
     cf* ldsx = WelchCfg<4096>::dbuf ? lds1 : lds0;
     x4096_scatter<1>(v, ldsx, tid);
+    GJ_STAMP(t6);
+    GJ_STAMP_ADD(1, t5, t6);
     __syncthreads();
+    GJ_STAMP(t7);
+    GJ_STAMP_ADD(2, t6, t7);
     x4096_gather<1>(v, ldsx, tid);
     if (!WelchCfg<4096>::dbuf) __syncthreads();
+    GJ_STAMP(t8);
+    GJ_STAMP_ADD(3, t7, t8);
     fft_pass<4096, 2, GJ_W_TWOSTEP != 0, GJ_W_FMA != 0>(v, tw[2], ktw);
+    GJ_STAMP(t9);
+    GJ_STAMP_ADD(0, t8, t9);
 }
 
 template <int N>
@@ -168,6 +202,7 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
     __shared__ cf lds1[Cfg::dbuf ? SPAN : 1];
     // (sum I, sum Q) per wave; three slots when half-segment sums are carried over (see HS below)
     __shared__ float wsum[3][B][WPF][2];
+    if constexpr (GJ_W_PRIO != 0) __builtin_amdgcn_s_setprio(GJ_W_PRIO);
     const int tid = threadIdx.x;
     const int b = tid / TF, jl0 = tid % TF;   // jl0: butterfly of pass 0 (input index jl0 + TF s)
     const int jl = XP ? X4096::jl1(tid) : jl0;   // butterfly of the later passes = bins held at the end
@@ -191,21 +226,16 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
         else load_twiddles<N, 2>(tw[2], twtab, jl);
     }
 
-    // CARRY (one transform per workgroup = consecutive segments, N = 4096): see GJ_W_CARRY above
-    constexpr bool CARRY = HS && Cfg::win16 && (GJ_W_CARRY != 0) && (GJ_W_PREFETCH != 0);
     // window folded into the unpack: w (2u - 255) = u (2w) + (-255 w); (w[2i], w[2i+1]) share a
-    // VGPR pair and op_sel picks the half, so 16 points cost 16 register pairs.
-    // CARRY: w[n + N/2] = 1 - w[n] (periodic Hann), so the eight values of the first half do for both.
-    constexpr int NW = CARRY ? 4 : 8;
-    c2 w2p[NW], wcp[Cfg::win16 ? 1 : 8];
+    // VGPR pair and op_sel picks the half, so 16 points cost 16 register pairs
+    c2 w2p[8], wcp[Cfg::win16 ? 1 : 8];
 #pragma unroll
-    for (int s = 0; s < NW; ++s) {
+    for (int s = 0; s < 8; ++s) {
         const float wa = wintab[jl0 + TF * (2 * s)], wb = wintab[jl0 + TF * (2 * s + 1)];
-        w2p[s] = CARRY ? make_c2(wa, wb) : make_c2(2.0f * wa, 2.0f * wb);
+        w2p[s] = make_c2(2.0f * wa, 2.0f * wb);
         if constexpr (!Cfg::win16) wcp[s] = make_c2(-g.off2 * wa, -g.off2 * wb);
     }
     [[maybe_unused]] const c2 khalf = make_c2(g.neg_off, g.neg_off);
-    [[maybe_unused]] const c2 kmoff = make_c2(-g.off2, -g.off2);
     c2 accp[Cfg::pkacc ? 16 : 1];      // (sum re^2, sum im^2): one packed FMA per bin and step
     float accs[Cfg::pkacc ? 1 : 16];   // or scalar sums (two FMAs per bin and step, 16 VGPRs fewer)
 #pragma unroll
@@ -221,85 +251,71 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
         const unsigned byte0 = (seg_idx * (unsigned)(N / 2) + (unsigned)jl0) * 2u;
 #pragma unroll
         for (int s = 0; s < 16; ++s)
-            dst[s] = (*reinterpret_cast<const uint16_t*>(chunk8 + (byte0 + 2u * TF * s)));
-    };
-    // samples s0 .. s0+7 of segment seg_idx (one half segment)
-    auto load_half = [&](unsigned (&dst)[8], unsigned seg_idx, int s0) {
-        const unsigned byte0 = (seg_idx * (unsigned)(N / 2) + (unsigned)jl0) * 2u;
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-            dst[s] = (*reinterpret_cast<const uint16_t*>(chunk8 + (byte0 + 2u * TF * (s0 + s))));
+            dst[s] = GJ_LOAD_RAW(*reinterpret_cast<const uint16_t*>(chunk8 + (byte0 + 2u * TF * s)));
     };
     const unsigned nsteps = (seg_hi - seg_lo + B - 1) / B;
     // raw samples of the NEXT step are fetched while the current one is transformed
-    unsigned raw[CARRY ? 1 : 16];
-    unsigned rawh[CARRY ? 8 : 1];      // CARRY: only the new half segment is ever loaded
-    c2 carry[CARRY ? 8 : 1];           // CARRY: 2u - off2 of the previous step's second half = this step's first half
+    unsigned raw[16];
+    load_step(raw, (seg_lo + b < seg_hi) ? seg_lo + b : seg_lo);
+    unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     [[maybe_unused]] unsigned ws_cur = 0, ws_prv = 2;   // HS: slot of this step's half-sum / of the previous step's
-    if constexpr (CARRY) {
-        // first step of the workgroup: the first half has no predecessor -- unpack it here, once
-        load_half(rawh, seg_lo, 0);
-        c2 flo = make_c2(0.f, 0.f);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const c2 f = make_c2((float)(rawh[s] & 255u), (float)((rawh[s] >> 8) & 255u));
-            flo = cadd(flo, f);
-            carry[s] = twice_plus_k(f, kmoff);
-        }
-        const float li = group_sum_dpp_f<64>(flo.x), lq = group_sum_dpp_f<64>(flo.y);
-        if ((tid & 63) == 0) {
-            wsum[ws_prv][b][(tid >> 6) % WPF][0] = li;
-            wsum[ws_prv][b][(tid >> 6) % WPF][1] = lq;
-        }
-        load_half(rawh, seg_lo, 8);
-    } else {
-        load_step(raw, (seg_lo + b < seg_hi) ? seg_lo + b : seg_lo);
-    }
+    GJ_STAMP(t_begin);
     for (unsigned it = 0; it < nsteps; ++it) {
+        GJ_STAMP(t_it0);
         const unsigned seg = seg_lo + it * B + b;
         const bool active = seg < seg_hi;
         c2 v[16];
-        c2 fsum = make_c2(0.f, 0.f);   // (sum I, sum Q) of the raw bytes: integers < 2^24, exact in f32
+        if (!GJ_W_PREFETCH && it > 0) load_step(raw, active ? seg : seg_lo);
         // HS (one transform per workgroup = consecutive segments per step): the first half of a
         // segment is the second half of the previous one, so only the second half is summed each
         // step and the previous step's half-sum is read back from its slot (eight packed adds less)
         const unsigned cur = HS ? ws_cur : (it & 1), prv = HS ? ws_prv : 0;
-        if constexpr (CARRY) {
+        if (HS && it == 0) {   // first step of the workgroup: the first half has no predecessor
+            c2 flo = make_c2(0.f, 0.f);
 #pragma unroll
-            for (int s = 0; s < 8; ++s)   // first half: carried, already 2u - off2
-                v[s] = (s & 1) ? scale_hi(carry[s], w2p[s >> 1]) : scale_lo(carry[s], w2p[s >> 1]);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {   // second half: unpack, keep for the next step, window 1 - w
-                const unsigned u = rawh[s];
-                const c2 f = make_c2((float)(u & 255u), (float)((u >> 8) & 255u));
-                fsum = cadd(fsum, f);
-                const c2 u2 = twice_plus_k(f, kmoff);
-                carry[s] = u2;
-                v[8 + s] = (s & 1) ? one_minus_hi(u2, w2p[s >> 1]) : one_minus_lo(u2, w2p[s >> 1]);
+            for (int s = 0; s < 8; ++s) flo = cadd(flo, make_c2((float)(raw[s] & 255u), (float)((raw[s] >> 8) & 255u)));
+            const float li = group_sum_dpp_f<64>(flo.x), lq = group_sum_dpp_f<64>(flo.y);
+            if ((tid & 63) == 0) {
+                wsum[prv][b][(tid >> 6) % WPF][0] = li;
+                wsum[prv][b][(tid >> 6) % WPF][1] = lq;
             }
-        } else {
-            if (!GJ_W_PREFETCH && it > 0) load_step(raw, active ? seg : seg_lo);
-            if (HS && it == 0) {   // first step of the workgroup: the first half has no predecessor
-                c2 flo = make_c2(0.f, 0.f);
+        }
+        c2 fsum = make_c2(0.f, 0.f);   // (sum I, sum Q) of the raw bytes: integers < 2^24, exact in f32
+        [[maybe_unused]] float scan_m = 0.f, scan_a = 0.f;
 #pragma unroll
-                for (int s = 0; s < 8; ++s) flo = cadd(flo, make_c2((float)(raw[s] & 255u), (float)((raw[s] >> 8) & 255u)));
-                const float li = group_sum_dpp_f<64>(flo.x), lq = group_sum_dpp_f<64>(flo.y);
-                if ((tid & 63) == 0) {
-                    wsum[prv][b][(tid >> 6) % WPF][0] = li;
-                    wsum[prv][b][(tid >> 6) % WPF][1] = lq;
+        for (int s = 0; s < 16; ++s) {
+            const unsigned u = raw[s];
+            const c2 f = make_c2((float)(u & 255u), (float)((u >> 8) & 255u));
+            if constexpr (GJ_W_SCANSUMS != 0 && HS) {
+                if (s >= 8) {
+                    const c2 t = cadd(f, khalf);
+                    const float r2 = fmaf(t.x, t.x, t.y * t.y);   // |z|^2, exact
+                    scan_m += r2;
+                    scan_a += __fsqrt_rn(r2);
                 }
             }
+            if constexpr (Cfg::win16)   // w (2u - 255) = (u - 127.5) (2w)
+                v[s] = (s & 1) ? scale_hi(cadd(f, khalf), w2p[s >> 1]) : scale_lo(cadd(f, khalf), w2p[s >> 1]);
+            else
+                v[s] = (s & 1) ? fma_hi(f, w2p[s >> 1], wcp[s >> 1]) : fma_lo(f, w2p[s >> 1], wcp[s >> 1]);
+            if (!HS || s >= 8) fsum = cadd(fsum, f);
+        }
+        if constexpr (GJ_W_PREFETCH && GJ_W_RAWREUSE && HS) {
+            const unsigned nseg_idx = (seg + B < seg_hi) ? seg + B : seg_lo;
+            const bool consecutive = seg + B < seg_hi;
+            const unsigned byte0 = (nseg_idx * (unsigned)(N / 2) + (unsigned)jl0) * 2u;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const unsigned u = raw[s];
-                const c2 f = make_c2((float)(u & 255u), (float)((u >> 8) & 255u));
-                if constexpr (Cfg::win16)   // w (2u - 255) = (u - 127.5) (2w)
-                    v[s] = (s & 1) ? scale_hi(cadd(f, khalf), w2p[s >> 1]) : scale_lo(cadd(f, khalf), w2p[s >> 1]);
-                else
-                    v[s] = (s & 1) ? fma_hi(f, w2p[s >> 1], wcp[s >> 1]) : fma_lo(f, w2p[s >> 1], wcp[s >> 1]);
-                if (!HS || s >= 8) fsum = cadd(fsum, f);
+            for (int s = 0; s < 8; ++s) raw[s] = raw[s + 8];
+            if (!consecutive) {   // wrap to the dummy segment: its first half must be loaded after all (values unused)
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                    raw[s] = GJ_LOAD_RAW(*reinterpret_cast<const uint16_t*>(chunk8 + (byte0 + 2u * TF * s)));
             }
-            if (GJ_W_PREFETCH) load_step(raw, (seg + B < seg_hi) ? seg + B : seg_lo);
+#pragma unroll
+            for (int s = 8; s < 16; ++s)
+                raw[s] = GJ_LOAD_RAW(*reinterpret_cast<const uint16_t*>(chunk8 + (byte0 + 2u * TF * s)));
+        } else if (GJ_W_PREFETCH) {
+            load_step(raw, (seg + B < seg_hi) ? seg + B : seg_lo);
         }
         float si, sq;
         if constexpr (TF >= 64) {
@@ -314,13 +330,20 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
             sq = group_sum_dpp_f<TF>(fsum.y);
         }
 
-        if constexpr (XP)
-            welch_passes_x4096(v, lds0, lds1, tid, tw, ktw, [&] {
-                // CARRY: the next step's new half, asked for while this step's points sit in LDS (about two thirds
-                // of a step = 2 us ahead of their use)
-                if constexpr (CARRY) load_half(rawh, (seg + 1 < seg_hi) ? seg + 1 : seg_lo, 8);
-            });
-        else welch_passes<N, 0>(v, lds0, lds1, it, b * lds_span(N), jl, tw, ktw);
+        if constexpr (GJ_W_SCANSUMS != 0 && HS) {
+            const int mi = group_sum_dpp<64>((int)(4.0f * scan_m));
+            const float ai = group_sum_dpp_f<64>(scan_a);
+            if ((tid & 63) == 0) {
+                float* dst = partial + (size_t)gridDim.x * N + ((size_t)blockIdx.x * 64 + (it & 63)) * 8 + (tid >> 6) * 2;
+                dst[0] = __int_as_float(mi);
+                dst[1] = ai;
+            }
+        }
+        GJ_STAMP(t_it1);
+        GJ_STAMP_ADD(4, t_it0, t_it1);   // unpack + window + sums (+ waiting for the prefetched loads)
+        if constexpr (XP) welch_passes_x4096(v, lds0, lds1, tid, tw, ktw, stamps);
+        else welch_passes<N, 0>(v, lds0, lds1, it, b * lds_span(N), jl, tw, ktw, stamps);
+        GJ_STAMP(t_it2);
 
         // detrend in the frequency domain on bins 0, 1, N-1
         if constexpr (TF >= 64) {
@@ -354,8 +377,19 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
                 else accs[s] = fmaf(v[s].x, v[s].x, fmaf(v[s].y, v[s].y, accs[s]));
             }
         }
+        GJ_STAMP(t_it3);
+        GJ_STAMP_ADD(5, t_it2, t_it3);   // detrend fix + |X|^2
         if constexpr (HS) { ws_prv = ws_cur; ws_cur = (ws_cur == 2) ? 0 : ws_cur + 1; }
     }
+#ifdef GJ_STAMPS
+    {
+        GJ_STAMP(t_end);
+        stamps[6] = t_end - t_begin;
+        stamps[7] = nsteps;
+        if ((tid & 63) == 0)
+            for (int k = 0; k < 8; ++k) atomicAdd(&g_welch_stamps[k], stamps[k]);
+    }
+#endif
     float* out = partial + ((size_t)blockIdx.x * B + b) * N + jl;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -414,11 +448,7 @@ struct WelchPlan {
     double scale_full, scale_last;
 };
 
-// plan_bytes (a part of a split capture): the workgroups-per-chunk split is chosen as for a capture of plan_bytes,
-// so that a chunk's partial spectra -- and with them the float sum behind its PSD row -- are cut the same way
-// whether the chunk is processed as part of the whole capture or as part of a piece of it.
-static bool welch_plan(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int nperseg, double fs, WelchPlan& pl,
-                       size_t plan_bytes = 0) {
+static bool welch_plan(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int nperseg, double fs, WelchPlan& pl) {
     if (nperseg < 16 || nperseg > 4096 || (nperseg & (nperseg - 1))) return false;
     if (chunk_samples < (size_t)nperseg) return false;
     // the kernel addresses a chunk with 32-bit byte offsets from a 64-bit chunk base
@@ -447,16 +477,15 @@ static bool welch_plan(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int npe
     if (cap > 256) cap = 256;
     size_t want = 1;
     double best = 1e300;
-    const size_t plan_rows = plan_bytes ? gj_welch_rows(plan_bytes, chunk_samples, nperseg) : pl.rows;
     for (size_t sp = 1; sp <= cap; ++sp) {
-        const size_t wgs = (plan_rows ? plan_rows : 1) * sp;
+        const size_t wgs = (pl.rows ? pl.rows : 1) * sp;
         const double rounds = (double)((wgs + slots - 1) / slots);
         const double steps = (double)pl.g.nseg_full / (double)(sp * pl.batch) + 1.5;   // 1.5: twiddle/window set-up
         const double cost = rounds * steps;
         if (cost < best * 0.999) { best = cost; want = sp; }
     }
     pl.g.splits = (unsigned)want;
-    pl.ws_bytes = pl.rows * want * (size_t)kBlockPoints * sizeof(float);
+    pl.ws_bytes = pl.rows * want * (size_t)kBlockPoints * sizeof(float) + (GJ_W_SCANSUMS ? pl.rows * want * 64 * 8 * sizeof(float) : 0);
     const double sw2 = 0.375 * nperseg;   // sum of the squared periodic Hann window
     const double norm2 = unpack_norm2(ctx);   // the kernel works on 2u - off2 = sample * (2 / scale): 65025 by default
     pl.scale_full = 1.0 / (fs * sw2 * norm2 * (double)pl.g.nseg_full);
@@ -464,9 +493,20 @@ static bool welch_plan(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int npe
     return true;
 }
 
-size_t welch_workspace(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int nperseg, size_t plan_bytes) {
+#ifdef GJ_STAMPS
+extern "C" int gj_debug_welch_stamps(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_welch_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_welch_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
+size_t welch_workspace(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int nperseg) {
     WelchPlan pl;
-    if (!welch_plan(ctx, nbytes, chunk_samples, nperseg, 1.0, pl, plan_bytes)) return 0;
+    if (!welch_plan(ctx, nbytes, chunk_samples, nperseg, 1.0, pl)) return 0;
     return pl.ws_bytes;
 }
 
@@ -479,10 +519,10 @@ static void welch_launch(gj_ctx* ctx, const uint8_t* d_iq, const WelchPlan& pl, 
 }
 
 int launch_welch(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_samples, int nperseg, double fs,
-                 int flags, float* d_psd, float* d_psd_db, size_t plan_bytes) {
+                 int flags, float* d_psd, float* d_psd_db) {
     WelchPlan pl;
     if (!(fs > 0.0)) return fail(ctx, GJ_ERR_INVALID, "fs must be > 0");
-    if (!welch_plan(ctx, nbytes, chunk_samples, nperseg, fs, pl, plan_bytes))
+    if (!welch_plan(ctx, nbytes, chunk_samples, nperseg, fs, pl))
         return fail(ctx, GJ_ERR_UNSUPPORTED, "nperseg must be a power of two in [16, 4096] and <= chunk_samples, chunk_samples < 2^31 - nperseg");
     if ((reinterpret_cast<uintptr_t>(d_iq) & 1) != 0) return fail(ctx, GJ_ERR_INVALID, "capture must be 2-byte aligned");
     if (pl.rows == 0) return GJ_OK;
