@@ -637,6 +637,7 @@ def end_to_end(np, dev, cap, nbytes):
     out = {}
 
     def run(source):
+        """upload, then the four calls (round 2's order)"""
         t0 = time.perf_counter()
         c = dev.capture(source)
         t1 = time.perf_counter()
@@ -647,26 +648,53 @@ def end_to_end(np, dev, cap, nbytes):
         t2 = time.perf_counter()
         c.free()
         assert pm.size and psd.size and st.count and on.start_index
-        return t1 - t0, t2 - t0
+        return t1 - t0, t2 - t0, (pm, psd, st, on)
+
+    def run_overlapped(source):
+        """gj_ingest_*: the fused scan and K2 run on the pieces that have landed while the rest uploads"""
+        t0 = time.perf_counter()
+        c = dev.ingest(source, rssi_threshold=0.0, welch=(CHUNK_SAMPLES, NPERSEG), want_db=False)
+        pm = dev.chunk_power(c)
+        psd, _ = dev.welch(c, chunk_samples=CHUNK_SAMPLES, nperseg=NPERSEG, want_db=False)
+        st = dev.amp_stats(c, 0.0)
+        on = dev.onset(c)
+        t2 = time.perf_counter()
+        up_ms = c.ingest_ms[0]
+        c.free()
+        return up_ms / 1e3, t2 - t0, (pm, psd, st, on)
+
+    def same(a, b):
+        return bool(np.array_equal(a[0], b[0]) and a[1].tobytes() == b[1].tobytes() and a[2].sum == b[2].sum
+                    and a[2].first_index == b[2].first_index and bytes(a[3]) == bytes(b[3]))
 
     run(host[:min(nbytes, 1 << 28)])                        # every fill thread's pinned buffers allocated, code paths warm
-    up, tot = run(host)
+    run_overlapped(host[:min(nbytes, 1 << 28)])
+    up, tot, ref = run(host)
+    out["host_buffer_upload_then_run"] = {"upload_ms": up * 1e3, "total_ms": tot * 1e3, "upload_GBps": nbytes / up / 1e9,
+                                          "msamples_per_s": nbytes / 2 / tot / 1e6}
+    up, tot, got = run_overlapped(host)
     out["host_buffer"] = {"upload_ms": up * 1e3, "total_ms": tot * 1e3, "upload_GBps": nbytes / up / 1e9,
-                          "msamples_per_s": nbytes / 2 / tot / 1e6}
+                          "msamples_per_s": nbytes / 2 / tot / 1e6, "overlapped": True,
+                          "identical_to_upload_then_run": same(got, ref)}
     d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
     path = os.path.join(d, f"gpsjam_bench_{os.getpid()}.bin")
     try:
         host.tofile(path)
-        up, tot = run(path)
+        up, tot, _ = run(path)
+        out["file_upload_then_run"] = {"upload_ms": up * 1e3, "total_ms": tot * 1e3, "upload_GBps": nbytes / up / 1e9,
+                                       "msamples_per_s": nbytes / 2 / tot / 1e6}
+        up, tot, got = run_overlapped(path)
         out["file"] = {"upload_ms": up * 1e3, "total_ms": tot * 1e3, "upload_GBps": nbytes / up / 1e9,
-                       "msamples_per_s": nbytes / 2 / tot / 1e6, "where": d + " (page-cache resident)"}
+                       "msamples_per_s": nbytes / 2 / tot / 1e6, "where": d + " (page-cache resident)", "overlapped": True,
+                       "identical_to_upload_then_run": same(got, ref)}
     finally:
         try:
             os.remove(path)
         except OSError:
             pass
-    out["what"] = ("one H2D per capture (gpsjam.Capture), then K1 power map + K2 Welch 4096 + K3 amp stats + K4 onset "
-                   "and the D2H of their results; wall clock")
+    out["what"] = ("one H2D per capture, K1 power map + K2 Welch 4096 + K3 amp stats + K4 onset and the D2H of their results, "
+                   "wall clock.  host_buffer / file: gj_ingest_* -- the kernels run on the 16-MiB pieces that have landed while the "
+                   "rest uploads; *_upload_then_run: gpsjam.Capture, then the four calls (round 2's order)")
     out["uploads"] = gpsjam.Capture.uploads
     return out
 

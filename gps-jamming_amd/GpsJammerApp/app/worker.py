@@ -196,8 +196,12 @@ class GPSAnalysisThread(QThread):
             if self.stop_requested:
                 self.power_map = np.array([])
             else:
-                cap = gpsjam.resident_capture(path)     # one upload; the triangulation reuses it
-                dev = cap.dev
+                # one upload; the power scan runs on the pieces of the file while the rest is still uploading, and
+                # the amplitude statistics the triangulation will ask for (its default threshold) come out of the
+                # same pass over the bytes
+                dev = gpsjam.default_device()
+                dev.last_kernel_ms = 0.0
+                cap = gpsjam.resident_capture(path, chunk_bytes=chunk_bytes, eps=1e-10, rssi_threshold=0.1)
                 self.power_map = dev.chunk_power(cap, chunk_bytes=chunk_bytes, eps=1e-10)
                 self.scan_kernel_ms = dev.last_kernel_ms
                 if self.scan_kernel_ms > 0:

@@ -32,6 +32,14 @@ struct gj_lane {
     unsigned char* rpin = nullptr;        // pinned host memory the results are copied into (async D2H)
     size_t rpin_bytes = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr;
+    // overlapped ingest (gj_ingest_*): uploads run on a stream of the lane's own while the kernels on the context's
+    // stream work on the pieces that have landed; one event per 16-MiB piece; a workspace of the lane's own, because
+    // the scan / Welch state lives across many short lock sections
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t* piece_ev = nullptr;
+    size_t n_piece_ev = 0;
+    unsigned char* ws = nullptr;
+    size_t ws_bytes = 0;
 };
 
 struct gj_retired {                       // an arena replaced while queued kernels may still read it
@@ -198,6 +206,29 @@ __device__ __forceinline__ float group_sum_dpp_f(float v) {
 
 // entry points implemented per translation unit (called from api.hip)
 namespace gj {
+// K2 and the fused scan in three steps (begin / range / end), so that gj_ingest_* can launch them on the pieces of a
+// capture that have landed in HBM while the rest is still being uploaded
+struct WelchJob {
+    alignas(8) unsigned char plan[96];   // WelchPlan (k_welch.hip)
+    int nperseg = 0;
+    size_t rows = 0, ws_bytes = 0;
+    float* partial = nullptr;            // per-workgroup spectra: ws_bytes of workspace, set by the caller
+};
+int welch_begin(gj_ctx*, size_t nbytes, size_t chunk_samples, int nperseg, double fs, size_t plan_bytes, WelchJob&);
+int welch_range(gj_ctx*, const WelchJob&, const uint8_t* d_iq, size_t chunk0, size_t chunk1);
+int welch_end(gj_ctx*, const WelchJob&, int flags, float* d_psd, float* d_psd_db);
+struct ScanJob {
+    alignas(8) unsigned char state[320];   // ScanState (k_scan.hip)
+    size_t ntiles = 0, nchunks = 0, ws_bytes = 0;
+    unsigned char* ws = nullptr;           // ws_bytes of workspace, set by the caller before scan_start
+};
+int scan_begin(gj_ctx*, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags, float* d_power,
+               float rssi_threshold, gj_amp_stats* d_amp, int noise_samples, int window, float factor, gj_onset* d_onset,
+               ScanJob&);
+int scan_start(gj_ctx*, ScanJob&);                              // clears the accumulators (after job.ws is set)
+int scan_range(gj_ctx*, const ScanJob&, size_t tile0, size_t tile1);
+int scan_end(gj_ctx*, const ScanJob&);
+bool scan_fusable(const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes);
 int launch_chunk_power(gj_ctx*, const uint8_t*, size_t, size_t, float, int, float*);
 int launch_power_threshold(gj_ctx*, const float*, size_t, float, float, float*, uint8_t*);
 int launch_amp_stats(gj_ctx*, const uint8_t*, size_t, float, gj_amp_stats*);

@@ -12,7 +12,10 @@
 #include <sys/syscall.h>
 #include <unistd.h>
 
+#include <sched.h>
+
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <new>
 #include <thread>
@@ -41,6 +44,11 @@ void lane_free(gj_lane* L) {
     if (L->rpin) (void)hipHostFree(L->rpin);
     for (hipEvent_t e : {L->ev_start, L->ev_stop, L->ev_done})
         if (e) (void)hipEventDestroy(e);
+    for (size_t k = 0; k < L->n_piece_ev; ++k)
+        if (L->piece_ev[k]) (void)hipEventDestroy(L->piece_ev[k]);
+    delete[] L->piece_ev;
+    if (L->copy_stream) (void)hipStreamDestroy(L->copy_stream);
+    if (L->ws) (void)hipFree(L->ws);
     delete L;
 }
 
@@ -182,12 +190,18 @@ int fill_threads() {
 // it has queued piece `piece` (16 MiB, in HBM once ev fires): the overlapped ingest hangs its kernels there.
 struct PieceSink {
     virtual void queued(size_t piece, size_t off, size_t len, hipEvent_t ev) = 0;
+    virtual void failed() {}
     virtual ~PieceSink() = default;
 };
 
-template <typename Fill>
+// With a sink the CALLING thread does not fill: it runs `meanwhile()` (the ingest's dispatcher, which launches kernels
+// on the pieces as they land) while `nthreads` workers copy; `piece_events[k]` is recorded behind piece k.
+struct NoMeanwhile {
+    void operator()() const {}
+};
+template <typename Fill, typename Meanwhile = NoMeanwhile>
 int staged_copy(gj_ctx* ctx, gj_lane* L, hipStream_t stream, unsigned char* d_dst, size_t nbytes, Fill&& fill,
-                PieceSink* sink = nullptr) {
+                PieceSink* sink = nullptr, hipEvent_t* piece_events = nullptr, Meanwhile&& meanwhile = Meanwhile()) {
     if (nbytes == 0) return GJ_OK;
     const size_t npieces = (nbytes + kPinBytes - 1) / kPinBytes;
     const int nthreads = (int)(npieces < (size_t)fill_threads() ? npieces : (size_t)fill_threads());
@@ -198,7 +212,7 @@ int staged_copy(gj_ctx* ctx, gj_lane* L, hipStream_t stream, unsigned char* d_ds
     wait_hook(ctx, kWaitPiece);
     std::atomic<int> failed{0};
     const int device = ctx->device;
-    auto worker = [&](int t) {
+    auto worker_body = [&](int t) {
         if (hipSetDevice(device) != hipSuccess) { failed.store(1); return; }
         size_t mine = 0;
         for (size_t piece = (size_t)t; piece < npieces; piece += (size_t)nthreads, ++mine) {
@@ -209,15 +223,25 @@ int staged_copy(gj_ctx* ctx, gj_lane* L, hipStream_t stream, unsigned char* d_ds
             if (!fill(static_cast<unsigned char*>(L->pin[b]), off, len)) { failed.store(2); return; }
             if (hipMemcpyAsync(d_dst + off, L->pin[b], len, hipMemcpyHostToDevice, stream) != hipSuccess ||
                 hipEventRecord(L->pin_ev[b], stream) != hipSuccess) { failed.store(1); return; }
-            if (sink) sink->queued(piece, off, len, L->pin_ev[b]);
+            if (piece_events && hipEventRecord(piece_events[piece], stream) != hipSuccess) { failed.store(1); return; }
+            if (sink) sink->queued(piece, off, len, piece_events ? piece_events[piece] : L->pin_ev[b]);
         }
         // the bounce buffers are reused by the lane's next call: the tail pieces must have left them
         for (int k = 0; k < 2; ++k)
             if (mine > (size_t)k && hipEventSynchronize(L->pin_ev[2 * t + k]) != hipSuccess) failed.store(1);
     };
+    auto worker = [&](int t) {
+        worker_body(t);
+        if (failed.load() && sink) sink->failed();   // the dispatcher must not wait for pieces that will never come
+    };
     std::vector<std::thread> pool;
-    for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker, t);
-    worker(0);
+    for (int t = sink ? 0 : 1; t < nthreads; ++t) pool.emplace_back(worker, t);
+    if (sink) {
+        if (failed.load()) sink->failed();
+        meanwhile();
+    } else {
+        worker(0);
+    }
     for (auto& th : pool) th.join();
     if (failed.load() == 2) return fail(ctx, GJ_ERR_INVALID, "reading the capture failed");
     if (failed.load()) return fail(ctx, GJ_ERR_HIP, "host-to-device staging failed");
@@ -418,6 +442,282 @@ int gj_upload_file(gj_ctx* ctx, const char* path, size_t offset, size_t max_byte
     *dptr = p;
     *nbytes_out = nbytes;
     return GJ_OK;
+}
+
+}   // extern "C"
+
+// ---------------------------------------------------------------- overlapped ingest
+// Upload + analysis of one capture with the kernels running on the pieces that have LANDED while the rest is still on
+// its way ("end-to-end is 17-35x the kernel time and nothing overlaps it").  The reference's ingest
+// (worker.py:209-217 f.read per chunk, triangulateRSSI.py:29 np.fromfile) reads, then computes; here the 16-MiB pieces
+// go file/array -> pinned bounce buffers -> HBM on a stream of the lane's own, each followed by an event, and the
+// calling thread -- which does not copy -- walks the pieces in order: wait (on the host) until piece k has been QUEUED,
+// make the context's stream wait for its event, launch the fused scan on its 256 tiles and K2 on the 1-s chunks that are
+// now complete.  After the last piece: the tail kernels (amplitude totals, onset, threshold-free finalize, PSD sum).
+// Same kernels, same per-tile / per-workgroup partial results, same fixed-order sums: bit-identical to upload-then-run.
+namespace gj {
+namespace {
+
+struct IngestSink : PieceSink {
+    std::atomic<unsigned char>* queued_flag;
+    std::atomic<int> dead{0};
+    void queued(size_t piece, size_t, size_t, hipEvent_t) override { queued_flag[piece].store(1, std::memory_order_release); }
+    void failed() override { dead.store(1); }
+};
+
+int lane_ingest_resources(gj_ctx* ctx, gj_lane* L, size_t npieces, size_t ws_bytes) {
+    if (!L->copy_stream) GJ_HIP(ctx, hipStreamCreateWithFlags(&L->copy_stream, hipStreamNonBlocking));
+    if (L->n_piece_ev < npieces) {
+        hipEvent_t* ev = new (std::nothrow) hipEvent_t[npieces]();
+        if (!ev) return fail(ctx, GJ_ERR_NOMEM, "piece events");
+        for (size_t k = 0; k < L->n_piece_ev; ++k) ev[k] = L->piece_ev[k];
+        delete[] L->piece_ev;
+        L->piece_ev = ev;
+        for (size_t k = L->n_piece_ev; k < npieces; ++k) {
+            L->n_piece_ev = k;
+            GJ_HIP(ctx, hipEventCreateWithFlags(&L->piece_ev[k], hipEventDisableTiming));
+        }
+        L->n_piece_ev = npieces;
+    }
+    if (L->ws_bytes < ws_bytes) {
+        if (L->ws) (void)hipFree(L->ws);
+        L->ws = nullptr;
+        L->ws_bytes = 0;
+        void* p = nullptr;
+        if (hipMalloc(&p, align_up(ws_bytes, 1 << 20)) != hipSuccess) return fail(ctx, GJ_ERR_NOMEM, "ingest workspace of %zu bytes", ws_bytes);
+        L->ws = static_cast<unsigned char*>(p);
+        L->ws_bytes = align_up(ws_bytes, 1 << 20);
+    }
+    return GJ_OK;
+}
+
+template <typename Fill>
+int ingest_impl(gj_ctx* ctx, size_t nbytes, Fill&& fill, const gj_ingest_plan& plan, float* power, size_t power_cap, float* psd,
+                float* psd_db, size_t psd_cap_floats, gj_ingest_result* res, void** dptr) {
+    if (!res || !dptr) return fail(ctx, GJ_ERR_INVALID, "null argument");
+    *dptr = nullptr;
+    memset(res, 0, sizeof(*res));
+    res->nbytes = nbytes;
+    const bool want_scan = plan.chunk_bytes != 0;
+    const bool want_welch = plan.nperseg != 0;
+    const size_t n_chunks = want_scan ? gj_chunk_count(nbytes, plan.chunk_bytes) : 0;
+    const size_t rows = want_welch ? gj_welch_rows(nbytes, plan.chunk_samples, plan.nperseg) : 0;
+    const size_t nfl = rows * (size_t)(want_welch ? plan.nperseg : 0);
+    res->n_chunks = n_chunks;
+    res->rows = rows;
+    if (want_scan && n_chunks && (!power || power_cap < n_chunks)) return fail(ctx, GJ_ERR_CAPACITY, "power buffer holds %zu, need %zu", power_cap, n_chunks);
+    if (want_welch && rows && (!psd || psd_cap_floats < nfl)) return fail(ctx, GJ_ERR_CAPACITY, "psd buffer holds %zu floats, need %zu", psd_cap_floats, nfl);
+    if (want_welch && (plan.nperseg < 16 || plan.nperseg > 4096 || (plan.nperseg & (plan.nperseg - 1))))
+        return fail(ctx, GJ_ERR_UNSUPPORTED, "nperseg must be a power of two in [16, 4096]");
+    const auto t_begin = std::chrono::steady_clock::now();
+    LaneHold hold(ctx);
+    gj_lane* L = hold.L;
+    if (!L) return GJ_ERR_NOMEM;
+    int rc = lane_events(ctx, L);
+    if (rc) return rc;
+    void* p = nullptr;
+    if (hipMalloc(&p, align_up(nbytes, 256) + 256) != hipSuccess) return fail(ctx, GJ_ERR_NOMEM, "hipMalloc(%zu)", nbytes);
+    unsigned char* d_cap = static_cast<unsigned char*>(p);
+    auto bail = [&](int code) {
+        (void)hipDeviceSynchronize();   // nothing may still be writing into, or reading from, the capture
+        (void)hipFree(p);
+        return code;
+    };
+    // device results of this call: [power][amp][onset][psd][psd_db]
+    const size_t off_amp = align_up(n_chunks * sizeof(float), 256);
+    const size_t off_onset = off_amp + 256;
+    const size_t off_psd = off_onset + 256;
+    const size_t off_db = off_psd + align_up(nfl * sizeof(float), 256);
+    const size_t res_bytes = off_db + (psd_db ? align_up(nfl * sizeof(float), 256) : 0);
+    rc = lane_stage(ctx, L, res_bytes + 256);
+    if (!rc) rc = lane_rpin(ctx, L, res_bytes + 256);
+    if (rc) return bail(rc);
+    float* d_power = reinterpret_cast<float*>(L->stage);
+    gj_amp_stats* d_amp = reinterpret_cast<gj_amp_stats*>(L->stage + off_amp);
+    gj_onset* d_onset = reinterpret_cast<gj_onset*>(L->stage + off_onset);
+    float* d_psd = reinterpret_cast<float*>(L->stage + off_psd);
+    float* d_db = psd_db ? reinterpret_cast<float*>(L->stage + off_db) : nullptr;
+
+    // plans (no GPU work yet)
+    ScanJob sj;
+    WelchJob wj;
+    const bool fused = want_scan && n_chunks && scan_fusable(d_cap, nbytes, plan.chunk_bytes);
+    if (fused) {
+        rc = scan_begin(ctx, d_cap, nbytes, plan.chunk_bytes, plan.eps, plan.power_flags, d_power, plan.rssi_threshold, d_amp,
+                        plan.noise_samples, plan.window, plan.factor, d_onset, sj);
+        if (rc) return bail(rc);
+    }
+    if (want_welch) {
+        rc = welch_begin(ctx, nbytes, plan.chunk_samples, plan.nperseg, plan.fs, 0, wj);
+        if (rc) return bail(rc);
+    }
+    const size_t npieces = (nbytes + kPinBytes - 1) / kPinBytes;
+    const size_t ws_scan = fused ? sj.ws_bytes : 0;
+    rc = lane_ingest_resources(ctx, L, npieces ? npieces : 1, ws_scan + (want_welch ? wj.ws_bytes : 0) + 256);
+    if (rc) return bail(rc);
+    sj.ws = L->ws;
+    wj.partial = reinterpret_cast<float*>(L->ws + ws_scan);
+    const size_t psd_chunk_bytes = want_welch ? 2 * plan.chunk_samples : 0;
+
+    hipStream_t s = nullptr;
+    {
+        Guard g(ctx);
+        s = ctx->stream;
+        if (hipEventRecord(L->ev_start, s) != hipSuccess) return bail(fail(ctx, GJ_ERR_HIP, "event"));
+        if (fused) rc = scan_start(ctx, sj);
+    }
+    if (rc) return bail(rc);
+
+    // kernels on everything that is complete once the first `landed` bytes are in HBM
+    size_t tiles_done = 0, chunks_done = 0;
+    auto launch_upto = [&](size_t landed, bool last) -> int {
+        Guard g(ctx);
+        int r = GJ_OK;
+        if (fused) {
+            const size_t t1 = last ? sj.ntiles : landed / 65536;
+            if (t1 > tiles_done) r = scan_range(ctx, sj, tiles_done, t1);
+            if (t1 > tiles_done) tiles_done = t1;
+        }
+        if (!r && want_welch && rows) {
+            const size_t c1 = last ? rows : landed / psd_chunk_bytes;
+            if (c1 > chunks_done) r = welch_range(ctx, wj, d_cap, chunks_done, c1);
+            if (c1 > chunks_done) chunks_done = c1 < rows ? c1 : rows;
+        }
+        return r;
+    };
+
+    double upload_ms = 0.0;
+    if (nbytes >= kPinThreshold) {
+        std::vector<std::atomic<unsigned char>> flags(npieces);
+        for (auto& f : flags) f.store(0);
+        IngestSink sink;
+        sink.queued_flag = flags.data();
+        int disp_rc = GJ_OK;
+        rc = staged_copy(ctx, L, L->copy_stream, d_cap, nbytes, fill, &sink, L->piece_ev, [&] {
+            // dispatcher: the calling thread.  Holds no lock while it waits for a piece to be queued.
+            for (size_t k = 0; k < npieces && !disp_rc; ++k) {
+                unsigned spins = 0;
+                while (!flags[k].load(std::memory_order_acquire)) {
+                    if (sink.dead.load()) return;
+                    if (++spins > 64) usleep(20); else sched_yield();
+                }
+                if (hipStreamWaitEvent(s, L->piece_ev[k], 0) != hipSuccess) { disp_rc = fail(ctx, GJ_ERR_HIP, "hipStreamWaitEvent failed"); return; }
+                const size_t landed = (k + 1 == npieces) ? nbytes : (k + 1) * kPinBytes;
+                disp_rc = launch_upto(landed, k + 1 == npieces);
+            }
+        });
+        upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        if (!rc) rc = disp_rc;
+        if (rc) return bail(rc);
+    } else {
+        // a small capture: one copy on the context's stream, then everything
+        if (nbytes) {
+            std::vector<unsigned char> tmp;
+            unsigned char* pin = nullptr;
+            // through the lane's first bounce buffer when it fits, so that the copy is asynchronous; else in pieces
+            for (size_t off = 0; off < nbytes; off += kPinBytes) {
+                const size_t len = nbytes - off < kPinBytes ? nbytes - off : kPinBytes;
+                if (!L->pin[0] && hipHostMalloc(&L->pin[0], kPinBytes, hipHostMallocDefault) != hipSuccess) return bail(fail(ctx, GJ_ERR_NOMEM, "pinned buffer"));
+                pin = static_cast<unsigned char*>(L->pin[0]);
+                if (!fill(pin, off, len)) return bail(fail(ctx, GJ_ERR_INVALID, "reading the capture failed"));
+                if (hipMemcpyAsync(d_cap + off, pin, len, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+                    return bail(fail(ctx, GJ_ERR_HIP, "host-to-device copy failed"));
+            }
+            (void)tmp;
+        }
+        upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        rc = launch_upto(nbytes, true);
+        if (rc) return bail(rc);
+    }
+    {
+        Guard g(ctx);
+        if (fused) rc = scan_end(ctx, sj);
+        else if (want_scan && n_chunks) {   // odd chunk sizes / unaligned: the three separate passes
+            rc = launch_chunk_power(ctx, d_cap, nbytes, plan.chunk_bytes, plan.eps, plan.power_flags, d_power);
+            if (!rc) rc = launch_amp_stats(ctx, d_cap, nbytes, plan.rssi_threshold, d_amp);
+            if (!rc) rc = launch_onset(ctx, d_cap, nbytes, plan.noise_samples, plan.window, plan.factor, d_onset);
+        }
+        if (!rc && want_welch && rows) rc = welch_end(ctx, wj, plan.welch_flags, d_psd, d_db);
+        if (!rc && (hipEventRecord(L->ev_stop, s) != hipSuccess ||
+                    (res_bytes && hipMemcpyAsync(L->rpin, L->stage, res_bytes, hipMemcpyDeviceToHost, s) != hipSuccess) ||
+                    hipEventRecord(L->ev_done, s) != hipSuccess))
+            rc = fail(ctx, GJ_ERR_HIP, "queueing the results failed");
+    }
+    if (!rc) rc = wait_event(ctx, L->ev_done);
+    if (rc) return bail(rc);
+    if (want_scan && n_chunks) {
+        memcpy(power, L->rpin, n_chunks * sizeof(float));
+        memcpy(&res->amp, L->rpin + off_amp, sizeof(gj_amp_stats));
+        memcpy(&res->onset, L->rpin + off_onset, sizeof(gj_onset));
+    }
+    if (want_welch && rows) {
+        memcpy(psd, L->rpin + off_psd, nfl * sizeof(float));
+        if (psd_db) memcpy(psd_db, L->rpin + off_db, nfl * sizeof(float));
+    }
+    res->upload_ms = (float)upload_ms;
+    res->total_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    *dptr = p;
+    return GJ_OK;
+}
+
+}   // namespace
+}   // namespace gj
+
+extern "C" {
+
+int gj_ingest_u8(gj_ctx* ctx, const uint8_t* host, size_t nbytes, const gj_ingest_plan* plan, float* power, size_t power_cap,
+                 float* psd, float* psd_db, size_t psd_cap_floats, gj_ingest_result* result, void** dptr) {
+    if (!ctx) return GJ_ERR_INVALID;
+    if (!plan || (nbytes && !host)) return fail(ctx, GJ_ERR_INVALID, "null argument");
+    return ingest_impl(ctx, nbytes, [host](unsigned char* dst, size_t off, size_t len) {
+        memcpy(dst, host + off, len);
+        return true;
+    }, *plan, power, power_cap, psd, psd_db, psd_cap_floats, result, dptr);
+}
+
+int gj_ingest_file(gj_ctx* ctx, const char* path, size_t offset, size_t max_bytes, const gj_ingest_plan* plan, float* power,
+                   size_t power_cap, float* psd, float* psd_db, size_t psd_cap_floats, gj_ingest_result* result, void** dptr) {
+    if (!ctx) return GJ_ERR_INVALID;
+    if (!path || !plan) return fail(ctx, GJ_ERR_INVALID, "null argument");
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(ctx, GJ_ERR_INVALID, "cannot open %s", path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+        close(fd);
+        return fail(ctx, GJ_ERR_INVALID, "cannot stat %s", path);
+    }
+    size_t nbytes = (size_t)st.st_size > offset ? (size_t)st.st_size - offset : 0;
+    if (max_bytes && nbytes > max_bytes) nbytes = max_bytes;
+    static const bool want_pread = [] {
+        const char* e = getenv("GPSJAM_FILE_READ");
+        return e && strcmp(e, "pread") == 0;
+    }();
+    const size_t pg = (size_t)sysconf(_SC_PAGESIZE);
+    const size_t map_off = offset / pg * pg, lead = offset - map_off;
+    void* m = (nbytes && !want_pread) ? mmap(nullptr, nbytes + lead, PROT_READ, MAP_PRIVATE, fd, (off_t)map_off) : MAP_FAILED;
+    int rc;
+    if (m != MAP_FAILED) {   // see gj_upload_file for why mapping is the default
+        (void)madvise(m, nbytes + lead, MADV_SEQUENTIAL);
+        const unsigned char* src = static_cast<const unsigned char*>(m) + lead;
+        rc = ingest_impl(ctx, nbytes, [src](unsigned char* dst, size_t off, size_t len) {
+            memcpy(dst, src + off, len);
+            return true;
+        }, *plan, power, power_cap, psd, psd_db, psd_cap_floats, result, dptr);
+        (void)munmap(m, nbytes + lead);
+    } else {
+        (void)posix_fadvise(fd, 0, 0, POSIX_FADV_NOREUSE);
+        rc = ingest_impl(ctx, nbytes, [fd, offset](unsigned char* dst, size_t off, size_t len) {
+            size_t done = 0;
+            while (done < len) {
+                const ssize_t k = pread(fd, dst + done, len - done, (off_t)(offset + off + done));
+                if (k <= 0) return false;
+                done += (size_t)k;
+            }
+            return true;
+        }, *plan, power, power_cap, psd, psd_db, psd_cap_floats, result, dptr);
+    }
+    close(fd);
+    return rc;
 }
 
 // ---------------------------------------------------------------- host-buffer entry points

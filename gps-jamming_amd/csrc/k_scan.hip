@@ -961,7 +961,7 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
                                                                    AmpTile* __restrict__ tiles,
                                                                    unsigned* __restrict__ cblk, size_t noise_bytes,
                                                                    OnsetScratch* __restrict__ sc, Unpack up,
-                                                                   unsigned skip_tiles = 0) {
+                                                                   unsigned skip_tiles = 0, unsigned tile_base = 0) {
     // skip_tiles (a part of a split capture): the first tiles of the buffer are the HALO in front of the part's own
     // range -- they feed K4's block sums only; chunk powers and amplitude tiles start at the own range (`nbytes` =
     // its length, `power` / `tiles` / `acc` its arrays).
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
     __shared__ double red_s[kScanThreads / 64];
     __shared__ long long red_f[kScanThreads / 64];
     const int tid = threadIdx.x;
-    const size_t t = blockIdx.x;
+    const size_t t = (size_t)blockIdx.x + tile_base;   // tile_base: this launch covers the tiles from there on (gj_ingest_*)
     const size_t b0 = t * kScanTile;                               // first byte of the tile
     const size_t use_end = 2 * nsamples;                           // a trailing odd byte is never used
     const size_t b1 = (b0 + kScanTile < use_end) ? b0 + kScanTile : use_end;
@@ -1112,101 +1112,180 @@ struct ScanPart {
     gj_amp_part* d_amp;        // out
 };
 
-static int stream_scan_impl(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
-                            float* d_power, float rssi_threshold, gj_amp_stats* d_amp, int noise_samples, int window,
-                            float factor, gj_onset* d_onset, const ScanPart* part) {
+struct ScanState {
+    const uint8_t* d_iq;
+    size_t nbytes, chunk_bytes, own_bytes, nsamples, own_samples, ntiles, skip, own_tiles, nchunks, tpc, noise_bytes;
+    float eps, rssi_threshold, factor;
+    int flags, noise_samples, window, valid;
+    bool noise_fused, noise_here, track, is_part;
+    float* d_power;
+    gj_amp_stats* d_amp;
+    gj_onset* d_onset;
+    ScanPart part;
+    size_t off_tiles, off_acc, off_blk;
+};
+static_assert(sizeof(ScanState) <= sizeof(ScanJob::state), "ScanJob::state too small");
+
+bool scan_fusable(const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes) {
+    return chunk_bytes >= kScanTile && chunk_bytes % kScanTile == 0 && (reinterpret_cast<uintptr_t>(d_iq) & 15) == 0 && nbytes >= 2;
+}
+
+static int scan_begin_impl(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
+                           float* d_power, float rssi_threshold, gj_amp_stats* d_amp, int noise_samples, int window,
+                           float factor, gj_onset* d_onset, const ScanPart* part, ScanJob& job) {
     if (noise_samples <= 0 || window <= 0) return fail(ctx, GJ_ERR_INVALID, "noise_samples and window must be > 0");
     if (window > kOnsetMaxWin) return fail(ctx, GJ_ERR_UNSUPPORTED, "window > %d", kOnsetMaxWin);
+    ScanState st;
+    memset(&st, 0, sizeof(st));
+    st.d_iq = d_iq; st.nbytes = nbytes; st.chunk_bytes = chunk_bytes; st.eps = eps; st.flags = flags; st.d_power = d_power;
+    st.rssi_threshold = rssi_threshold; st.d_amp = d_amp; st.noise_samples = noise_samples; st.window = window;
+    st.factor = factor; st.d_onset = d_onset;
+    st.is_part = part != nullptr;
+    if (part) st.part = *part;
     const size_t halo = part ? part->halo_bytes : 0;
-    const size_t own_bytes = nbytes - halo;
-    const size_t nsamples = nbytes / 2;                         // of the buffer (halo + own)
-    const size_t own_samples = own_bytes / 2;
-    const size_t ntiles = (2 * nsamples + kScanTile - 1) / kScanTile;
-    const size_t skip = halo / kScanTile;
-    const size_t own_tiles = ntiles - skip;
-    const size_t nchunks = gj_chunk_count(own_bytes, chunk_bytes);
-    const size_t tpc = chunk_bytes / kScanTile;
-    const size_t nblk = (nsamples + 511) / 512;
-    if (ntiles > 0x7fffffffull) return fail(ctx, GJ_ERR_UNSUPPORTED, "capture too long");
+    st.own_bytes = nbytes - halo;
+    st.nsamples = nbytes / 2;                         // of the buffer (halo + own)
+    st.own_samples = st.own_bytes / 2;
+    st.ntiles = (2 * st.nsamples + kScanTile - 1) / kScanTile;
+    st.skip = halo / kScanTile;
+    st.own_tiles = st.ntiles - st.skip;
+    st.nchunks = gj_chunk_count(st.own_bytes, chunk_bytes);
+    st.tpc = chunk_bytes / kScanTile;
+    const size_t nblk = (st.nsamples + 511) / 512;
+    if (st.ntiles > 0x7fffffffull) return fail(ctx, GJ_ERR_UNSUPPORTED, "capture too long");
     // workspace: [OnsetScratch][AmpTile x own tiles (whole capture only)][acc u64 x 2 x nchunks][c512 u32 x nblk]
-    const size_t off_tiles = 256;
-    const size_t off_acc = off_tiles + (part ? 0 : align_up((own_tiles + 1) * sizeof(AmpTile), 256));
-    const size_t off_blk = off_acc + align_up(nchunks * 16, 256);
-    int rc = ensure_workspace(ctx, off_blk + (nblk + 16) * sizeof(unsigned));
-    if (rc) return rc;
-    OnsetScratch* sc = reinterpret_cast<OnsetScratch*>(ctx->ws);
-    AmpTile* tiles = part ? part->d_tiles : reinterpret_cast<AmpTile*>(ctx->ws + off_tiles);
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(ctx->ws + off_acc);
-    unsigned* cblk = reinterpret_cast<unsigned*>(ctx->ws + off_blk);
-    GJ_HIP(ctx, hipMemsetAsync(sc, 0, sizeof(OnsetScratch), ctx->stream));
-    if (tpc > 1) GJ_HIP(ctx, hipMemsetAsync(acc, 0, nchunks * 16, ctx->stream));
+    st.off_tiles = 256;
+    st.off_acc = st.off_tiles + (part ? 0 : align_up((st.own_tiles + 1) * sizeof(AmpTile), 256));
+    st.off_blk = st.off_acc + align_up(st.nchunks * 16, 256);
     // triangulateTDOA.py:39 speaks of the whole capture; a part must itself hold at least one window
-    const size_t total_samples = part ? part->total_samples : nsamples;
-    const int valid = total_samples >= (size_t)noise_samples + (size_t)window && nsamples >= (size_t)window;
+    const size_t total_samples = part ? part->total_samples : st.nsamples;
+    st.valid = total_samples >= (size_t)noise_samples + (size_t)window && st.nsamples >= (size_t)window;
     // the K4 noise span rides along in the same pass when the buffer starts with it and it ends on a 16-byte boundary
-    const size_t noise_bytes = (size_t)2 * noise_samples;
-    const bool noise_here = !part || (part->buf_sample0 == 0 && noise_bytes <= nbytes);
-    const bool noise_fused = valid && noise_here && (noise_bytes % 16 == 0);
-    if (valid && !noise_here && !part->d_noise)
-        return fail(ctx, GJ_ERR_INVALID, "this part does not hold the capture's noise span (%zu bytes): d_noise is required", noise_bytes);
+    st.noise_bytes = (size_t)2 * noise_samples;
+    st.noise_here = !part || (part->buf_sample0 == 0 && st.noise_bytes <= nbytes);
+    st.noise_fused = st.valid && st.noise_here && (st.noise_bytes % 16 == 0);
+    if (st.valid && !st.noise_here && !part->d_noise)
+        return fail(ctx, GJ_ERR_INVALID, "this part does not hold the capture's noise span (%zu bytes): d_noise is required", st.noise_bytes);
     // When the offset is a half-integer (off2 odd) no component of 2u - off2 is zero, so every amplitude is at
     // least sqrt(2) * half_scale (0.0055 for the default unpack): a threshold below that makes every sample a hit
     // and the first index needs no tracking.  With an integer offset (gj_set_unpack(128, ...)) amplitudes can be
     // zero and the shortcut never applies.  Same float expression as the kernels' `a > thr`.
     const Unpack upk = unpack_of(ctx);
     const bool all_hit = (ctx->off2 & 1) && (sqrtf(2.0f) * upk.half_scale > rssi_threshold);
-    const bool track = !all_hit;
-    if (track)
-        hipLaunchKernelGGL(stream_scan_kernel<true>, dim3((unsigned)ntiles), dim3(kScanThreads), 0, ctx->stream, d_iq,
-                           nsamples, own_bytes, chunk_bytes, (unsigned)tpc, eps, flags, d_power, acc, rssi_threshold, tiles,
-                           cblk, noise_fused ? noise_bytes : (size_t)0, sc, upk, (unsigned)skip);
+    st.track = !all_hit;
+    memcpy(job.state, &st, sizeof(st));
+    job.ntiles = st.ntiles;
+    job.nchunks = st.nchunks;
+    job.ws_bytes = align_up(st.off_blk + (nblk + 16) * sizeof(unsigned), 256);
+    job.ws = nullptr;
+    return GJ_OK;
+}
+
+int scan_begin(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags, float* d_power,
+               float rssi_threshold, gj_amp_stats* d_amp, int noise_samples, int window, float factor, gj_onset* d_onset,
+               ScanJob& job) {
+    if (!scan_fusable(d_iq, nbytes, chunk_bytes)) return fail(ctx, GJ_ERR_UNSUPPORTED, "the fused scan needs chunk_bytes to be a multiple of 65536 and a 16-byte aligned capture");
+    return scan_begin_impl(ctx, d_iq, nbytes, chunk_bytes, eps, flags, d_power, rssi_threshold, d_amp, noise_samples, window,
+                           factor, d_onset, nullptr, job);
+}
+
+int scan_start(gj_ctx* ctx, ScanJob& job) {
+    ScanState st;
+    memcpy(&st, job.state, sizeof(st));
+    GJ_HIP(ctx, hipMemsetAsync(job.ws, 0, sizeof(OnsetScratch), ctx->stream));
+    if (st.tpc > 1) GJ_HIP(ctx, hipMemsetAsync(job.ws + st.off_acc, 0, st.nchunks * 16, ctx->stream));
+    return GJ_OK;
+}
+
+int scan_range(gj_ctx* ctx, const ScanJob& job, size_t tile0, size_t tile1) {
+    ScanState st;
+    memcpy(&st, job.state, sizeof(st));
+    if (tile1 > st.ntiles) tile1 = st.ntiles;
+    if (tile0 >= tile1) return GJ_OK;
+    OnsetScratch* sc = reinterpret_cast<OnsetScratch*>(job.ws);
+    AmpTile* tiles = st.is_part ? st.part.d_tiles : reinterpret_cast<AmpTile*>(job.ws + st.off_tiles);
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(job.ws + st.off_acc);
+    unsigned* cblk = reinterpret_cast<unsigned*>(job.ws + st.off_blk);
+    const Unpack upk = unpack_of(ctx);
+    const unsigned n = (unsigned)(tile1 - tile0);
+    if (st.track)
+        hipLaunchKernelGGL(stream_scan_kernel<true>, dim3(n), dim3(kScanThreads), 0, ctx->stream, st.d_iq, st.nsamples,
+                           st.own_bytes, st.chunk_bytes, (unsigned)st.tpc, st.eps, st.flags, st.d_power, acc, st.rssi_threshold,
+                           tiles, cblk, st.noise_fused ? st.noise_bytes : (size_t)0, sc, upk, (unsigned)st.skip, (unsigned)tile0);
     else
-        hipLaunchKernelGGL(stream_scan_kernel<false>, dim3((unsigned)ntiles), dim3(kScanThreads), 0, ctx->stream, d_iq,
-                           nsamples, own_bytes, chunk_bytes, (unsigned)tpc, eps, flags, d_power, acc, rssi_threshold, tiles,
-                           cblk, noise_fused ? noise_bytes : (size_t)0, sc, upk, (unsigned)skip);
+        hipLaunchKernelGGL(stream_scan_kernel<false>, dim3(n), dim3(kScanThreads), 0, ctx->stream, st.d_iq, st.nsamples,
+                           st.own_bytes, st.chunk_bytes, (unsigned)st.tpc, st.eps, st.flags, st.d_power, acc, st.rssi_threshold,
+                           tiles, cblk, st.noise_fused ? st.noise_bytes : (size_t)0, sc, upk, (unsigned)st.skip, (unsigned)tile0);
     GJ_LAUNCH_CHECK(ctx);
-    if (tpc > 1) {
-        hipLaunchKernelGGL(chunk_power_finalize_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0,
-                           ctx->stream, acc, nchunks, own_bytes, chunk_bytes, eps, flags, d_power, ctx->off2, true);
+    return GJ_OK;
+}
+
+int scan_end(gj_ctx* ctx, const ScanJob& job) {
+    ScanState st;
+    memcpy(&st, job.state, sizeof(st));
+    OnsetScratch* sc = reinterpret_cast<OnsetScratch*>(job.ws);
+    AmpTile* tiles = st.is_part ? st.part.d_tiles : reinterpret_cast<AmpTile*>(job.ws + st.off_tiles);
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(job.ws + st.off_acc);
+    unsigned* cblk = reinterpret_cast<unsigned*>(job.ws + st.off_blk);
+    const Unpack upk = unpack_of(ctx);
+    const uint8_t* d_iq = st.d_iq;
+    const size_t halo = st.is_part ? st.part.halo_bytes : 0;
+    if (st.tpc > 1) {
+        hipLaunchKernelGGL(chunk_power_finalize_kernel, dim3((unsigned)((st.nchunks + 255) / 256)), dim3(256), 0,
+                           ctx->stream, acc, st.nchunks, st.own_bytes, st.chunk_bytes, st.eps, st.flags, st.d_power, ctx->off2, true);
         GJ_LAUNCH_CHECK(ctx);
     }
     // amplitude totals + the chunk-power edge cases (last chunk odd / without a complete pair)
-    if (part)
-        hipLaunchKernelGGL(amp_part_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, d_iq + halo, own_samples, tiles,
-                           own_tiles, part->buf_sample0 + (long long)(halo / 2), part->d_amp, upk, d_power, nchunks, own_bytes,
-                           chunk_bytes, flags);
+    if (st.is_part)
+        hipLaunchKernelGGL(amp_part_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, d_iq + halo, st.own_samples, tiles,
+                           st.own_tiles, st.part.buf_sample0 + (long long)(halo / 2), st.part.d_amp, upk, st.d_power, st.nchunks,
+                           st.own_bytes, st.chunk_bytes, st.flags);
     else
-        hipLaunchKernelGGL(amp_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, d_iq, nsamples, tiles, ntiles, d_amp,
-                           upk, d_power, nchunks, nbytes, chunk_bytes, flags);
+        hipLaunchKernelGGL(amp_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, d_iq, st.nsamples, tiles, st.ntiles, st.d_amp,
+                           upk, st.d_power, st.nchunks, st.nbytes, st.chunk_bytes, st.flags);
     GJ_LAUNCH_CHECK(ctx);
-    if (valid) {
-        if (!noise_fused) {
+    if (st.valid) {
+        if (!st.noise_fused) {
             hipLaunchKernelGGL(onset_noise_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream,
-                               noise_here ? d_iq : part->d_noise, noise_samples, sc, ctx->off2);
+                               st.noise_here ? d_iq : st.part.d_noise, st.noise_samples, sc, ctx->off2);
             GJ_LAUNCH_CHECK(ctx);
         }
-        const size_t nout = nsamples - window + 1;
+        const size_t nout = st.nsamples - st.window + 1;
         const size_t nct = ((nout + 511) / 512 + kCoarseBlocks - 1) / kCoarseBlocks;
         hipLaunchKernelGGL(onset_coarse_kernel<512>, dim3((unsigned)nct), dim3(kScanThreads), 0, ctx->stream, d_iq,
-                           (const unsigned*)cblk, nsamples, window, noise_samples, factor, sc, ctx->off2);
+                           (const unsigned*)cblk, st.nsamples, st.window, st.noise_samples, st.factor, sc, ctx->off2);
         GJ_LAUNCH_CHECK(ctx);
         const size_t nt = (nout + kOnsetOut - 1) / kOnsetOut;
         hipLaunchKernelGGL(onset_scan_kernel, dim3((unsigned)(nt < 256 ? nt : 256)), dim3(kScanThreads), 0, ctx->stream,
-                           d_iq, nsamples, window, sc, ctx->off2);
+                           d_iq, st.nsamples, st.window, sc, ctx->off2);
         GJ_LAUNCH_CHECK(ctx);
     }
-    hipLaunchKernelGGL(onset_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, d_iq, sc, window, valid, d_onset, ctx->off2,
-                       part ? part->buf_sample0 : 0ll);
+    hipLaunchKernelGGL(onset_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, d_iq, sc, st.window, st.valid, st.d_onset,
+                       ctx->off2, st.is_part ? st.part.buf_sample0 : 0ll);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
+}
+
+static int stream_scan_impl(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
+                            float* d_power, float rssi_threshold, gj_amp_stats* d_amp, int noise_samples, int window,
+                            float factor, gj_onset* d_onset, const ScanPart* part) {
+    ScanJob job;
+    int rc = scan_begin_impl(ctx, d_iq, nbytes, chunk_bytes, eps, flags, d_power, rssi_threshold, d_amp, noise_samples, window,
+                             factor, d_onset, part, job);
+    if (rc) return rc;
+    rc = ensure_workspace(ctx, job.ws_bytes);
+    if (rc) return rc;
+    job.ws = ctx->ws;
+    rc = scan_start(ctx, job);
+    if (!rc) rc = scan_range(ctx, job, 0, job.ntiles);
+    if (!rc) rc = scan_end(ctx, job);
+    return rc;
 }
 
 int launch_stream_scan(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
                        float* d_power, float rssi_threshold, gj_amp_stats* d_amp, int noise_samples, int window,
                        float factor, gj_onset* d_onset) {
-    const bool fusable = chunk_bytes >= kScanTile && chunk_bytes % kScanTile == 0 &&
-                         (reinterpret_cast<uintptr_t>(d_iq) & 15) == 0 && nbytes >= 2;
-    if (!fusable) {   // odd chunk sizes / unaligned captures: the three separate passes
+    if (!scan_fusable(d_iq, nbytes, chunk_bytes)) {   // odd chunk sizes / unaligned captures: the three separate passes
         int rc = launch_chunk_power(ctx, d_iq, nbytes, chunk_bytes, eps, flags, d_power);
         if (!rc) rc = launch_amp_stats(ctx, d_iq, nbytes, rssi_threshold, d_amp);
         if (!rc) rc = launch_onset(ctx, d_iq, nbytes, noise_samples, window, factor, d_onset);

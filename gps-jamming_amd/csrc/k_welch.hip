@@ -157,7 +157,9 @@ template <int N>
 __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_kernel(const uint8_t* __restrict__ iq, WelchGeom g,
                                                               const cf* __restrict__ twtab,
                                                               const float* __restrict__ wintab,
-                                                              float* __restrict__ partial) {
+                                                              float* __restrict__ partial, unsigned wg_base) {
+    // wg_base: index of this launch's first workgroup in the whole capture's grid (0 unless the capture is
+    // transformed piece by piece while it is still being uploaded, gj_ingest_*)
     constexpr int TF = N / 16, B = kBlockPoints / N, NP = fft_npass(N);
     constexpr int WPF = (TF >= 64) ? TF / 64 : 1;   // waves per transform
     constexpr bool XP = (N == 4096) && GJ_W_XPOSE;
@@ -171,7 +173,8 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
     const int tid = threadIdx.x;
     const int b = tid / TF, jl0 = tid % TF;   // jl0: butterfly of pass 0 (input index jl0 + TF s)
     const int jl = XP ? X4096::jl1(tid) : jl0;   // butterfly of the later passes = bins held at the end
-    const unsigned c = blockIdx.x / g.splits, part = blockIdx.x % g.splits;
+    const unsigned wg = blockIdx.x + wg_base;
+    const unsigned c = wg / g.splits, part = wg % g.splits;
     const unsigned nseg = (c + 1 == g.nchunks) ? g.nseg_last : g.nseg_full;
     const unsigned seg_lo = (unsigned)((unsigned long long)part * nseg / g.splits);
     const unsigned seg_hi = (unsigned)((unsigned long long)(part + 1) * nseg / g.splits);
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
         }
         if constexpr (HS) { ws_prv = ws_cur; ws_cur = (ws_cur == 2) ? 0 : ws_cur + 1; }
     }
-    float* out = partial + ((size_t)blockIdx.x * B + b) * N + jl;
+    float* out = partial + ((size_t)wg * B + b) * N + jl;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         if constexpr (Cfg::pkacc) out[TF * s] = accp[s].x + accp[s].y;
@@ -473,35 +476,58 @@ size_t welch_workspace(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int npe
 extern const float* window_table(gj_ctx* ctx, int n);
 
 template <int N>
-static void welch_launch(gj_ctx* ctx, const uint8_t* d_iq, const WelchPlan& pl, float* partial) {
-    hipLaunchKernelGGL(welch_kernel<N>, dim3(pl.g.nchunks * pl.g.splits), dim3(kBlockThreads), 0, ctx->stream, d_iq,
-                       pl.g, ctx->d_twiddle, window_table(ctx, N), partial);
+static void welch_launch(gj_ctx* ctx, const uint8_t* d_iq, const WelchPlan& pl, float* partial, unsigned c0, unsigned c1) {
+    hipLaunchKernelGGL(welch_kernel<N>, dim3((c1 - c0) * pl.g.splits), dim3(kBlockThreads), 0, ctx->stream, d_iq, pl.g,
+                       ctx->d_twiddle, window_table(ctx, N), partial, c0 * pl.g.splits);
 }
 
-int launch_welch(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_samples, int nperseg, double fs,
-                 int flags, float* d_psd, float* d_psd_db, size_t plan_bytes) {
-    WelchPlan pl;
+// The transform of a capture in three steps, so that chunk ranges can be launched while later chunks are still on
+// their way to HBM (gj_ingest_*): begin (plan; `partial` = where the per-workgroup spectra go), range (chunks
+// [c0, c1)), end (fixed-order sum, scale, fftshift, dB).  launch_welch = begin + one range + end.
+int welch_begin(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int nperseg, double fs, size_t plan_bytes, WelchJob& job) {
     if (!(fs > 0.0)) return fail(ctx, GJ_ERR_INVALID, "fs must be > 0");
+    WelchPlan pl;
     if (!welch_plan(ctx, nbytes, chunk_samples, nperseg, fs, pl, plan_bytes))
         return fail(ctx, GJ_ERR_UNSUPPORTED, "nperseg must be a power of two in [16, 4096] and <= chunk_samples, chunk_samples < 2^31 - nperseg");
-    if ((reinterpret_cast<uintptr_t>(d_iq) & 1) != 0) return fail(ctx, GJ_ERR_INVALID, "capture must be 2-byte aligned");
-    if (pl.rows == 0) return GJ_OK;
     if ((unsigned long long)pl.g.nchunks * pl.g.splits > 0x7fffffffull) return fail(ctx, GJ_ERR_UNSUPPORTED, "too many chunks");
-    int rc = ensure_workspace(ctx, pl.ws_bytes);
-    if (rc) return rc;
-    float* partial = reinterpret_cast<float*>(ctx->ws);
-    switch (nperseg) {
-        case 16: welch_launch<16>(ctx, d_iq, pl, partial); break;
-        case 32: welch_launch<32>(ctx, d_iq, pl, partial); break;
-        case 64: welch_launch<64>(ctx, d_iq, pl, partial); break;
-        case 128: welch_launch<128>(ctx, d_iq, pl, partial); break;
-        case 256: welch_launch<256>(ctx, d_iq, pl, partial); break;
-        case 512: welch_launch<512>(ctx, d_iq, pl, partial); break;
-        case 1024: welch_launch<1024>(ctx, d_iq, pl, partial); break;
-        case 2048: welch_launch<2048>(ctx, d_iq, pl, partial); break;
-        default: welch_launch<4096>(ctx, d_iq, pl, partial); break;
+    static_assert(sizeof(WelchPlan) <= sizeof(job.plan), "WelchJob::plan too small");
+    memcpy(job.plan, &pl, sizeof(pl));
+    job.nperseg = nperseg;
+    job.rows = pl.rows;
+    job.ws_bytes = pl.ws_bytes;
+    job.partial = nullptr;
+    return GJ_OK;
+}
+
+int welch_range(gj_ctx* ctx, const WelchJob& job, const uint8_t* d_iq, size_t c0, size_t c1) {
+    WelchPlan pl;
+    memcpy(&pl, job.plan, sizeof(pl));
+    if (c1 > pl.rows) c1 = pl.rows;
+    if (c0 >= c1) return GJ_OK;
+    if ((reinterpret_cast<uintptr_t>(d_iq) & 1) != 0) return fail(ctx, GJ_ERR_INVALID, "capture must be 2-byte aligned");
+    float* partial = job.partial;
+    const unsigned a = (unsigned)c0, b = (unsigned)c1;
+    switch (job.nperseg) {
+        case 16: welch_launch<16>(ctx, d_iq, pl, partial, a, b); break;
+        case 32: welch_launch<32>(ctx, d_iq, pl, partial, a, b); break;
+        case 64: welch_launch<64>(ctx, d_iq, pl, partial, a, b); break;
+        case 128: welch_launch<128>(ctx, d_iq, pl, partial, a, b); break;
+        case 256: welch_launch<256>(ctx, d_iq, pl, partial, a, b); break;
+        case 512: welch_launch<512>(ctx, d_iq, pl, partial, a, b); break;
+        case 1024: welch_launch<1024>(ctx, d_iq, pl, partial, a, b); break;
+        case 2048: welch_launch<2048>(ctx, d_iq, pl, partial, a, b); break;
+        default: welch_launch<4096>(ctx, d_iq, pl, partial, a, b); break;
     }
     GJ_LAUNCH_CHECK(ctx);
+    return GJ_OK;
+}
+
+int welch_end(gj_ctx* ctx, const WelchJob& job, int flags, float* d_psd, float* d_psd_db) {
+    WelchPlan pl;
+    memcpy(&pl, job.plan, sizeof(pl));
+    if (pl.rows == 0) return GJ_OK;
+    const int nperseg = job.nperseg;
+    float* partial = job.partial;
     const bool aligned = ((reinterpret_cast<uintptr_t>(d_psd) | reinterpret_cast<uintptr_t>(d_psd_db)) & 15) == 0;
     if (aligned)
         hipLaunchKernelGGL(welch_finalize_kernel, dim3((nperseg / 4 + 255) / 256, pl.g.nchunks), dim3(256), 0, ctx->stream,
@@ -513,6 +539,21 @@ int launch_welch(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_s
                            (float)pl.scale_full, (float)pl.scale_last, (flags & GJ_WELCH_SHIFT) ? 1 : 0, d_psd, d_psd_db);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
+}
+
+int launch_welch(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_samples, int nperseg, double fs,
+                 int flags, float* d_psd, float* d_psd_db, size_t plan_bytes) {
+    WelchJob job;
+    int rc = welch_begin(ctx, nbytes, chunk_samples, nperseg, fs, plan_bytes, job);
+    if (rc) return rc;
+    if ((reinterpret_cast<uintptr_t>(d_iq) & 1) != 0) return fail(ctx, GJ_ERR_INVALID, "capture must be 2-byte aligned");
+    if (job.rows == 0) return GJ_OK;
+    rc = ensure_workspace(ctx, job.ws_bytes);
+    if (rc) return rc;
+    job.partial = reinterpret_cast<float*>(ctx->ws);
+    rc = welch_range(ctx, job, d_iq, 0, job.rows);
+    if (rc) return rc;
+    return welch_end(ctx, job, flags, d_psd, d_psd_db);
 }
 
 }   // namespace gj

@@ -55,12 +55,15 @@ _resident = {}            # (realpath, size, mtime_ns) -> Capture, insertion ord
 _resident_lock = __import__("threading").Lock()
 
 
-def resident_capture(path) -> "Capture":
+def resident_capture(path, **ingest) -> "Capture":
     """The capture file ``path`` in HBM on the default device, uploaded on first use and kept
     (process-wide, least-recently-used eviction above GPSJAM_RESIDENT_GIB, default 64 of the
     288 GB; an evicted capture is freed once nobody holds it any more): the worker's power scan, the RSSI solver and the PSD script all read the same
     files (worker.py:209-217 -> :590-600 -> triangulateRSSI.py:29), and each used to pay its own
-    host->device pass.  Raises FileNotFoundError like open()."""
+    host->device pass.  ``ingest`` (keyword arguments of ``Device.ingest``): what the caller is about to
+    compute -- on the first use of a file it is computed WHILE the file uploads and rides on the Capture; a
+    file that is already resident is returned as it is (the caller's call then runs on it as usual).
+    Raises FileNotFoundError like open()."""
     import os
     st = os.stat(path)
     key = (os.path.realpath(path), st.st_size, st.st_mtime_ns)
@@ -75,7 +78,7 @@ def resident_capture(path) -> "Capture":
             # eviction only drops the cache's reference: a caller that still holds the Capture (a scan
             # running in another thread) keeps it alive, and its memory is freed when that reference goes
             _resident.pop(next(iter(_resident)))
-        cap = dev.capture(path)
+        cap = dev.ingest(path, **ingest) if ingest else dev.capture(path)
         _resident[key] = cap
         return cap
 
@@ -170,9 +173,22 @@ class Capture:
 
     uploads = 0
 
+    @classmethod
+    def _adopt(cls, dev: "Device", ptr: int, nbytes: int, path=None) -> "Capture":
+        """A Capture around a device pointer the library has just handed out (gj_ingest_*)."""
+        self = cls.__new__(cls)
+        self.dev, self.ptr, self.nbytes, self.path = dev, int(ptr or 0), int(nbytes), path
+        self.results, self.ingest_ms = {}, None
+        Capture.uploads += 1
+        return self
+
     def __init__(self, dev: "Device", source, offset: int = 0, max_bytes: int = 0):
         import os
         self.dev = dev
+        # results computed while the capture was uploaded (Device.ingest), keyed by the call that would recompute
+        # them: ("chunk_power", chunk_bytes, eps, odd_chunk_zero), ("amp_stats", threshold), ("onset", noise_samples,
+        # window, factor), ("welch", chunk_samples, nperseg, fs, shift)
+        self.results, self.ingest_ms = {}, None
         p, n = C.c_void_p(), C.c_size_t(0)
         if isinstance(source, (str, bytes, os.PathLike)):
             self.path = os.fspath(source)
@@ -241,6 +257,57 @@ class Device:
     def capture(self, source, offset: int = 0, max_bytes: int = 0) -> Capture:
         """Upload a capture file (path) or a uint8 array once; see ``Capture``."""
         return Capture(self, source, offset, max_bytes)
+
+    def ingest(self, source, *, chunk_bytes: int = 65536, eps: float = 1e-10, odd_chunk_zero: bool = False,
+               rssi_threshold: float = 0.0, noise_samples: int = 200000, window: int = 1000, factor: float = 50.0,
+               welch=None, fs: float = 2.048e6, shift: bool = True, want_db: bool = False, offset: int = 0,
+               max_bytes: int = 0) -> Capture:
+        """Upload a capture file (path) or uint8 array AND analyse it while it uploads (gj_ingest_*: the kernels run
+        on the 16-MiB pieces that have landed).  ``chunk_bytes`` != 0: the fused scan (K1 power map, K3 amplitude
+        statistics at ``rssi_threshold``, K4 onset); ``welch=(chunk_samples, nperseg)``: the PSD waterfall.  The
+        results ride on the returned Capture (``.results``) and are handed out by ``chunk_power`` / ``amp_stats`` /
+        ``onset`` / ``welch`` when these are called on it with the same parameters -- bit-identical to what those
+        calls compute on an uploaded capture, without a second pass."""
+        import os
+        plan = _ffi.IngestPlan(int(chunk_bytes), float(eps), _ffi.GJ_CP_ODD_CHUNK_ZERO if odd_chunk_zero else 0,
+                               float(rssi_threshold), int(noise_samples), int(window), float(factor),
+                               int(welch[0]) if welch else 0, int(welch[1]) if welch else 0,
+                               _ffi.GJ_WELCH_SHIFT if shift else 0, float(fs))
+        is_path = isinstance(source, (str, bytes, os.PathLike))
+        if is_path:
+            path = os.fspath(source)
+            size = os.stat(path).st_size                     # FileNotFoundError like open()
+            nbytes = max(0, size - int(offset))
+            if max_bytes:
+                nbytes = min(nbytes, int(max_bytes))
+        else:
+            path = None
+            raw = as_u8(source)
+            if offset or max_bytes:
+                raw = raw[offset:offset + max_bytes] if max_bytes else raw[offset:]
+            nbytes = int(raw.size)
+        n_chunks = self._lib.gj_chunk_count(nbytes, chunk_bytes) if chunk_bytes else 0
+        rows = self._lib.gj_welch_rows(nbytes, welch[0], welch[1]) if welch else 0
+        power = np.empty(n_chunks, np.float32)
+        nper = int(welch[1]) if welch else 0
+        psd = np.empty((rows, nper), np.float32)
+        db = np.empty((rows, nper), np.float32) if (welch and want_db) else None
+        res, p = _ffi.IngestResult(), C.c_void_p()
+        args = (C.byref(plan), power.ctypes.data, power.size, psd.ctypes.data, db.ctypes.data if db is not None else None,
+                psd.size, C.byref(res), C.byref(p))
+        if is_path:
+            self._check(self._lib.gj_ingest_file(self._ctx, os.fsencode(path), int(offset), int(max_bytes), *args))
+        else:
+            self._check(self._lib.gj_ingest_u8(self._ctx, raw.ctypes.data if raw.size else None, raw.size, *args))
+        cap = Capture._adopt(self, p.value, res.nbytes, path)
+        cap.ingest_ms = (float(res.upload_ms), float(res.total_ms))
+        if chunk_bytes and n_chunks:
+            cap.results[("chunk_power", int(chunk_bytes), float(np.float32(eps)), bool(odd_chunk_zero))] = power
+            cap.results[("amp_stats", float(np.float32(rssi_threshold)))] = AmpStats.from_buffer_copy(bytes(res.amp))
+            cap.results[("onset", int(noise_samples), int(window), float(np.float32(factor)))] = Onset.from_buffer_copy(bytes(res.onset))
+        if welch and rows:
+            cap.results[("welch", int(welch[0]), nper, float(fs), bool(shift))] = (psd, db)
+        return cap
 
     @staticmethod
     def _input(raw):
@@ -317,6 +384,10 @@ class Device:
     # ------------------------------------------------------------------ host arrays
     def chunk_power(self, raw, chunk_bytes: int = 65536, eps: float = 1e-10,
                     odd_chunk_zero: bool = False) -> np.ndarray:
+        if isinstance(raw, Capture):
+            hit = raw.results.get(("chunk_power", int(chunk_bytes), float(np.float32(eps)), bool(odd_chunk_zero)))
+            if hit is not None:
+                return hit.copy()
         ptr, nbytes, _keep = self._input(raw)
         n = self._lib.gj_chunk_count(nbytes, chunk_bytes)
         out = np.empty(n, np.float32)
@@ -331,6 +402,10 @@ class Device:
     def welch(self, raw, chunk_samples: int = 2048000, nperseg: int = 1024, fs: float = 2.048e6,
               shift: bool = True, want_db: bool = True):
         """(psd[rows, nperseg], psd_db[rows, nperseg] | None), float32."""
+        if isinstance(raw, Capture):
+            hit = raw.results.get(("welch", int(chunk_samples), int(nperseg), float(fs), bool(shift)))
+            if hit is not None and (hit[1] is not None or not want_db):
+                return hit[0].copy(), (hit[1].copy() if want_db else None)
         ptr, nbytes, _keep = self._input(raw)
         rows = self._lib.gj_welch_rows(nbytes, chunk_samples, nperseg)
         psd = np.empty((rows, nperseg), np.float32)
@@ -344,6 +419,10 @@ class Device:
         return psd, db
 
     def amp_stats(self, raw, threshold: float) -> AmpStats:
+        if isinstance(raw, Capture):
+            hit = raw.results.get(("amp_stats", float(np.float32(threshold))))
+            if hit is not None:
+                return AmpStats.from_buffer_copy(bytes(hit))
         ptr, nbytes, _keep = self._input(raw)
         out, ms = AmpStats(), C.c_float(0)
         self._check(self._lib.gj_amp_stats_u8(self._ctx, ptr, nbytes, threshold,
@@ -353,6 +432,10 @@ class Device:
 
     def onset(self, raw, noise_samples: int = 200000, window: int = 1000,
               factor: float = 50.0) -> Onset:
+        if isinstance(raw, Capture):
+            hit = raw.results.get(("onset", int(noise_samples), int(window), float(np.float32(factor))))
+            if hit is not None:
+                return Onset.from_buffer_copy(bytes(hit))
         ptr, nbytes, _keep = self._input(raw)
         out, ms = Onset(), C.c_float(0)
         self._check(self._lib.gj_onset_u8(self._ctx, ptr, nbytes, noise_samples,

@@ -52,6 +52,18 @@ class Onset(C.Structure):
         return self.start_index >= 0 and self.margin_hit < self.NEAR_TIE
 
 
+class IngestPlan(C.Structure):
+    """gj_ingest_plan (include/gpsjam.h): what gj_ingest_* computes while the capture is uploaded."""
+    _fields_ = [("chunk_bytes", C.c_size_t), ("eps", C.c_float), ("power_flags", C.c_int),
+                ("rssi_threshold", C.c_float), ("noise_samples", C.c_int), ("window", C.c_int), ("factor", C.c_float),
+                ("chunk_samples", C.c_size_t), ("nperseg", C.c_int), ("welch_flags", C.c_int), ("fs", C.c_double)]
+
+
+class IngestResult(C.Structure):
+    _fields_ = [("nbytes", C.c_size_t), ("n_chunks", C.c_size_t), ("rows", C.c_size_t), ("amp", AmpStats),
+                ("onset", Onset), ("upload_ms", C.c_float), ("total_ms", C.c_float)]
+
+
 class PartView(C.Structure):
     """gj_part_view: one part of a capture split over GPUs (include/gpsjam.h)."""
     _fields_ = [("d_buf", C.c_void_p), ("buf_bytes", C.c_size_t), ("buf_first_byte", C.c_size_t),
@@ -114,6 +126,10 @@ SIGNATURES = {
     "gj_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
     "gj_upload": (_i, [_vp, _vp, _sz, C.POINTER(_vp)]),
     "gj_upload_file": (_i, [_vp, C.c_char_p, _sz, _sz, C.POINTER(_vp), _psz]),
+    "gj_ingest_u8": (_i, [_vp, _vp, _sz, C.POINTER(IngestPlan), _vp, _sz, _vp, _vp, _sz, C.POINTER(IngestResult),
+                          C.POINTER(_vp)]),
+    "gj_ingest_file": (_i, [_vp, C.c_char_p, _sz, _sz, C.POINTER(IngestPlan), _vp, _sz, _vp, _vp, _sz,
+                            C.POINTER(IngestResult), C.POINTER(_vp)]),
     "gj_timer_start": (_i, [_vp]),
     "gj_timer_stop": (_i, [_vp, _pf]),
     "gj_chunk_count": (_sz, [_sz, _sz]),

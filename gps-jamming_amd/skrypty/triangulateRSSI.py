@@ -71,7 +71,9 @@ def _amplitude_statistics(iq_filename, threshold):
     """('ok', first_index, np.float32 mean amplitude) from the GPU, or ('unreadable' |
     'below_threshold', None, None).  Raises if the HIP library / GPU is unavailable."""
     try:
-        cap = gpsjam.resident_capture(iq_filename)       # uploaded once per file, shared with the power scan
+        # uploaded once per file, shared with the power scan; a file seen for the first time is analysed while it
+        # uploads (the amplitude statistics ride on the capture)
+        cap = gpsjam.resident_capture(iq_filename, rssi_threshold=float(threshold))
     except FileNotFoundError:
         print(f"BŁĄD: Plik '{iq_filename}' nie został znaleziony.")
         return 'unreadable', None, None

@@ -41,7 +41,8 @@ def analyze_full_file(filename, fft_size=FFT_SIZE, sample_rate=SAMPLE_RATE, chun
     print("Przetwarzanie... to może chwilę potrwać.")
 
     # one upload; K2 and the byte histogram both run on the device-resident capture
-    cap = gpsjam.resident_capture(filename)
+    cap = gpsjam.resident_capture(filename, chunk_bytes=0, welch=(chunk_size, fft_size), fs=sample_rate, shift=True,
+                                  want_db=True)     # a file seen for the first time: K2 runs while it uploads
     dev = cap.dev
     _, psd_db = dev.welch(cap, chunk_samples=chunk_size, nperseg=fft_size, fs=sample_rate, shift=True, want_db=True)
     histogram = dev.byte_histogram(cap, chunk_size, fft_size, 100)                   # raw_chunk[::100], :35

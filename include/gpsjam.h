@@ -218,6 +218,39 @@ int gj_stream_scan_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes,
                        float rssi_threshold, gj_amp_stats* d_amp,
                        int noise_samples, int window, float factor, gj_onset* d_onset);
 
+/* ------------------------------------------------- overlapped ingest ----------------- */
+/* Overlapped ingest: upload a capture AND analyse it, with the kernels running on the 16-MiB pieces that have
+ * landed in HBM while the rest is still on its way (the reference reads, then computes: worker.py:209-230,
+ * triangulateRSSI.py:29-31, widmo_plot.py:26-54).  What is computed: with chunk_bytes != 0 the fused scan (K1 power
+ * map, K3 amplitude statistics, K4 onset -- gj_stream_scan_dev), with nperseg != 0 the Welch waterfall (K2 --
+ * gj_welch_dev).  Results are bit-identical to gj_upload* followed by those calls.  The capture stays resident:
+ * *dptr is a device pointer like gj_upload's (free with gj_free), usable with every "*_dev" and "*_u8" entry point. */
+typedef struct gj_ingest_plan {
+    size_t chunk_bytes; /* K1 power chunks; 0: no scan (K3 and K4 are skipped too) */
+    float eps;
+    int power_flags; /* GJ_CP_* */
+    float rssi_threshold; /* K3 */
+    int noise_samples, window; /* K4 */
+    float factor;
+    size_t chunk_samples; /* K2 */
+    int nperseg; /* 0: no PSD */
+    int welch_flags; /* GJ_WELCH_* */
+    double fs;
+} gj_ingest_plan;
+typedef struct gj_ingest_result {
+    size_t nbytes, n_chunks, rows;
+    gj_amp_stats amp;
+    gj_onset onset;
+    float upload_ms; /* wall clock until the last piece had been queued and its bounce buffer released */
+    float total_ms;  /* wall clock of the whole call: results on the host */
+} gj_ingest_result;
+int gj_ingest_u8(gj_ctx* ctx, const uint8_t* host, size_t nbytes, const gj_ingest_plan* plan, float* power,
+                 size_t power_cap, float* psd, float* psd_db, size_t psd_cap_floats, gj_ingest_result* result,
+                 void** dptr);
+int gj_ingest_file(gj_ctx* ctx, const char* path, size_t offset, size_t max_bytes, const gj_ingest_plan* plan,
+                   float* power, size_t power_cap, float* psd, float* psd_db, size_t psd_cap_floats,
+                   gj_ingest_result* result, void** dptr);
+
 /* ------------------------------------------------- K5: TDOA cross-correlation ------- */
 /* Replaces signal.correlate(sig1, sig0, 'full') + argmax|.| - (N-1)
  * (skrypty/triangulateTDOA.py:80-89) for every requested antenna pair.

@@ -23,6 +23,7 @@ class FakeCapture:
         else:
             self.raw = np.ascontiguousarray(np.asarray(source, dtype=np.uint8))
         self.nbytes, self.ptr = int(self.raw.size), 1
+        self.results, self.ingest_ms = {}, None
 
     def free(self):
         self.ptr = 0
@@ -37,6 +38,9 @@ class OracleDevice:
 
     def capture(self, source, offset=0, max_bytes=0):
         return FakeCapture(self, source)
+
+    def ingest(self, source, **kw):
+        return FakeCapture(self, source)          # the test double computes on demand
 
     def byte_histogram(self, cap, chunk_samples=2048000, nperseg=1024, stride=100):
         _, _, samples = orc.widmo_waterfall(_bytes_of(cap), nperseg=nperseg, chunk_samples=chunk_samples)

@@ -266,3 +266,69 @@ def test_near_tie_on_a_gibibyte_is_resolved_in_a_few_windows(dev, monkeypatch, c
     assert tdoa.near_tie_events and seen == [n - 300000 - 1000 + 490]
     assert any("rounding band" in m for m in caplog.messages)
     assert dt < 1.0, dt
+
+
+# ----------------------------------------------------------------------------- ingest overlapped with compute
+def _fresh(dev, raw, welch):
+    """upload-then-run: the established order"""
+    with dev.capture(raw) as cap:
+        pm = dev.chunk_power(cap)
+        st = dev.amp_stats(cap, 0.1)
+        on = dev.onset(cap)
+        psd, db = dev.welch(cap, chunk_samples=welch[0], nperseg=welch[1], want_db=True)
+    return pm, st, on, psd, db
+
+
+@pytest.mark.parametrize("nbytes", [160 * (1 << 20) + 4097, 70 * (1 << 20), 5_000_001, 131072, 2])
+def test_ingest_is_bit_identical_to_upload_then_run(dev, tmp_path, nbytes):
+    """gj_ingest_*: the fused scan and K2 run on the 16-MiB pieces that have landed while the rest uploads (above
+    64 MiB; below, one copy then the kernels).  Power map, amplitude statistics, onset record and PSD rows must be
+    the bits upload-then-run gives -- from a host array and from a file, odd lengths included."""
+    base = generate(StreamSpec(seed=83, jam_start=900_000, jam_end=1 << 40, jam_sigma=50.0), 1_500_000)
+    raw = np.tile(base, nbytes // base.size + 1)[:nbytes].copy()
+    welch = (2048000, 4096) if nbytes > (1 << 23) else (65536, 256)
+    pm, st, on, psd, db = _fresh(dev, raw, welch)
+    path = tmp_path / "cap.bin"
+    raw.tofile(path)
+    for source in (raw, str(path)):
+        cap = dev.ingest(source, rssi_threshold=0.1, welch=welch, want_db=True)
+        try:
+            assert cap.nbytes == nbytes and len(cap.results) == (4 if psd.size else (3 if pm.size else 0)) or nbytes < 131072
+            uploads = gpsjam.Capture.uploads
+            np.testing.assert_array_equal(dev.chunk_power(cap), pm)            # served from the ingest's results
+            a = dev.amp_stats(cap, 0.1)
+            assert (a.first_index, a.count, a.sum, a.mean) == (st.first_index, st.count, st.sum, st.mean)
+            o = dev.onset(cap)
+            assert bytes(o) == bytes(on)
+            p2, d2 = dev.welch(cap, chunk_samples=welch[0], nperseg=welch[1], want_db=True)
+            assert p2.tobytes() == psd.tobytes() and d2.tobytes() == db.tobytes()
+            assert gpsjam.Capture.uploads == uploads
+            # other parameters are not in the results: computed on the resident capture, as always
+            np.testing.assert_array_equal(dev.chunk_power(cap, chunk_bytes=131072), dev.chunk_power(raw, chunk_bytes=131072))
+            assert dev.amp_stats(cap, 0.0).count == nbytes // 2
+            np.testing.assert_array_equal(cap.download(0, min(nbytes, 4096)), raw[:4096])
+            if nbytes > 4096:
+                np.testing.assert_array_equal(cap.download(nbytes - 4096), raw[-4096:])
+        finally:
+            cap.free()
+
+
+def test_ingest_without_scan_or_without_psd(dev):
+    raw = generate(StreamSpec(seed=84, jam_start=300_000, jam_end=1 << 40, jam_sigma=50.0), 40_000_000)
+    with dev.capture(raw) as ref:
+        pm = dev.chunk_power(ref)
+        psd, _ = dev.welch(ref, chunk_samples=2048000, nperseg=1024, want_db=False)
+    a = dev.ingest(raw, chunk_bytes=0, welch=(2048000, 1024))
+    b = dev.ingest(raw)
+    try:
+        assert list(a.results) == [("welch", 2048000, 1024, 2.048e6, True)] and sorted(k[0] for k in b.results) == ["amp_stats", "chunk_power", "onset"]
+        assert dev.welch(a, chunk_samples=2048000, nperseg=1024, want_db=False)[0].tobytes() == psd.tobytes()
+        np.testing.assert_array_equal(dev.chunk_power(b), pm)
+        assert a.ingest_ms[1] >= a.ingest_ms[0] > 0
+    finally:
+        a.free()
+        b.free()
+    with pytest.raises(gpsjam.GpsJamError):
+        dev.ingest(raw[:1 << 20], welch=(2048000, 1000))                     # not a power of two
+    with pytest.raises(FileNotFoundError):
+        dev.ingest("/nonexistent/capture.bin")
