@@ -355,6 +355,23 @@ __device__ __forceinline__ float amp_of_half(unsigned w, unsigned k2, unsigned k
     return __fsqrt_rn((float)m) * hs;
 }
 
+__device__ __forceinline__ unsigned m_of(unsigned i8, unsigned q8, int o2 = 255) {
+    const int vi = 2 * (int)i8 - o2, vq = 2 * (int)q8 - o2;
+    return (unsigned)(vi * vi + vq * vq);   // = 4 |z|^2
+}
+
+// (2I-255)^2 + (2Q-255)^2 of sample HI (0: bytes 0-1, 1: bytes 2-3) of the dword w: v_perm_b32 spreads (I, Q)
+// into the two 16-bit halves, v_pk_mad_i16 forms (2I-255, 2Q-255), v_dot2_i32_i16 squares and adds
+template <int HI>
+__device__ __forceinline__ int msq_of_half(unsigned w, unsigned k2, unsigned km255) {
+    const unsigned spread = __builtin_amdgcn_perm(w, w, HI ? 0x0C030C02u : 0x0C010C00u);
+    unsigned h;
+    int m;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(h) : "v"(spread), "v"(k2), "v"(km255));
+    asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(m) : "v"(h));
+    return m;
+}
+
 constexpr size_t kAmpTileSamples = kScanTile / 2;
 
 struct AmpTile {
@@ -377,6 +394,9 @@ __global__ __launch_bounds__(kScanThreads) void amp_tiles_kernel(const uint8_t* 
     const uint4* v = reinterpret_cast<const uint4*>(iq + 2 * s0);
     unsigned k2 = 0x00020002u, km255 = pk_minus_off2(up.off2);
     asm volatile("" : "+v"(k2), "+v"(km255));   // both in VGPRs (one constant-bus slot per op)
+    // The arithmetic -- and its ORDER -- is that of the fused scan (stream_scan_kernel): per 16-byte vector the eight
+    // sqrt(m) are added in float, the vector sums in double, the tile total is scaled by half_scale once; the ragged
+    // end of the stream (< 8 samples) is added by thread 0.  K3 alone and K3 inside the fused pass give the same bits.
     for (size_t gidx = tid; gidx < nfull; gidx += kScanThreads) {
         const uint4 w = v[gidx];
         const unsigned ws[4] = {w.x, w.y, w.z, w.w};
@@ -384,18 +404,27 @@ __global__ __launch_bounds__(kScanThreads) void amp_tiles_kernel(const uint8_t* 
         const long long base = (long long)(s0 + gidx * 8);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float a0 = amp_of_half<0>(ws[k], k2, km255, up.half_scale), a1 = amp_of_half<1>(ws[k], k2, km255, up.half_scale);
-            part += a0;
-            part += a1;
-            if (a0 > thr && base + 2 * k < first) first = base + 2 * k;
-            if (a1 > thr && base + 2 * k + 1 < first) first = base + 2 * k + 1;
+            const float r0 = __fsqrt_rn((float)msq_of_half<0>(ws[k], k2, km255)), r1 = __fsqrt_rn((float)msq_of_half<1>(ws[k], k2, km255));
+            part += r0;
+            part += r1;
+            if (r0 * up.half_scale > thr && base + 2 * k < first) first = base + 2 * k;
+            if (r1 * up.half_scale > thr && base + 2 * k + 1 < first) first = base + 2 * k + 1;
         }
         sum += (double)part;
     }
-    for (size_t s = s0 + nfull * 8 + tid; s < s1; s += kScanThreads) {
-        const float a = amp_of(iq[2 * s], iq[2 * s + 1], up);
-        sum += (double)a;
-        if (a > thr && (long long)s < first) first = (long long)s;
+    if (aligned) {
+        if (tid == 0)
+            for (size_t s = s0 + nfull * 8; s < s1; ++s) {
+                const float r = __fsqrt_rn((float)m_of(iq[2 * s], iq[2 * s + 1], up.off2));
+                sum += (double)r;
+                if (r * up.half_scale > thr && (long long)s < first) first = (long long)s;
+            }
+    } else {
+        for (size_t s = s0 + tid; s < s1; s += kScanThreads) {
+            const float r = __fsqrt_rn((float)m_of(iq[2 * s], iq[2 * s + 1], up.off2));
+            sum += (double)r;
+            if (r * up.half_scale > thr && (long long)s < first) first = (long long)s;
+        }
     }
     sum = wave_sum_f64(sum);
 #pragma unroll
@@ -407,7 +436,7 @@ __global__ __launch_bounds__(kScanThreads) void amp_tiles_kernel(const uint8_t* 
     __syncthreads();
     if (tid == 0) {
         AmpTile t;
-        t.sum = ((rs[0] + rs[1]) + (rs[2] + rs[3]));
+        t.sum = ((rs[0] + rs[1]) + (rs[2] + rs[3])) * (double)up.half_scale;
         long long f = rf[0];
         for (int k = 1; k < 4; ++k) f = rf[k] < f ? rf[k] : f;
         t.first = f;
@@ -627,10 +656,6 @@ __device__ __forceinline__ float onset_threshold(const OnsetScratch* sc, int noi
     return noise * factor;
 }
 
-__device__ __forceinline__ unsigned m_of(unsigned i8, unsigned q8, int o2 = 255) {
-    const int vi = 2 * (int)i8 - o2, vq = 2 * (int)q8 - o2;
-    return (unsigned)(vi * vi + vq * vq);   // = 4 |z|^2
-}
 
 __global__ __launch_bounds__(kScanThreads) void onset_noise_kernel(const uint8_t* __restrict__ iq, int noise_samples,
                                                                    OnsetScratch* __restrict__ sc, int o2) {
@@ -940,17 +965,6 @@ __device__ __forceinline__ int wave_sum_lane63(int v) {
     return v;
 }
 
-// (2I-255)^2 + (2Q-255)^2 of sample HI (0: bytes 0-1, 1: bytes 2-3) of the dword w: v_perm_b32 spreads (I, Q)
-// into the two 16-bit halves, v_pk_mad_i16 forms (2I-255, 2Q-255), v_dot2_i32_i16 squares and adds
-template <int HI>
-__device__ __forceinline__ int msq_of_half(unsigned w, unsigned k2, unsigned km255) {
-    const unsigned spread = __builtin_amdgcn_perm(w, w, HI ? 0x0C030C02u : 0x0C010C00u);
-    unsigned h;
-    int m;
-    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(h) : "v"(spread), "v"(k2), "v"(km255));
-    asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(m) : "v"(h));
-    return m;
-}
 
 template <bool TRACK_FIRST>
 __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t* __restrict__ iq, size_t nsamples,

@@ -301,6 +301,9 @@ class Device:
             self._check(self._lib.gj_ingest_u8(self._ctx, raw.ctypes.data if raw.size else None, raw.size, *args))
         cap = Capture._adopt(self, p.value, res.nbytes, path)
         cap.ingest_ms = (float(res.upload_ms), float(res.total_ms))
+        for a in (power, psd, db):
+            if a is not None:
+                a.flags.writeable = False                    # handed out as they are on every matching call
         if chunk_bytes and n_chunks:
             cap.results[("chunk_power", int(chunk_bytes), float(np.float32(eps)), bool(odd_chunk_zero))] = power
             cap.results[("amp_stats", float(np.float32(rssi_threshold)))] = AmpStats.from_buffer_copy(bytes(res.amp))
@@ -387,7 +390,7 @@ class Device:
         if isinstance(raw, Capture):
             hit = raw.results.get(("chunk_power", int(chunk_bytes), float(np.float32(eps)), bool(odd_chunk_zero)))
             if hit is not None:
-                return hit.copy()
+                return hit                                   # read-only array computed while the capture uploaded
         ptr, nbytes, _keep = self._input(raw)
         n = self._lib.gj_chunk_count(nbytes, chunk_bytes)
         out = np.empty(n, np.float32)
@@ -405,7 +408,7 @@ class Device:
         if isinstance(raw, Capture):
             hit = raw.results.get(("welch", int(chunk_samples), int(nperseg), float(fs), bool(shift)))
             if hit is not None and (hit[1] is not None or not want_db):
-                return hit[0].copy(), (hit[1].copy() if want_db else None)
+                return hit[0], (hit[1] if want_db else None)   # read-only arrays computed while the capture uploaded
         ptr, nbytes, _keep = self._input(raw)
         rows = self._lib.gj_welch_rows(nbytes, chunk_samples, nperseg)
         psd = np.empty((rows, nperseg), np.float32)

@@ -54,8 +54,7 @@ def test_fused_scan_integer_offset_tracks_first_index(dev, thr):
         assert k >= lead
         assert (alone.first_index, alone.count) == (k, n - k)
         assert (fused.first_index, fused.count) == (alone.first_index, alone.count)
-        np.testing.assert_allclose(fused.sum, alone.sum, rtol=1e-7)     # per-tile float partial sums differ in order
-        np.testing.assert_allclose(fused.mean, alone.mean, rtol=1e-6)
+        assert fused.sum == alone.sum and fused.mean == alone.mean     # K3 alone and inside the fused pass: same bits
         np.testing.assert_allclose(fused.mean, amp[k:].mean(), rtol=1e-6)
     finally:
         dev.set_unpack()
@@ -63,8 +62,7 @@ def test_fused_scan_integer_offset_tracks_first_index(dev, thr):
     d = _fused(dev, raw, 0.0)
     assert (d.first_index, d.count) == (0, n)
     d2 = dev.amp_stats(raw, 0.0)
-    assert (d2.first_index, d2.count) == (d.first_index, d.count)
-    np.testing.assert_allclose(d2.sum, d.sum, rtol=1e-7)
+    assert (d2.first_index, d2.count, d2.sum) == (d.first_index, d.count, d.sum)
 
 
 def test_fused_scan_small_scale_threshold_between(dev):
@@ -77,8 +75,7 @@ def test_fused_scan_small_scale_threshold_between(dev):
         alone = dev.amp_stats(raw, thr)
         fused = _fused(dev, raw, thr)
         assert 0 < alone.first_index < n
-        assert (fused.first_index, fused.count) == (alone.first_index, alone.count)
-        np.testing.assert_allclose(fused.sum, alone.sum, rtol=1e-7)
+        assert (fused.first_index, fused.count, fused.sum) == (alone.first_index, alone.count, alone.sum)
     finally:
         dev.set_unpack()
 
