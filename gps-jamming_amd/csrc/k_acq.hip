@@ -516,7 +516,8 @@ int launch_acq_search(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t fi
     if (nsampchip < 0 || 4 * nsampchip >= nsamp || !(ctime > 0.0)) return fail(ctx, GJ_ERR_INVALID, "bad nsampchip / ctime");
     if ((reinterpret_cast<uintptr_t>(d_iq) & 1) != 0) return fail(ctx, GJ_ERR_INVALID, "capture must be 2-byte aligned");
     // step s reads samples [first + s nsamp, first + s nsamp + 2 nsamp)  (rcvgetbuff of 2*nsamp, then += nsamp)
-    const size_t need = first_sample + (size_t)(intg + 1) * nsamp;
+    if (first_sample > nbytes / 2) return fail(ctx, GJ_ERR_INVALID, "first_sample %zu is past the capture's %zu samples", first_sample, nbytes / 2);
+    const size_t need = first_sample + (size_t)(intg + 1) * nsamp;   // cannot wrap: first_sample <= nbytes / 2
     if (need > nbytes / 2) return fail(ctx, GJ_ERR_INVALID, "search needs samples up to %zu, capture has %zu", need, nbytes / 2);
     int rc = ensure_workspace(ctx, acq_workspace(nsamp, n_freq, n_prn, intg, d_power == nullptr));
     if (rc) return rc;

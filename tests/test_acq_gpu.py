@@ -81,6 +81,8 @@ def test_acq_all_32_prns_and_errors(dev):
             assert abs(r.doppler_hz - dop) <= 200.0 and abs(r.code_index - delay) <= 1
         with pytest.raises(gpsjam.GpsJamError):
             srch.search(cap, first_sample=2 * 2048)                  # the eleven milliseconds do not fit any more
+        with pytest.raises(gpsjam.GpsJamError):
+            srch.search(cap, first_sample=(1 << 64) - 4096)          # would wrap the bounds arithmetic
     srch.close()
 
 

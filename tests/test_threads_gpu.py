@@ -1,6 +1,7 @@
 """The library may be entered from several host threads (the GUI's QThread, its
-HTTP handler thread and the triangulation thread): calls on ONE context are serialised by its
-mutex, different contexts are independent.  Both patterns, concurrently, against the oracle."""
+HTTP handler thread and the triangulation thread): calls on ONE context each work in a lane of
+their own (the context's mutex is held only while kernels are enqueued), different contexts are
+independent.  Both patterns, concurrently, against the oracle."""
 import threading
 
 import numpy as np
