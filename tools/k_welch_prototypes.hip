@@ -1,3 +1,7 @@
+// FROZEN READING COPY (round 2): K2 with its measured-and-rejected variants (GJ_W_PRIO, GJ_W_RAWREUSE, GJ_W_SCANSUMS,
+// GJ_STAMPS).  Not part of the build: the production kernel is gps-jamming_amd/csrc/k_welch.hip; DESIGN.md section 4-5
+// records what each variant measured.
+
 // K2: fused uint8 unpack + periodic-Hann Welch PSD (gfx950).
 // Replaces skrypty/widmo_plot.py:38-52 including scipy.signal.welch(..., nperseg=N,
 // return_onesided=False) (widmo_plot.py:48; scipy/signal/_spectral_py.py _spectral_helper).
