@@ -445,21 +445,25 @@ def launch_ranks(n, argv, limit_s):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this driver
     env.setdefault("OMP_NUM_THREADS", "1")
     print("[bench] launching " + " ".join(cmd), file=sys.stderr, flush=True)
-    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    # same session and process group as this parent: whatever stops the parent's group stops the ranks too; a
+    # SIGTERM / SIGINT sent to the parent alone is handed on (torch.distributed.run takes its workers down on SIGTERM)
+    proc = subprocess.Popen(cmd, env=env)
+
+    def hand_on(signum, _frame):
+        if proc.poll() is None:
+            proc.send_signal(signal.SIGTERM)
+
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, hand_on)
     try:
         return proc.wait(timeout=limit_s)
     except subprocess.TimeoutExpired:
         print(f"[bench] ranks still running after {limit_s:.0f} s: stopping them", file=sys.stderr, flush=True)
-    except KeyboardInterrupt:
-        pass
-    try:                                        # exactly the process group this call started
-        os.killpg(proc.pid, signal.SIGTERM)
-        proc.wait(timeout=20)
-    except (subprocess.TimeoutExpired, ProcessLookupError):
-        try:
-            os.killpg(proc.pid, signal.SIGKILL)
-        except ProcessLookupError:
-            pass
+    proc.terminate()                            # exactly the child this call started
+    try:
+        proc.wait(timeout=30)
+    except subprocess.TimeoutExpired:
+        proc.kill()
         proc.wait()
     return 124
 

@@ -35,3 +35,17 @@ def test_abandoned_callers_do_not_block_the_context():
         out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "abandoned callers: ok" in out.stdout
+
+
+def test_c_consumer_of_ingest_and_capture_parts():
+    """tests/c_split_ingest.c: gj_ingest_u8 and the capture-part entry points from plain C -- bit-identical to
+    upload-then-run and to the unsplit capture."""
+    libdir = os.path.join(REPO, "gps-jamming_amd", "csrc")
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "c_split_ingest")
+        subprocess.run(["gcc", "-std=c11", "-O2", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"),
+                        os.path.join(REPO, "tests", "c_split_ingest.c"), "-o", exe, "-L", libdir, "-lgpsjam_hip",
+                        f"-Wl,-rpath,{libdir}"], check=True)
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "c_split_ingest OK" in out.stdout and "identical to the unsplit capture" in out.stdout
