@@ -57,12 +57,14 @@ void reap_retired(gj_ctx* ctx) {
 
 // ---- the only host-side waits of the library: entered WITHOUT the context lock ------------------------------
 int wait_stream(gj_ctx* ctx, hipStream_t stream) {
+    NoCancel nc;
     wait_hook(ctx, kWaitStream);
     GJ_HIP(ctx, hipStreamSynchronize(stream));
     return GJ_OK;
 }
 
 int wait_event(gj_ctx* ctx, hipEvent_t ev) {
+    NoCancel nc;
     wait_hook(ctx, kWaitEvent);
     GJ_HIP(ctx, hipEventSynchronize(ev));
     return GJ_OK;

@@ -120,9 +120,25 @@ inline int fail(gj_ctx* ctx, int code, const char* fmt, ...) {
                             hipGetErrorString(e__), __FILE__, __LINE__);                          \
     } while (0)
 
+// A thread is never CANCELLED inside the library: QThread.terminate() is pthread_cancel on POSIX, deferred
+// cancellation acts at the next cancellation point, and several sit inside a call (usleep, pread, joins, the
+// runtime's own waits).  Unwinding from there would run through the HIP runtime's frames and through the join of the
+// fill threads (std::terminate).  While one of these guards is alive a cancellation request stays pending; it takes
+// effect after the call has returned -- bounded by the call (tens of milliseconds per GiB), with nothing half done.
+// (A thread that is killed outright leaves no chance to defer anything: that case is what the lanes, the robust
+// mutex and the lock-free waits are for.)
+struct NoCancel {
+    int old = 0;
+    NoCancel() { (void)pthread_setcancelstate(PTHREAD_CANCEL_DISABLE, &old); }
+    ~NoCancel() { (void)pthread_setcancelstate(old, nullptr); }
+    NoCancel(const NoCancel&) = delete;
+    NoCancel& operator=(const NoCancel&) = delete;
+};
+
 // The context lock, for the ENQUEUE part of a call only.  Nothing that can block for long is done under it:
 // waits go through wait_event / wait_stream below, after the Guard has been left.
 struct Guard {
+    NoCancel nc;
     gj_ctx* c;
     explicit Guard(gj_ctx* ctx) : c(ctx) {
         if (pthread_mutex_lock(&c->mu) == EOWNERDEAD) {   // the previous owner died inside a critical section

@@ -108,6 +108,7 @@ void lane_checkin(gj_ctx* ctx, gj_lane* L) {
 namespace {
 
 struct LaneHold {
+    NoCancel nc;   // from check-out to check-in the calling thread owns buffers, events and (while copying) helper threads
     gj_ctx* ctx;
     gj_lane* L;
     explicit LaneHold(gj_ctx* c) : ctx(c), L(lane_checkout(c)) { (void)hipSetDevice(c->device); }

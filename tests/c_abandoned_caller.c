@@ -5,6 +5,8 @@
  *   A dies inside a 256-MiB gj_upload (staged copy)          -> its lane is taken back, the next call is correct
  *   B dies inside gj_chunk_power_u8, waiting for its event   -> same
  *   C dies as the OWNER of the context mutex                 -> the next locker recovers the mutex
+ *   D is pthread_cancel'ed (QThread.terminate() on POSIX) while inside gj_upload -> the call completes, the
+ *     cancellation takes effect after it has returned (the library defers it), nothing is unwound half way
  * gcc tests/c_abandoned_caller.c -Iinclude -Lgps-jamming_amd/csrc -lgpsjam_hip -lpthread */
 #define _GNU_SOURCE
 #include <pthread.h>
@@ -17,14 +19,31 @@
 #include "gpsjam.h"
 
 static __thread int doomed_site = 0;
+static volatile int inside_upload = 0, uploads_done = 0;
+static __thread int announce = 0;
 static void hook(void* arg, int site) {
     (void)arg;
+    if (announce && site == 3) inside_upload = 1;
     if (doomed_site && site == doomed_site) syscall(SYS_exit, 0); /* this thread only; nothing is unwound */
 }
 
 static gj_ctx* ctx;
 static uint8_t* big;
 static const size_t BIG = (size_t)256 << 20;
+
+static void* cancelled_in_upload(void* p) {
+    (void)p;
+    announce = 1;                               /* the hook below raises `inside_upload` at the staged-copy site */
+    for (;;) {
+        void* d = NULL;
+        if (gj_upload(ctx, big, BIG, &d) == GJ_OK) {
+            gj_free(ctx, d);
+            ++uploads_done;
+        }
+        pthread_testcancel();                   /* outside the library: here a pending cancellation may act */
+    }
+    return (void*)1;
+}
 
 static void* die_in_upload(void* p) {
     (void)p;
@@ -92,6 +111,20 @@ int main(void) {
         if (busy != 0) return 5;
     }
     if (reclaimed < 2 || deaths < 1) return 6;
+    /* D: cancelled while inside gj_upload */
+    {
+        void* ret = NULL;
+        pthread_create(&t, NULL, cancelled_in_upload, NULL);
+        while (!inside_upload) usleep(100);
+        pthread_cancel(t);                      /* the request arrives while the thread is inside the library */
+        pthread_join(t, &ret);
+        if (ret != PTHREAD_CANCELED) { fprintf(stderr, "the cancelled thread was not cancelled\n"); return 8; }
+        if (uploads_done < 1) { fprintf(stderr, "the upload was torn down half way (%d done)\n", uploads_done); return 8; }
+        if (check_power("after a caller was cancelled inside gj_upload")) return 4;
+        gj_debug_counters(ctx, &lanes, &busy, &reclaimed, &deaths);
+        printf("after a caller was cancelled inside gj_upload: %d upload(s) completed first, lanes %d busy %d\n", uploads_done, lanes, busy);
+        if (busy != 0) return 5;
+    }
     /* the context still uploads and frees */
     void* d = NULL;
     if (gj_upload(ctx, big, BIG, &d) != GJ_OK || gj_free(ctx, d) != GJ_OK) return 7;
