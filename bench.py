@@ -117,6 +117,10 @@ def main():
         import datetime
         limit = datetime.timedelta(seconds=300)   # a collective that never completes must end the run, not hang it
         if args.backend == "nccl":
+            # one node: RCCL's bootstrap needs no outside interface (the container's hostname may not resolve) and
+            # there is no InfiniBand to probe; the data path is xGMI peer-to-peer either way
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("NCCL_IB_DISABLE", "1")
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
         else:
             dist.init_process_group(backend=args.backend, timeout=limit)

@@ -62,6 +62,9 @@ class Communicator:
         addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
         port = int(port if port is not None else int(os.environ.get("MASTER_PORT", "29500")) + _PORT_OFFSET)
         lib = dev._lib
+        if addr in ("127.0.0.1", "localhost"):        # one node: see bench.py
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("NCCL_IB_DISABLE", "1")
         uid = C.create_string_buffer(ID_BYTES)
         if self.rank == 0:
             rc = lib.gj_comm_unique_id(uid)
