@@ -59,6 +59,9 @@
 // (72 -> 48 front-end instructions per thread), same VGPR count.
 #define GJ_W_CARRY 1
 #endif
+#ifndef GJ_W_CARRY_MASK
+#define GJ_W_CARRY_MASK 0x1400u   // bit k set: transform size 2^k carries.  1024 and 4096; 2048 spills with it (+2 %, measured)
+#endif
 #ifndef GJ_W_XPOSE
 #define GJ_W_XPOSE 1     // 1: N = 4096 uses the bank-conflict-free exchange schedule (fft_core.h X4096)
 #endif
@@ -114,9 +117,10 @@ struct WelchBins {   // (thread, slot) that ends up holding bin k
 // Two LDS buffers, used alternately by consecutive exchanges: a thread may scatter into one
 // while slower threads of the workgroup still gather from the other, so ONE barrier per
 // exchange (between scatter and gather) is enough.
-template <int N, int PASS>
+// `after_scatter0()` runs right behind the first scatter (see welch_passes_x4096)
+template <int N, int PASS, typename Mid>
 __device__ __forceinline__ void welch_passes(c2 (&v)[16], cf* lds0, cf* lds1, unsigned it, int base, int jl,
-                                             const c2 (&tw)[3][15], const InnerTw& ktw) {
+                                             const c2 (&tw)[3][15], const InnerTw& ktw, Mid&& after_scatter0) {
     constexpr int NP = fft_npass(N);
     fft_pass<N, PASS, GJ_W_TWOSTEP != 0, GJ_W_FMA != 0>(v, tw[PASS], ktw);
     if constexpr (PASS + 1 < NP) {
@@ -124,10 +128,11 @@ __device__ __forceinline__ void welch_passes(c2 (&v)[16], cf* lds0, cf* lds1, un
         const bool second = ((NP - 1) % 2 == 0) ? (PASS & 1) : ((it + PASS) & 1);
         cf* lds = (WelchCfg<N>::dbuf && second) ? lds1 : lds0;
         lds_scatter<N, PASS>(v, lds, base, jl);
+        if constexpr (PASS == 0) after_scatter0();
         __syncthreads();
         lds_gather<N>(v, lds, base, jl);
         if (!WelchCfg<N>::dbuf) __syncthreads();
-        welch_passes<N, PASS + 1>(v, lds0, lds1, it, base, jl, tw, ktw);
+        welch_passes<N, PASS + 1>(v, lds0, lds1, it, base, jl, tw, ktw, after_scatter0);
     }
 }
 
@@ -166,12 +171,20 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
     constexpr int SPAN = XP ? X4096::kSpan : lds_span(kBlockPoints);
     __shared__ cf lds0[SPAN];
     using Cfg = WelchCfg<N>;
-    constexpr bool HS = (B == 1) && (GJ_W_HALFSUM != 0);
+    // RUNS (transform groups of one wave or more, N >= 1024): group b of the workgroup walks a run of CONSECUTIVE
+    // segments (b-th slice of the workgroup's segments) instead of taking every B-th one, so that every step's first
+    // half segment is the previous step's second half for ALL these sizes, not only for N = 4096 (B = 1): the
+    // half-segment sums (HS) and the unpacked half (CARRY) are then carried from step to step.  Smaller transforms keep
+    // the interleaved order: their groups are fractions of a wave and consecutive groups read consecutive memory.
+    constexpr bool RUNS = (TF >= 64) && (GJ_W_HALFSUM != 0);
+    constexpr bool HS = RUNS;
     __shared__ cf lds1[Cfg::dbuf ? SPAN : 1];
     // (sum I, sum Q) per wave; three slots when half-segment sums are carried over (see HS below)
     __shared__ float wsum[3][B][WPF][2];
     const int tid = threadIdx.x;
-    const int b = tid / TF, jl0 = tid % TF;   // jl0: butterfly of pass 0 (input index jl0 + TF s)
+    // a transform group of one wave or more: its index is wave-uniform, so the run bookkeeping lives in SGPRs
+    const int b = (TF >= 64) ? __builtin_amdgcn_readfirstlane(tid / TF) : tid / TF;
+    const int jl0 = tid % TF;   // jl0: butterfly of pass 0 (input index jl0 + TF s)
     const int jl = XP ? X4096::jl1(tid) : jl0;   // butterfly of the later passes = bins held at the end
     const unsigned wg = blockIdx.x + wg_base;
     const unsigned c = wg / g.splits, part = wg % g.splits;
@@ -194,8 +207,9 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
         else load_twiddles<N, 2>(tw[2], twtab, jl);
     }
 
-    // CARRY (one transform per workgroup = consecutive segments, N = 4096): see GJ_W_CARRY above
-    constexpr bool CARRY = HS && Cfg::win16 && (GJ_W_CARRY != 0) && (GJ_W_PREFETCH != 0);
+    // CARRY (every group walks consecutive segments, N >= 1024): see GJ_W_CARRY above
+    constexpr bool CARRY = HS && Cfg::win16 && (GJ_W_CARRY != 0) && (GJ_W_PREFETCH != 0) &&
+                           (((GJ_W_CARRY_MASK >> welch_log2(N)) & 1u) != 0);
     // window folded into the unpack: w (2u - 255) = u (2w) + (-255 w); (w[2i], w[2i+1]) share a
     // VGPR pair and op_sel picks the half, so 16 points cost 16 register pairs.
     // CARRY: w[n + N/2] = 1 - w[n] (periodic Hann), so the eight values of the first half do for both.
@@ -234,14 +248,18 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
             dst[s] = (*reinterpret_cast<const uint16_t*>(chunk8 + (byte0 + 2u * TF * (s0 + s))));
     };
     const unsigned nsteps = (seg_hi - seg_lo + B - 1) / B;
+    // this transform group's segments: [my_lo, my_hi) one per step (RUNS), or seg_lo + b, + B, ... (interleaved)
+    const unsigned my_lo = RUNS ? ((seg_lo + b * nsteps < seg_hi) ? seg_lo + b * nsteps : seg_hi) : seg_lo;
+    const unsigned my_hi = RUNS ? ((my_lo + nsteps < seg_hi) ? my_lo + nsteps : seg_hi) : seg_hi;
+    const unsigned seg_idle = (my_lo < seg_hi) ? my_lo : seg_lo;   // what a group without work loads (values unused)
     // raw samples of the NEXT step are fetched while the current one is transformed
     unsigned raw[CARRY ? 1 : 16];
     unsigned rawh[CARRY ? 8 : 1];      // CARRY: only the new half segment is ever loaded
     c2 carry[CARRY ? 8 : 1];           // CARRY: 2u - off2 of the previous step's second half = this step's first half
     [[maybe_unused]] unsigned ws_cur = 0, ws_prv = 2;   // HS: slot of this step's half-sum / of the previous step's
     if constexpr (CARRY) {
-        // first step of the workgroup: the first half has no predecessor -- unpack it here, once
-        load_half(rawh, seg_lo, 0);
+        // first step of the group's run: the first half has no predecessor -- unpack it here, once
+        load_half(rawh, seg_idle, 0);
         c2 flo = make_c2(0.f, 0.f);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
@@ -254,13 +272,14 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
             wsum[ws_prv][b][(tid >> 6) % WPF][0] = li;
             wsum[ws_prv][b][(tid >> 6) % WPF][1] = lq;
         }
-        load_half(rawh, seg_lo, 8);
+        load_half(rawh, seg_idle, 8);
     } else {
-        load_step(raw, (seg_lo + b < seg_hi) ? seg_lo + b : seg_lo);
+        load_step(raw, RUNS ? seg_idle : ((seg_lo + b < seg_hi) ? seg_lo + b : seg_lo));
     }
     for (unsigned it = 0; it < nsteps; ++it) {
-        const unsigned seg = seg_lo + it * B + b;
-        const bool active = seg < seg_hi;
+        const unsigned seg = RUNS ? my_lo + it : seg_lo + it * B + b;
+        const bool active = seg < my_hi;
+        const unsigned seg_next = RUNS ? ((seg + 1 < my_hi) ? seg + 1 : seg_idle) : ((seg + B < seg_hi) ? seg + B : seg_lo);
         c2 v[16];
         c2 fsum = make_c2(0.f, 0.f);   // (sum I, sum Q) of the raw bytes: integers < 2^24, exact in f32
         // HS (one transform per workgroup = consecutive segments per step): the first half of a
@@ -281,7 +300,7 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
                 v[8 + s] = (s & 1) ? one_minus_hi(u2, w2p[s >> 1]) : one_minus_lo(u2, w2p[s >> 1]);
             }
         } else {
-            if (!GJ_W_PREFETCH && it > 0) load_step(raw, active ? seg : seg_lo);
+            if (!GJ_W_PREFETCH && it > 0) load_step(raw, active ? seg : seg_idle);
             if (HS && it == 0) {   // first step of the workgroup: the first half has no predecessor
                 c2 flo = make_c2(0.f, 0.f);
 #pragma unroll
@@ -302,7 +321,7 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
                     v[s] = (s & 1) ? fma_hi(f, w2p[s >> 1], wcp[s >> 1]) : fma_lo(f, w2p[s >> 1], wcp[s >> 1]);
                 if (!HS || s >= 8) fsum = cadd(fsum, f);
             }
-            if (GJ_W_PREFETCH) load_step(raw, (seg + B < seg_hi) ? seg + B : seg_lo);
+            if (GJ_W_PREFETCH) load_step(raw, seg_next);
         }
         float si, sq;
         if constexpr (TF >= 64) {
@@ -317,13 +336,13 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
             sq = group_sum_dpp_f<TF>(fsum.y);
         }
 
-        if constexpr (XP)
-            welch_passes_x4096(v, lds0, lds1, tid, tw, ktw, [&] {
-                // CARRY: the next step's new half, asked for while this step's points sit in LDS (about two thirds
-                // of a step = 2 us ahead of their use)
-                if constexpr (CARRY) load_half(rawh, (seg + 1 < seg_hi) ? seg + 1 : seg_lo, 8);
-            });
-        else welch_passes<N, 0>(v, lds0, lds1, it, b * lds_span(N), jl, tw, ktw);
+        // CARRY: the next step's new half, asked for while this step's points sit in LDS (about two thirds of a step
+        // = 2 us ahead of their use, and where the fewest registers are live)
+        auto prefetch_half = [&] {
+            if constexpr (CARRY) load_half(rawh, seg_next, 8);
+        };
+        if constexpr (XP) welch_passes_x4096(v, lds0, lds1, tid, tw, ktw, prefetch_half);
+        else welch_passes<N, 0>(v, lds0, lds1, it, b * lds_span(N), jl, tw, ktw, prefetch_half);
 
         // detrend in the frequency domain on bins 0, 1, N-1
         if constexpr (TF >= 64) {
