@@ -209,6 +209,8 @@ class SplitStreams:
         self.deal = deal_pairs(self.n_ant, ranks_with_parts)
         self.pairs = self.deal.get(rank, [])
         self.pair_cap = max(1, max(len(v) for v in self.deal.values()))
+        all_solved = [x for r in sorted(self.deal) for p in self.deal[r] for x in p]   # rank order = the combine's order
+        self._d_all_pairs = torch.tensor(all_solved or [0, 0], dtype=torch.int32, device=d)
         self.part_len = dev.part_result_len(self.chunk_cap, self.tile_cap, self.rows_cap, nperseg, self.pair_cap)
         self.o_tiles = HEADER + self.chunk_cap
         self.o_pairs = self.o_tiles + 2 * self.tile_cap
@@ -241,6 +243,7 @@ class SplitStreams:
         self._final = ([torch.zeros((self.n_ant, self.final_len), dtype=torch.float64, device=d) for _ in range(2)]
                        if self.is_root else [None, None])
         self._done = [torch.cuda.Event() for _ in range(2)] if d.type == "cuda" else [None, None]
+        self._ev_vec_free = [None, None]
         self._idx = 0
         self.last_psd = [None] * self.n_ant     # rank 0: each capture's waterfall rows as rebuilt by the last combine
         # workspaces
@@ -303,6 +306,8 @@ class SplitStreams:
             self._main.wait_event(self._ev_side)
         self._idx ^= 1
         vec = self._vecs[self._idx]
+        if self.overlap and self._ev_vec_free[self._idx] is not None:
+            self._main.wait_event(self._ev_vec_free[self._idx])     # the gather / combine of two steps ago has read it
         for j, s in enumerate(self.streams):
             p = s.part
             carries = j == 0                      # the pairs this rank solved ride on its first part's vector
@@ -320,24 +325,30 @@ class SplitStreams:
 
     def exchange(self, dst: int = 0) -> Optional[StepResults]:
         assert dst == 0
+        # Gather and (rank 0) combine run on the SECOND stream: a chain of small latency-bound kernels (one-workgroup
+        # threshold, amplitude total, packing) that would otherwise sit between two steps' K2 launches with the chip
+        # idle; the main stream goes straight on to the next step.  Everything they read is in the packed vectors
+        # (two sets, used alternately).
         vec = self.pack()
         k = self._idx
-        if self.world > 1:
-            if self.overlap:
-                self._side.wait_event(self._ev_packed)
-            with self._on_side():
+        final = None
+        if self.overlap:
+            self._side.wait_event(self._ev_packed)
+        with self._on_side():
+            if self.world > 1:
                 rows = gather_rows(vec.view(-1), self.rank, self.world, 0, out=self._gathered[k])
-                if self.overlap:
-                    ev = torch.cuda.Event()
-                    ev.record(self._side)
-                    self._main.wait_event(ev)
-        else:
-            rows = vec.view(1, -1)
+            else:
+                rows = vec.view(1, -1)
+            if self.is_root:
+                final = self._combine(rows, self._final[k])
+                if self._done[k] is not None:
+                    self._done[k].record(self._side)
+            if self.overlap:
+                if self._ev_vec_free[k] is None:
+                    self._ev_vec_free[k] = torch.cuda.Event()
+                self._ev_vec_free[k].record(self._side)
         if not self.is_root:
             return None
-        final = self._combine(rows, self._final[k])
-        if self._done[k] is not None:
-            self._done[k].record(self._main)
         return StepResults(final, self._done[k], self.n_ant)
 
     def step(self) -> Optional[StepResults]:
@@ -348,8 +359,8 @@ class SplitStreams:
     # ---------------------------------------------------------------- rank 0: parts -> captures
     def _combine(self, rows: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         """Rebuild each capture's device arrays from its parts' vectors and run the tail kernels a single-GPU stream
-        runs (threshold, amplitude totals, onset, mean spectrum, packing): main stream, no host synchronisation."""
-        dev, L = self.dev, self.part_len
+        runs (threshold, amplitude totals, onset, mean spectrum, packing): second stream, no host synchronisation."""
+        dev, L = self.dev_side, self.part_len
         vec = lambda p: rows[p.rank, p.local * L:(p.local + 1) * L]          # noqa: E731
         # every solved pair, in rank order (which rank solved what is static)
         lag_l, peak_l, marg_l, pair_l = [], [], [], []
@@ -362,7 +373,7 @@ class SplitStreams:
                 marg_l.append(blk[:, 4].to(torch.float32))
                 pair_l += self.deal[r]
         if pair_l:
-            d_pairs = torch.tensor([x for p in pair_l for x in p], dtype=torch.int32, device=rows.device)
+            d_pairs = self._d_all_pairs          # made once: a host-to-device copy here would stall the host every step
             lags, peaks, margs = torch.cat(lag_l), torch.cat(peak_l), torch.cat(marg_l)
         out.zero_()
         for a in range(self.n_ant):
@@ -392,9 +403,9 @@ class SplitStreams:
                                 d_pairs if carries else None, lags if carries else None, peaks if carries else None,
                                 margs if carries else None, out[a])
             self.last_psd[a] = psd[:n_rows]
-            if rows.is_cuda:                       # the temporaries above are read by kernels queued on the main stream
+            if rows.is_cuda:                       # the temporaries above are read by kernels queued on this stream
                 for t in (power, tiles, onset_parts, amp_parts, psd, stats, amp, onset):
-                    t.record_stream(self._main)
+                    t.record_stream(self._side)
         return out
 
     def close(self):
