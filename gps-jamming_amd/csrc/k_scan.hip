@@ -7,6 +7,8 @@
 // coalesced loads, integer arithmetic on the packed bytes (v_dot4_u32_u8), wave shuffles
 // + one LDS hop for the block reduction.  Sums of squares are exact integers:
 //   (I-127.5)^2 + (Q-127.5)^2 = ((2I-255)^2 + (2Q-255)^2) / 4.
+#include <type_traits>
+
 #include "gj_common.h"
 
 namespace gj {
@@ -999,7 +1001,10 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
     asm volatile("" : "+v"(k2), "+v"(km255));                      // keep both in VGPRs (one constant-bus slot per op)
     // `live` is false only for the lanes past the end of a partial last tile (see below): they take
     // part in the wave-wide reductions with zero contributions
-    auto body = [&](const uint4& q, size_t i, const bool live) {
+    // noise_c: std::true_type in the few tiles that touch K4's noise span (the first 400 KB of a capture), false_type
+    // everywhere else -- the other 16 377 tiles of a GiB do not pay for the span test
+    auto body = [&](const uint4& q, unsigned i, const bool live, auto noise_c) {   // i: vector index inside the tile (< 4096)
+        constexpr bool NOISE = decltype(noise_c)::value;
         const unsigned ws[4] = {q.x, q.y, q.z, q.w};
         int m[8];
 #pragma unroll
@@ -1013,37 +1018,48 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
             const float r = __fsqrt_rn((float)m[k]);
             part += r;
             if constexpr (TRACK_FIRST) {
-                const long long idx = (long long)((b0 >> 1) + i * 8 + k);
+                const long long idx = (long long)((b0 >> 1) + (size_t)i * 8 + k);
                 if (live && r * up.half_scale > thr && idx < first) first = idx;   // same expression as K3 alone
             }
         }
         const unsigned m8 = live ? (unsigned)(((m[0] + m[1]) + (m[2] + m[3])) + ((m[4] + m[5]) + (m[6] + m[7]))) : 0u;
         S += m8;
-        if (in_noise && b0 + (i << 4) < noise_bytes) nS += m8;      // noise_bytes % 16 == 0
+        if constexpr (NOISE) {
+            if (b0 + ((size_t)i << 4) < noise_bytes) nS += m8;      // noise_bytes % 16 == 0
+        }
         // block sum of 4|z|^2 over the wave = one 512-sample block
         const int c512 = wave_sum_lane63((int)m8);
         if ((tid & 63) == 63) cblk[(b0 >> 10) + (i >> 6)] = (unsigned)c512;
         sum += (double)(live ? part : 0.f);
     };
-    if (nvec == kScanTile / 16) {
+    if (nvec == kScanTile / 16 && !in_noise) {
         // full tile: 16 vectors per lane, four 16-byte loads in flight before the arithmetic starts
-        for (size_t i = tid; i < nvec; i += 4 * kScanThreads) {
+        for (unsigned i = tid; i < (unsigned)(kScanTile / 16); i += 4 * kScanThreads) {
             const uint4 q0 = v[i], q1 = v[i + kScanThreads], q2 = v[i + 2 * kScanThreads], q3 = v[i + 3 * kScanThreads];
-            body(q0, i, true);
-            body(q1, i + kScanThreads, true);
-            body(q2, i + 2 * kScanThreads, true);
-            body(q3, i + 3 * kScanThreads, true);
+            body(q0, i, true, std::false_type{});
+            body(q1, i + kScanThreads, true, std::false_type{});
+            body(q2, i + 2 * kScanThreads, true, std::false_type{});
+            body(q3, i + 3 * kScanThreads, true, std::false_type{});
+        }
+    } else if (nvec == kScanTile / 16) {
+        for (unsigned i = tid; i < (unsigned)(kScanTile / 16); i += 4 * kScanThreads) {
+            const uint4 q0 = v[i], q1 = v[i + kScanThreads], q2 = v[i + 2 * kScanThreads], q3 = v[i + 3 * kScanThreads];
+            body(q0, i, true, std::true_type{});
+            body(q1, i + kScanThreads, true, std::true_type{});
+            body(q2, i + 2 * kScanThreads, true, std::true_type{});
+            body(q3, i + 3 * kScanThreads, true, std::true_type{});
         }
     } else {
         // partial last tile: the trip count is WAVE-uniform (the 512-sample block sums are reduced
         // and stored per wave inside body(), so a wave must never split here); lanes past the end
         // run on a zero vector and are masked out of every sum
-        const size_t lane = tid & 63;
-        for (size_t ib = (size_t)tid - lane; ib < nvec; ib += kScanThreads) {
-            const size_t i = ib + lane;
-            const bool live = i < nvec;
+        const unsigned lane = tid & 63;
+        for (unsigned ib = (unsigned)tid - lane; ib < (unsigned)nvec; ib += kScanThreads) {
+            const unsigned i = ib + lane;
+            const bool live = i < (unsigned)nvec;
             const uint4 q = live ? v[i] : uint4{0u, 0u, 0u, 0u};
-            body(q, i, live);
+            if (in_noise) body(q, i, live, std::true_type{});
+            else body(q, i, live, std::false_type{});
         }
     }
     // ragged end of the stream (< 8 samples): one lane, scalar

@@ -329,3 +329,30 @@ def test_ingest_without_scan_or_without_psd(dev):
         dev.ingest(raw[:1 << 20], welch=(2048000, 1000))                     # not a power of two
     with pytest.raises(FileNotFoundError):
         dev.ingest("/nonexistent/capture.bin")
+
+
+def test_more_callers_than_lanes(dev):
+    """Twelve host threads on one context (eight lanes): the ninth caller waits for a lane with nothing held, every
+    answer is right, no lane stays out."""
+    raws = [generate(StreamSpec(seed=200 + k, jam_start=60000, jam_end=1 << 40, jam_sigma=30.0 + k), 150000 + 777 * k) for k in range(12)]
+    want = [(orc.chunk_power(r), orc.tdoa_onset(orc.tdoa_unpack(r), 20000, 1000, 50.0)) for r in raws]
+    errors = []
+    start = threading.Barrier(12)
+
+    def work(k):
+        try:
+            start.wait(30)
+            for _ in range(10):
+                np.testing.assert_allclose(dev.chunk_power(raws[k]), want[k][0], rtol=1e-6)
+                assert dev.onset(raws[k], 20000, 1000, 50.0).start_index == want[k][1]
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(12)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not errors, errors
+    c = dev.debug_counters()
+    assert c["lanes"] <= 8 and c["lanes_busy"] == 0
