@@ -218,6 +218,22 @@ __device__ __forceinline__ float group_sum_dpp_f(float v) {
     return v;
 }
 
+// Wave totals of TWO small non-negative integer-valued floats at once (K2's per-step sums of the raw I and Q bytes:
+// at most 16 x 255 per lane).  Both ride in one register, 16 bits each, through the four in-row DPP steps (a row of
+// 16 lanes sums to < 65536, so the fields never carry into each other); the four row totals are read into SGPRs and
+// added by the scalar unit.  13 vector instructions instead of 2 x 11, results wave-uniform and exact.
+__device__ __forceinline__ void wave_sum_pair_u16(float a, float b, float& sum_a, float& sum_b) {
+    unsigned p = (unsigned)a | ((unsigned)b << 16);
+    p += (unsigned)__builtin_amdgcn_update_dpp(0, (int)p, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+    p += (unsigned)__builtin_amdgcn_update_dpp(0, (int)p, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+    p += (unsigned)__builtin_amdgcn_update_dpp(0, (int)p, 0x141, 0xf, 0xf, false);   // row_half_mirror
+    p += (unsigned)__builtin_amdgcn_update_dpp(0, (int)p, 0x140, 0xf, 0xf, false);   // row_mirror
+    const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)p, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)p, 16),
+                   r2 = (unsigned)__builtin_amdgcn_readlane((int)p, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)p, 48);
+    sum_a = (float)((r0 & 0xffffu) + (r1 & 0xffffu) + (r2 & 0xffffu) + (r3 & 0xffffu));
+    sum_b = (float)((r0 >> 16) + (r1 >> 16) + (r2 >> 16) + (r3 >> 16));
+}
+
 }   // namespace gj
 
 // entry points implemented per translation unit (called from api.hip)

@@ -267,7 +267,8 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
             flo = cadd(flo, f);
             carry[s] = twice_plus_k(f, kmoff);
         }
-        const float li = group_sum_dpp_f<64>(flo.x), lq = group_sum_dpp_f<64>(flo.y);
+        float li, lq;
+        wave_sum_pair_u16(flo.x, flo.y, li, lq);
         if ((tid & 63) == 0) {
             wsum[ws_prv][b][(tid >> 6) % WPF][0] = li;
             wsum[ws_prv][b][(tid >> 6) % WPF][1] = lq;
@@ -305,7 +306,8 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
                 c2 flo = make_c2(0.f, 0.f);
 #pragma unroll
                 for (int s = 0; s < 8; ++s) flo = cadd(flo, make_c2((float)(raw[s] & 255u), (float)((raw[s] >> 8) & 255u)));
-                const float li = group_sum_dpp_f<64>(flo.x), lq = group_sum_dpp_f<64>(flo.y);
+                float li, lq;
+                wave_sum_pair_u16(flo.x, flo.y, li, lq);
                 if ((tid & 63) == 0) {
                     wsum[prv][b][(tid >> 6) % WPF][0] = li;
                     wsum[prv][b][(tid >> 6) % WPF][1] = lq;
@@ -325,8 +327,7 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
         }
         float si, sq;
         if constexpr (TF >= 64) {
-            si = group_sum_dpp_f<64>(fsum.x);   // wave-uniform
-            sq = group_sum_dpp_f<64>(fsum.y);
+            wave_sum_pair_u16(fsum.x, fsum.y, si, sq);   // wave-uniform, exact (at most 16 x 255 per lane)
             if ((tid & 63) == 0) {
                 wsum[cur][b][(tid >> 6) % WPF][0] = si;
                 wsum[cur][b][(tid >> 6) % WPF][1] = sq;
