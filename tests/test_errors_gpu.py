@@ -51,3 +51,46 @@ def test_empty_and_tiny_inputs(dev):
     st = dev.amp_stats(np.zeros(0, np.uint8), 0.0)
     assert st.first_index == -1 and st.count == 0
     assert dev.onset(np.zeros(100, np.uint8), 200000, 1000, 50.0).start_index == -1
+
+
+def test_capture_part_arguments_are_checked(dev):
+    """gj_part_*: a view that does not satisfy the alignment rules of include/gpsjam.h is refused with a status,
+    never run (a part whose own range starts off a chunk boundary, a halo that is not whole tiles or too short for the
+    window, a part without the capture's noise span, an own range outside the buffer)."""
+    import ctypes as C
+    from gpsjam import _ffi
+    n = 40 * 65536
+    raw = np.full(n, 128, np.uint8)
+    buf = dev.alloc(n).upload(raw)
+    d_pow, d_tiles, d_amp, d_on = dev.alloc(4 * 64), dev.alloc(16 * 64), dev.alloc(32), dev.alloc(32)
+
+    def scan(view, window=1000):
+        return dev._lib.gj_part_scan_dev(dev._ctx, C.byref(view), 65536, 1e-10, 0, d_pow.ptr, 0.0, d_tiles.ptr, d_amp.ptr,
+                                         20000, window, 50.0, d_on.ptr)
+
+    total = 100 * 65536
+    ok = _ffi.PartView(buf.ptr, n, 9 * 65536, 10 * 65536, 20 * 65536, total, buf.ptr)
+    assert scan(ok) == 0
+    dev.synchronize()
+    bad_start = _ffi.PartView(buf.ptr, n, 9 * 65536, 10 * 65536 + 4096, 20 * 65536, total, buf.ptr)
+    assert scan(bad_start) == -5                                                 # GJ_ERR_UNSUPPORTED
+    bad_halo = _ffi.PartView(buf.ptr, n, 10 * 65536 - 4096, 10 * 65536, 20 * 65536, total, buf.ptr)
+    assert scan(bad_halo) == -5
+    short_halo = _ffi.PartView(buf.ptr, n, 9 * 65536, 10 * 65536, 20 * 65536, total, buf.ptr)
+    assert dev._lib.gj_part_scan_dev(dev._ctx, C.byref(short_halo), 65536, 1e-10, 0, d_pow.ptr, 0.0, d_tiles.ptr, d_amp.ptr,
+                                     20000, 8192, 50.0, d_on.ptr) == 0          # 32768 samples of halo hold the largest window
+    no_noise = _ffi.PartView(buf.ptr, n, 9 * 65536, 10 * 65536, 20 * 65536, total, None)
+    assert scan(no_noise) == -1                                                  # GJ_ERR_INVALID
+    assert b"noise span" in dev._lib.gj_last_error(dev._ctx)
+    outside = _ffi.PartView(buf.ptr, n, 9 * 65536, 10 * 65536, 60 * 65536, total, buf.ptr)
+    assert scan(outside) == -1
+    ragged_middle = _ffi.PartView(buf.ptr, n, 9 * 65536, 10 * 65536, 20 * 65536 + 100, total, buf.ptr)
+    assert scan(ragged_middle) == -5                                             # only the capture's last part may end ragged
+    d_psd = dev.alloc(4 * 1024 * 64)
+    assert dev._lib.gj_part_welch_dev(dev._ctx, C.byref(bad_start), 32768, 1024, 2.048e6, 1, d_psd.ptr, None) == -5
+    assert dev._lib.gj_part_welch_dev(dev._ctx, C.byref(ok), 32768, 1024, 2.048e6, 1, d_psd.ptr, None) == 0
+    dev.synchronize()
+    pm = dev.chunk_power(raw[:4 * 65536])                                        # the context still works
+    assert pm.shape == (4,)
+    for b in (buf, d_pow, d_tiles, d_amp, d_on, d_psd):
+        b.free()
