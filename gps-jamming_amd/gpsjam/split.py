@@ -116,6 +116,52 @@ def deal_pairs(n_ant: int, ranks_with_parts: Sequence[int]) -> dict:
     return deal
 
 
+class CaptureRange:
+    """Bytes [b0, b1) of a capture FILE in HBM (gj_upload_file with an offset: every rank reads its own range, no
+    rank ever reads a whole file), with the three attributes PartStream needs of a buffer."""
+
+    dtype = torch.uint8
+
+    def __init__(self, dev, path, b0: int, b1: int, device):
+        self._cap = dev.capture(path, offset=int(b0), max_bytes=int(b1 - b0)) if b1 > b0 else None
+        self._n = int(b1 - b0)
+        self.device = device
+        if self._cap is not None and self._cap.nbytes != self._n:
+            raise ValueError(f"{path}: wanted bytes [{b0}, {b1}), the file gave {self._cap.nbytes}")
+
+    def data_ptr(self) -> int:
+        return self._cap.ptr if self._cap is not None else 0
+
+    def numel(self) -> int:
+        return self._n
+
+    def is_contiguous(self) -> bool:
+        return True
+
+    def free(self):
+        if self._cap is not None:
+            self._cap.free()
+            self._cap = None
+
+
+def from_files(dev, paths: Sequence[str], *, rank: int = 0, world_size: int = 1, device=None, **kw) -> "SplitStreams":
+    """The split pipeline over capture FILES (the reference's deployment: three antenna recordings,
+    GpsJammerApp/app/worker.py:586-600): the files are laid end to end and cut into ``world_size`` runs; this rank
+    uploads only the byte ranges of its own parts (+ halo, tail and, for parts that do not start their file, the first
+    400 000 bytes for K4's threshold)."""
+    import os
+    sizes = [os.path.getsize(p) for p in paths]
+    d = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+    def make_buffer(part, b0, b1):
+        return CaptureRange(dev, paths[part.antenna], b0, b1, d)
+
+    def make_noise(antenna, nbytes):
+        return CaptureRange(dev, paths[antenna], 0, nbytes, d)
+
+    return SplitStreams(dev, sizes, make_buffer, make_noise, rank=rank, world_size=world_size, device=d, **kw)
+
+
 class PartStream:
     """One part on this GPU: its buffers and the three per-part kernels (no host synchronisation anywhere)."""
 

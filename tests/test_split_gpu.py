@@ -268,3 +268,42 @@ def test_split_is_bit_identical_to_the_single_gpu_run(world, dev):
         s = got["g3"]["streams"][a]
         assert s["amp_first"] == k and s["amp_count"] == raw.size // 2 - k
         np.testing.assert_allclose(s["amp_mean"], avg, rtol=1e-6)
+
+
+def test_split_from_capture_files(dev, tmp_path):
+    """gpsjam.split.from_files: every part is read from its file by byte range (gj_upload_file with an offset); the
+    results are those of the same pipeline fed from arrays, and of the single-GPU run."""
+    import torch
+    from gpsjam import split
+    caps, kw = scenarios()["syn3"]
+    paths = []
+    for a, c in enumerate(caps):
+        p = tmp_path / f"ant{a}.bin"
+        c.tofile(p)
+        paths.append(str(p))
+    work = torch.cuda.Stream()
+    torch.cuda.set_stream(work)
+    dev.set_stream(work.cuda_stream)
+    try:
+        want = _single_gpu(dev, caps, kw)
+        for world in (1, 3):                      # as rank 0 of one, and the plan of three ranks walked rank by rank
+            plans = split.plan_parts([c.size for c in caps], world, split.unit_bytes(65536, kw["chunk_samples"]))
+            assert len({p.rank for p in plans}) == world
+            if world == 1:
+                st = split.from_files(dev, paths, rank=0, world_size=1, **kw)
+                got = st.step()
+                res, td = got.unpack()
+                _assert_identical("files", _collect(res, td, [p.cpu().numpy().copy() for p in st.last_psd]), want)
+                st.close()
+            else:
+                for r in range(world):            # the byte ranges each rank would read: exactly its parts' buffers
+                    for p in (q for q in plans if q.rank == r):
+                        b0, b1 = split.buffer_range(p, 1000, kw["slice_samples"])
+                        rng = split.CaptureRange(dev, paths[p.antenna], b0, b1, torch.device("cuda", 0))
+                        back = np.empty(b1 - b0, np.uint8)
+                        dev._check(dev._lib.gj_memcpy_d2h(dev._ctx, back.ctypes.data, rng.data_ptr(), back.size))
+                        np.testing.assert_array_equal(back, caps[p.antenna][b0:b1])
+                        rng.free()
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        dev.set_stream(None, external=False)
