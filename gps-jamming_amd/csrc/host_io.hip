@@ -612,19 +612,15 @@ int ingest_impl(gj_ctx* ctx, size_t nbytes, Fill&& fill, const gj_ingest_plan& p
         if (rc) return bail(rc);
     } else {
         // a small capture: one copy on the context's stream, then everything
-        if (nbytes) {
-            std::vector<unsigned char> tmp;
-            unsigned char* pin = nullptr;
-            // through the lane's first bounce buffer when it fits, so that the copy is asynchronous; else in pieces
-            for (size_t off = 0; off < nbytes; off += kPinBytes) {
-                const size_t len = nbytes - off < kPinBytes ? nbytes - off : kPinBytes;
-                if (!L->pin[0] && hipHostMalloc(&L->pin[0], kPinBytes, hipHostMallocDefault) != hipSuccess) return bail(fail(ctx, GJ_ERR_NOMEM, "pinned buffer"));
-                pin = static_cast<unsigned char*>(L->pin[0]);
-                if (!fill(pin, off, len)) return bail(fail(ctx, GJ_ERR_INVALID, "reading the capture failed"));
-                if (hipMemcpyAsync(d_cap + off, pin, len, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-                    return bail(fail(ctx, GJ_ERR_HIP, "host-to-device copy failed"));
-            }
-            (void)tmp;
+        // through the lane's first bounce buffer, piece by piece (at most four of them below the threshold)
+        for (size_t off = 0; off < nbytes; off += kPinBytes) {
+            const size_t len = nbytes - off < kPinBytes ? nbytes - off : kPinBytes;
+            if (!L->pin[0] && hipHostMalloc(&L->pin[0], kPinBytes, hipHostMallocDefault) != hipSuccess) return bail(fail(ctx, GJ_ERR_NOMEM, "pinned buffer"));
+            unsigned char* pin = static_cast<unsigned char*>(L->pin[0]);
+            if (!fill(pin, off, len)) return bail(fail(ctx, GJ_ERR_INVALID, "reading the capture failed"));
+            if (hipMemcpyAsync(d_cap + off, pin, len, hipMemcpyHostToDevice, s) != hipSuccess) return bail(fail(ctx, GJ_ERR_HIP, "host-to-device copy failed"));
+            const int wrc = wait_stream(ctx, s);   // the bounce buffer is refilled next: the copy must have left it
+            if (wrc) return bail(wrc);
         }
         upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
         rc = launch_upto(nbytes, true);
