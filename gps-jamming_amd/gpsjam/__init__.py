@@ -52,6 +52,7 @@ def read_capture(path) -> np.ndarray:
 
 
 _resident = {}            # (realpath, size, mtime_ns) -> Capture, insertion order = LRU order
+_resident_loading = {}    # key -> (threading.Event, kernel thread id of the loading thread): an upload in flight
 _resident_lock = __import__("threading").Lock()
 
 
@@ -63,31 +64,64 @@ def resident_capture(path, **ingest) -> "Capture":
     host->device pass.  ``ingest`` (keyword arguments of ``Device.ingest``): what the caller is about to
     compute -- on the first use of a file it is computed WHILE the file uploads and rides on the Capture; a
     file that is already resident is returned as it is (the caller's call then runs on it as usual).
-    Raises FileNotFoundError like open()."""
+    Raises FileNotFoundError like open().
+
+    The cache lock is held for dictionary operations only, never across an upload: two threads bringing in
+    different files do not wait for each other, and a thread that is stopped inside its upload (the GUI ends an
+    analysis with QThread.terminate(), ui_mainwindow.py:818-826) leaves nothing locked -- a second caller of the
+    same file waits for the upload in flight only while the thread that started it is alive, then takes over."""
     import os
+    import threading
     st = os.stat(path)
     key = (os.path.realpath(path), st.st_size, st.st_mtime_ns)
     dev = default_device()
-    with _resident_lock:
-        cap = _resident.pop(key, None)
-        if cap is not None and cap.ptr and cap.dev is dev:
-            _resident[key] = cap                      # most recently used last
-            return cap
-        limit = int(float(os.environ.get("GPSJAM_RESIDENT_GIB", "64")) * (1 << 30))
-        while _resident and sum(c.nbytes for c in _resident.values()) + st.st_size > limit:
-            # eviction only drops the cache's reference: a caller that still holds the Capture (a scan
-            # running in another thread) keeps it alive, and its memory is freed when that reference goes
-            _resident.pop(next(iter(_resident)))
+    while True:
+        with _resident_lock:
+            cap = _resident.pop(key, None)
+            if cap is not None and cap.ptr and cap.dev is dev:
+                _resident[key] = cap                      # most recently used last
+                return cap
+            pending = _resident_loading.get(key)
+            if pending is not None and not _thread_alive(pending[1]):
+                pending[0].set()                          # its loader is gone: whoever waits may try again
+                del _resident_loading[key]
+                pending = None
+            if pending is None:
+                mine = threading.Event()
+                _resident_loading[key] = (mine, threading.get_native_id())
+                limit = int(float(os.environ.get("GPSJAM_RESIDENT_GIB", "64")) * (1 << 30))
+                while _resident and sum(c.nbytes for c in _resident.values()) + st.st_size > limit:
+                    # eviction only drops the cache's reference: a caller that still holds the Capture (a scan
+                    # running in another thread) keeps it alive, and its memory is freed when that reference goes
+                    _resident.pop(next(iter(_resident)))
+                break
+        pending[0].wait(0.05)                             # short waits: the loader's liveness is re-checked above
+    try:
         cap = dev.ingest(path, **ingest) if ingest else dev.capture(path)
-        _resident[key] = cap
+        with _resident_lock:
+            _resident[key] = cap
         return cap
+    finally:
+        with _resident_lock:
+            if _resident_loading.get(key, (None,))[0] is mine:
+                del _resident_loading[key]
+        mine.set()
+
+
+def _thread_alive(native_id) -> bool:
+    """Kernel thread ``native_id`` of this process still exists (works for threads Python did not start, such as
+    a QThread: the threading module does not know when those end)."""
+    import os
+    return os.path.exists(f"/proc/self/task/{native_id}")
 
 
 def release_resident():
     """Free every cached capture (tests; long-running hosts that switch file sets)."""
     with _resident_lock:
-        while _resident:
-            _resident.popitem()[1].free()
+        caps = list(_resident.values())
+        _resident.clear()
+    for c in caps:
+        c.free()
 
 
 def library_path() -> str:
