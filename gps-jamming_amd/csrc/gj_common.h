@@ -28,6 +28,7 @@ struct gj_lane {
     unsigned char* stage = nullptr;       // grow-only device staging: [input][results]
     size_t stage_bytes = 0;
     void* pin[kPinBufs] = {};
+    size_t pin_cap[kPinBufs] = {};        // bytes each holds (grow-only: a piece is 1..16 MiB, by capture size)
     hipEvent_t pin_ev[kPinBufs] = {};
     unsigned char* rpin = nullptr;        // pinned host memory the results are copied into (async D2H)
     size_t rpin_bytes = 0;

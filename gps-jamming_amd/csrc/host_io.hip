@@ -165,11 +165,14 @@ bool is_device_ptr(const void* p) {
     return a.type == hipMemoryTypeDevice;
 }
 
-// Large captures go through pinned 16 MiB bounce buffers (the host copy of piece k+1 overlaps the DMA of piece k:
-// 29 GB/s with one fill thread against 21 GB/s for a pageable hipMemcpy of 1 GiB on the MI355X box,
-// tools/h2d_bench.hip); small ones take the plain path.
-constexpr size_t kPinBytes = 16u << 20;
-constexpr size_t kPinThreshold = 64u << 20;
+// Captures go through pinned bounce buffers, piece by piece: the host copy of one piece overlaps the DMA of another
+// on every fill thread (29 GB/s with one fill thread against 21 GB/s for a pageable hipMemcpy of 1 GiB on the MI355X
+// box, tools/h2d_bench.hip; 51 GB/s with eight).  Pieces are 16 MiB for the GiB-class captures of the benchmark and
+// smaller for the sizes the reference is used at (a 10-s capture is 41 MB, a minute 246 MB: worker.py:184-196), so
+// that those, too, keep every fill thread and the link busy; only a few MiB take one plain copy.
+constexpr size_t kPinBytes = 16u << 20;       // largest piece
+constexpr size_t kMinPiece = 1u << 20;        // smallest: whole 64-KiB scan tiles either way
+constexpr size_t kPinThreshold = 4u << 20;    // below this: one copy, no helper threads
 constexpr int kMaxFillThreads = gj_lane::kPinBufs / 2;
 
 // fill threads of one staged copy: GPSJAM_FILL_THREADS (1..16), default 8 (one memcpy thread tops out at ~31 GB/s
@@ -185,10 +188,29 @@ int fill_threads() {
     return n;
 }
 
+// Piece size of a staged copy of `nbytes`: about four pieces per fill thread, whole MiB, at most 16 MiB (reached from
+// 512 MiB up with the default eight threads: the GiB-class figures of profiles/r0*_ingest*.txt were measured with it).
+size_t piece_bytes(size_t nbytes) {
+    size_t p = align_up(nbytes / (4 * (size_t)fill_threads()) + 1, kMinPiece);
+    if (p > kPinBytes) p = kPinBytes;
+    return p;
+}
+
+// the lane's bounce buffer k with room for `bytes` (grow-only; the lane's previous call has left its buffers)
+int lane_pin(gj_ctx* ctx, gj_lane* L, int k, size_t bytes) {
+    if (L->pin[k] && L->pin_cap[k] >= bytes) return GJ_OK;
+    if (L->pin[k]) (void)hipHostFree(L->pin[k]);
+    L->pin[k] = nullptr;
+    L->pin_cap[k] = 0;
+    GJ_HIP(ctx, hipHostMalloc(&L->pin[k], bytes, hipHostMallocDefault));
+    L->pin_cap[k] = bytes;
+    return GJ_OK;
+}
+
 // Host source -> d_dst through the lane's pinned buffers, on `stream`, with no lock held anywhere.
 // `fill(dst, off, len)` puts bytes [off, off+len) of the source into a pinned buffer: memcpy from a numpy array or a
 // mapped file, or pread from a capture file.  `landed(piece)`, when given, is called by the fill thread right after
-// it has queued piece `piece` (16 MiB, in HBM once ev fires): the overlapped ingest hangs its kernels there.
+// it has queued piece `piece` (piece_bytes(nbytes) each, in HBM once ev fires): the overlapped ingest hangs its kernels there.
 struct PieceSink {
     virtual void queued(size_t piece, size_t off, size_t len, hipEvent_t ev) = 0;
     virtual void failed() {}
@@ -204,10 +226,12 @@ template <typename Fill, typename Meanwhile = NoMeanwhile>
 int staged_copy(gj_ctx* ctx, gj_lane* L, hipStream_t stream, unsigned char* d_dst, size_t nbytes, Fill&& fill,
                 PieceSink* sink = nullptr, hipEvent_t* piece_events = nullptr, Meanwhile&& meanwhile = Meanwhile()) {
     if (nbytes == 0) return GJ_OK;
-    const size_t npieces = (nbytes + kPinBytes - 1) / kPinBytes;
+    const size_t piece_len = piece_bytes(nbytes);
+    const size_t npieces = (nbytes + piece_len - 1) / piece_len;
     const int nthreads = (int)(npieces < (size_t)fill_threads() ? npieces : (size_t)fill_threads());
-    for (int k = 0; k < 2 * nthreads; ++k) {   // two bounce buffers per fill thread, made on first use
-        if (!L->pin[k]) GJ_HIP(ctx, hipHostMalloc(&L->pin[k], kPinBytes, hipHostMallocDefault));
+    for (int k = 0; k < 2 * nthreads; ++k) {   // two bounce buffers per fill thread, made (or grown) on first use
+        const int prc = lane_pin(ctx, L, k, piece_len);
+        if (prc) return prc;
         if (!L->pin_ev[k]) GJ_HIP(ctx, hipEventCreateWithFlags(&L->pin_ev[k], hipEventDisableTiming));
     }
     wait_hook(ctx, kWaitPiece);
@@ -217,8 +241,8 @@ int staged_copy(gj_ctx* ctx, gj_lane* L, hipStream_t stream, unsigned char* d_ds
         if (hipSetDevice(device) != hipSuccess) { failed.store(1); return; }
         size_t mine = 0;
         for (size_t piece = (size_t)t; piece < npieces; piece += (size_t)nthreads, ++mine) {
-            const size_t off = piece * kPinBytes;
-            const size_t len = (nbytes - off < kPinBytes) ? nbytes - off : kPinBytes;
+            const size_t off = piece * piece_len;
+            const size_t len = (nbytes - off < piece_len) ? nbytes - off : piece_len;
             const int b = 2 * t + (int)(mine & 1);
             if (mine >= 2 && hipEventSynchronize(L->pin_ev[b]) != hipSuccess) { failed.store(1); return; }
             if (!fill(static_cast<unsigned char*>(L->pin[b]), off, len)) { failed.store(2); return; }
@@ -552,7 +576,8 @@ int ingest_impl(gj_ctx* ctx, size_t nbytes, Fill&& fill, const gj_ingest_plan& p
         rc = welch_begin(ctx, nbytes, plan.chunk_samples, plan.nperseg, plan.fs, 0, wj);
         if (rc) return bail(rc);
     }
-    const size_t npieces = (nbytes + kPinBytes - 1) / kPinBytes;
+    const size_t piece_len = piece_bytes(nbytes);
+    const size_t npieces = (nbytes + piece_len - 1) / piece_len;
     const size_t ws_scan = fused ? sj.ws_bytes : 0;
     rc = lane_ingest_resources(ctx, L, npieces ? npieces : 1, ws_scan + (want_welch ? wj.ws_bytes : 0) + 256);
     if (rc) return bail(rc);
@@ -603,7 +628,7 @@ int ingest_impl(gj_ctx* ctx, size_t nbytes, Fill&& fill, const gj_ingest_plan& p
                     if (++spins > 64) usleep(20); else sched_yield();
                 }
                 if (hipStreamWaitEvent(s, L->piece_ev[k], 0) != hipSuccess) { disp_rc = fail(ctx, GJ_ERR_HIP, "hipStreamWaitEvent failed"); return; }
-                const size_t landed = (k + 1 == npieces) ? nbytes : (k + 1) * kPinBytes;
+                const size_t landed = (k + 1 == npieces) ? nbytes : (k + 1) * piece_len;
                 disp_rc = launch_upto(landed, k + 1 == npieces);
             }
         });
@@ -611,16 +636,15 @@ int ingest_impl(gj_ctx* ctx, size_t nbytes, Fill&& fill, const gj_ingest_plan& p
         if (!rc) rc = disp_rc;
         if (rc) return bail(rc);
     } else {
-        // a small capture: one copy on the context's stream, then everything
-        // through the lane's first bounce buffer, piece by piece (at most four of them below the threshold)
-        for (size_t off = 0; off < nbytes; off += kPinBytes) {
-            const size_t len = nbytes - off < kPinBytes ? nbytes - off : kPinBytes;
-            if (!L->pin[0] && hipHostMalloc(&L->pin[0], kPinBytes, hipHostMallocDefault) != hipSuccess) return bail(fail(ctx, GJ_ERR_NOMEM, "pinned buffer"));
+        // a few MiB: one piece through the lane's first bounce buffer on the context's stream, then everything
+        if (nbytes) {
+            rc = lane_pin(ctx, L, 0, align_up(nbytes, 1 << 16));
+            if (rc) return bail(rc);
             unsigned char* pin = static_cast<unsigned char*>(L->pin[0]);
-            if (!fill(pin, off, len)) return bail(fail(ctx, GJ_ERR_INVALID, "reading the capture failed"));
-            if (hipMemcpyAsync(d_cap + off, pin, len, hipMemcpyHostToDevice, s) != hipSuccess) return bail(fail(ctx, GJ_ERR_HIP, "host-to-device copy failed"));
-            const int wrc = wait_stream(ctx, s);   // the bounce buffer is refilled next: the copy must have left it
-            if (wrc) return bail(wrc);
+            if (!fill(pin, 0, nbytes)) return bail(fail(ctx, GJ_ERR_INVALID, "reading the capture failed"));
+            if (hipMemcpyAsync(d_cap, pin, nbytes, hipMemcpyHostToDevice, s) != hipSuccess) return bail(fail(ctx, GJ_ERR_HIP, "host-to-device copy failed"));
+            // the next call of this lane may refill the bounce buffer: the copy must have left it when this one returns,
+            // which the wait for ev_done below sees to (same stream)
         }
         upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
         rc = launch_upto(nbytes, true);

@@ -43,9 +43,12 @@ class IQCapture:
     arrays: ``len()``, slicing (-> IQCapture) and ``np.asarray`` (-> complex64 of
     (I-127.5) + j(Q-127.5), reference :34)."""
 
-    def __init__(self, raw):
+    def __init__(self, raw, path=None):
         raw = gpsjam.as_u8(raw)
         self.raw = raw[:raw.size - (raw.size & 1)]
+        # the capture FILE these bytes are (load_iq_data; None for slices and arrays): lets the onset search run on the
+        # process-wide resident copy of the file (gpsjam.resident_capture) instead of uploading the bytes again
+        self.path = path
 
     def __len__(self):
         return self.raw.size // 2
@@ -65,7 +68,7 @@ class IQCapture:
 
 def load_iq_data(filename):
     """Capture handle (reference :31-35 returned the expanded complex64 array)."""
-    return IQCapture(gpsjam.read_capture(filename))
+    return IQCapture(gpsjam.read_capture(filename), path=filename)
 
 
 def _raw_of(iq_data):
@@ -145,7 +148,19 @@ def find_interference_start(iq_data, noise_samples, window_size, threshold_facto
         raise TypeError("find_interference_start expects the capture returned by load_iq_data")
     if len(iq_data) < noise_samples + window_size:
         return -1
-    res = gpsjam.default_device().onset(raw, int(noise_samples), int(window_size), float(threshold_factor))
+    dev = gpsjam.default_device()
+    src = raw
+    if getattr(iq_data, "path", None) and raw.size:
+        # file-backed: one upload per file and process, shared with the worker's scan and the RSSI solver; on first
+        # use the onset is computed while the file uploads
+        try:
+            src = gpsjam.resident_capture(iq_data.path, noise_samples=int(noise_samples), window=int(window_size),
+                                          factor=float(threshold_factor))
+            if src.nbytes != raw.size + (src.nbytes & 1):     # the file changed under the handle: use the bytes we hold
+                src = raw
+        except OSError:
+            src = raw
+    res = dev.onset(src, int(noise_samples), int(window_size), float(threshold_factor))
     return _resolve_near_tie(res, window_size, lambda first: _onset_reference_expression(
         raw, int(noise_samples), int(window_size), float(threshold_factor), first))
 

@@ -276,10 +276,10 @@ def _fresh(dev, raw, welch):
     return pm, st, on, psd, db
 
 
-@pytest.mark.parametrize("nbytes", [160 * (1 << 20) + 4097, 70 * (1 << 20), 5_000_001, 131072, 2])
+@pytest.mark.parametrize("nbytes", [160 * (1 << 20) + 4097, 70 * (1 << 20), 40_960_001, 5_000_001, 1 << 22, (1 << 22) - 1, 131072, 2])
 def test_ingest_is_bit_identical_to_upload_then_run(dev, tmp_path, nbytes):
-    """gj_ingest_*: the fused scan and K2 run on the 16-MiB pieces that have landed while the rest uploads (above
-    64 MiB; below, one copy then the kernels).  Power map, amplitude statistics, onset record and PSD rows must be
+    """gj_ingest_*: the fused scan and K2 run on the pieces that have landed while the rest uploads (1 to 16 MiB each,
+    by capture size, from 4 MiB up; below, one copy then the kernels).  Power map, amplitude statistics, onset record and PSD rows must be
     the bits upload-then-run gives -- from a host array and from a file, odd lengths included."""
     base = generate(StreamSpec(seed=83, jam_start=900_000, jam_end=1 << 40, jam_sigma=50.0), 1_500_000)
     raw = np.tile(base, nbytes // base.size + 1)[:nbytes].copy()

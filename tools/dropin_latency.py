@@ -59,7 +59,7 @@ def main():
                 res = triangulateRSSI.triangulate_jammer_location(paths, threshold=0.0)
                 t2 = time.perf_counter()
                 caps = [triangulateTDOA.load_iq_data(p) for p in paths[:2]]
-                on = [triangulateTDOA.find_interference_start(c) for c in caps]
+                on = [triangulateTDOA.find_interference_start(c, 200000, 1000, 50.0) for c in caps]
                 t3 = time.perf_counter()
                 assert th.power_map_ready and res["success"] and all(o > 0 for o in on), (res, on)
                 rows.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
