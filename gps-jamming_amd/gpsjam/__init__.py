@@ -297,7 +297,7 @@ class Device:
                welch=None, fs: float = 2.048e6, shift: bool = True, want_db: bool = False, offset: int = 0,
                max_bytes: int = 0) -> Capture:
         """Upload a capture file (path) or uint8 array AND analyse it while it uploads (gj_ingest_*: the kernels run
-        on the 16-MiB pieces that have landed).  ``chunk_bytes`` != 0: the fused scan (K1 power map, K3 amplitude
+        on the pieces that have landed: 1-16 MiB each, by capture size).  ``chunk_bytes`` != 0: the fused scan (K1 power map, K3 amplitude
         statistics at ``rssi_threshold``, K4 onset); ``welch=(chunk_samples, nperseg)``: the PSD waterfall.  The
         results ride on the returned Capture (``.results``) and are handed out by ``chunk_power`` / ``amp_stats`` /
         ``onset`` / ``welch`` when these are called on it with the same parameters -- bit-identical to what those

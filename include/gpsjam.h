@@ -219,7 +219,7 @@ int gj_stream_scan_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes,
                        int noise_samples, int window, float factor, gj_onset* d_onset);
 
 /* ------------------------------------------------- overlapped ingest ----------------- */
-/* Overlapped ingest: upload a capture AND analyse it, with the kernels running on the 16-MiB pieces that have
+/* Overlapped ingest: upload a capture AND analyse it, with the kernels running on the pieces (1-16 MiB, by capture size) that have
  * landed in HBM while the rest is still on its way (the reference reads, then computes: worker.py:209-230,
  * triangulateRSSI.py:29-31, widmo_plot.py:26-54).  What is computed: with chunk_bytes != 0 the fused scan (K1 power
  * map, K3 amplitude statistics, K4 onset -- gj_stream_scan_dev), with nperseg != 0 the Welch waterfall (K2 --
