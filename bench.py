@@ -55,6 +55,29 @@ JAM_GAIN = (1.0, 0.9, 0.85, 0.95)
 JAM_SPAN = (0.4, 0.7)      # burst in source time, as fractions of the capture
 
 
+_LINE_FD = None
+
+
+def guard_stdout():
+    """Rank 0 prints ONE JSON line on stdout and nothing else may: RCCL, for one, writes a version banner to stdout
+    when its first communicator is made.  From here on file descriptor 1 of this process points at stderr (so does
+    everything a library prints), and `emit` writes the line to the descriptor stdout had."""
+    global _LINE_FD
+    if _LINE_FD is None:
+        sys.stdout.flush()
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    data = (json.dumps(obj) + "\n").encode()
+    if _LINE_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_LINE_FD, data)
+
+
 def stream_spec(StreamSpec, antenna, nsamp):
     return StreamSpec(seed=1234, antenna=antenna, delay=DELAYS[antenna % len(DELAYS)],
                       jam_start=int(JAM_SPAN[0] * nsamp), jam_end=int(JAM_SPAN[1] * nsamp), noise_sigma=6.25,
@@ -85,6 +108,9 @@ def main():
                          "over the N GPUs (gpsjam.split) instead of one capture per GPU")
     ap.add_argument("--antennas", type=int, default=3,
                     help="captures in --split mode (the reference's deployment has three, worker.py:586-600)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="N = 1 only: form a process group of ONE (--backend, default nccl = RCCL) and issue the slot "
+                         "all-gather and the result gather of the N > 1 path anyway -- the collective call path on one GPU")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="diagnostic: ranks only form the process group, all-reduce one number and print it")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
@@ -95,6 +121,7 @@ def main():
         # plain `python bench.py --gpus N`: this process never touches the GPU, it starts one rank per GPU
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout))
 
+    guard_stdout()
     import numpy as np
     import torch
     import gpsjam
@@ -112,7 +139,13 @@ def main():
         raise SystemExit(rendezvous_only(args, torch, world, rank, local_rank))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    grouped = world > 1 or args.force_exchange     # a process group exists (of one, with --force-exchange)
+    if args.force_exchange and world == 1 and "MASTER_ADDR" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
+    if grouped:
         import torch.distributed as dist
         import datetime
         limit = datetime.timedelta(seconds=300)   # a collective that never completes must end the run, not hang it
@@ -133,7 +166,7 @@ def main():
     dev.set_stream(work_stream.cuda_stream)
     if args.split:
         run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank)
-        if world > 1:
+        if grouped:
             dist.barrier()
             dist.destroy_process_group()
         dev.close()
@@ -160,11 +193,11 @@ def main():
         del tmp
     stream = AntennaStream(dev, cap, nperseg=NPERSEG, chunk_samples=CHUNK_SAMPLES, slice_samples=SLICE,
                            rank=rank, world_size=world, overlap=not args.no_overlap, aux_slots=aux,
-                           transport=args.transport)
+                           transport=args.transport, exchange_always=args.force_exchange and world == 1)
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
 
     # clock / power-state conditioning, not part of the W warm-up steps: the first launches after
@@ -236,7 +269,7 @@ def main():
             acq_ms = None
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if grouped:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     welch_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
@@ -276,7 +309,8 @@ def main():
                        "xcorr_slice": SLICE, "xcorr_antennas": stream.n_ant, "xcorr_pairs": len(tdoa.pairs),
                        "streams": world, "sharding": "one capture per GPU", "backend": args.backend if world > 1 else None,
                        "transport": args.transport if world > 1 else None},
-            "rccl_ranks": world if (world > 1 and (args.backend == "nccl" or args.transport == "rccl")) else 0,
+            "rccl_ranks": world if (grouped and (args.backend == "nccl" or args.transport == "rccl")) else 0,
+            "forced_exchange": bool(args.force_exchange and world == 1),
             "roofline": {"bound": "hbm", "kernel": "welch_kernel<4096> + welch_finalize_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic"], "traffic_unit": "HBM bytes per launch",
@@ -336,8 +370,8 @@ def main():
                 line["end_to_end"] = end_to_end(np, dev, cap, nbytes)
             except Exception as e:      # e.g. no room for the scratch copy of the capture
                 line["end_to_end"] = {"error": repr(e)}
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        emit(line)
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
     stream.close()
@@ -427,7 +461,7 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
             "self_check": self_check(results, tdoa, onsets, nsamp, A),
             "host": host_info(),
         }
-        print(json.dumps(line), flush=True)
+        emit(line)
     st.close()
 
 
@@ -477,7 +511,7 @@ def rendezvous_only(args, torch, world, rank, local_rank):
     cannot find each other / RCCL cannot start" from anything the DSP path does."""
     import datetime
     if world == 1:
-        print(json.dumps({"rendezvous": "single process", "world": 1}), flush=True)
+        emit({"rendezvous": "single process", "world": 1})
         return 0
     import torch.distributed as dist
     limit = datetime.timedelta(seconds=120)
@@ -491,8 +525,7 @@ def rendezvous_only(args, torch, world, rank, local_rank):
     dist.all_reduce(t)
     ok = float(t.item()) == world * (world + 1) / 2
     if rank == 0:
-        print(json.dumps({"rendezvous": "ok" if ok else "wrong sum", "world": world, "backend": args.backend,
-                          "sum": float(t.item())}), flush=True)
+        emit({"rendezvous": "ok" if ok else "wrong sum", "world": world, "backend": args.backend, "sum": float(t.item())})
     dist.barrier()
     dist.destroy_process_group()
     return 0 if ok else 1
@@ -701,7 +734,7 @@ def end_to_end(np, dev, cap, nbytes):
         except OSError:
             pass
     out["what"] = ("one H2D per capture, K1 power map + K2 Welch 4096 + K3 amp stats + K4 onset and the D2H of their results, "
-                   "wall clock.  host_buffer / file: gj_ingest_* -- the kernels run on the 16-MiB pieces that have landed while the "
+                   "wall clock.  host_buffer / file: gj_ingest_* -- the kernels run on the pieces that have landed (16 MiB each at this size) while the "
                    "rest uploads; *_upload_then_run: gpsjam.Capture, then the four calls (round 2's order)")
     out["uploads"] = gpsjam.Capture.uploads
     return out

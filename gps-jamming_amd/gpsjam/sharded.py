@@ -251,10 +251,12 @@ def slot_fields(slot: torch.Tensor, n_samples: int):
 
 
 def gather_rows(row: torch.Tensor, rank: int, world_size: int, dst: int = 0,
-                out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+                out: Optional[torch.Tensor] = None, always: bool = False) -> Optional[torch.Tensor]:
     """Every rank's ``row`` on ``dst`` as one [world, len] tensor (rows in rank order); None on the
-    other ranks.  One collective (torch.distributed.gather: RCCL on HIP tensors, gloo on CPU)."""
-    if world_size == 1:
+    other ranks.  One collective (torch.distributed.gather: RCCL on HIP tensors, gloo on CPU).
+    ``always``: issue the collective even in a group of one (tests / bench.py --force-exchange: the RCCL
+    call path on a single GPU)."""
+    if world_size == 1 and not always:
         return row.unsqueeze(0)
     import torch.distributed as dist
     if rank == dst:
@@ -266,11 +268,12 @@ def gather_rows(row: torch.Tensor, rank: int, world_size: int, dst: int = 0,
     return None
 
 
-def allgather_rows(row: torch.Tensor, world_size: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def allgather_rows(row: torch.Tensor, world_size: int, out: Optional[torch.Tensor] = None,
+                   always: bool = False) -> torch.Tensor:
     """Every rank's ``row`` on EVERY rank as one [world, len] tensor: ONE collective straight into the
     contiguous receive buffer (all_gather_into_tensor = ncclAllGather on HIP tensors; the list form of
-    all_gather flattens and copies out once more)."""
-    if world_size == 1:
+    all_gather flattens and copies out once more).  ``always``: as in ``gather_rows``."""
+    if world_size == 1 and not always:
         return row.unsqueeze(0)
     import torch.distributed as dist
     if out is None:
@@ -347,6 +350,8 @@ class AntennaStream:
     memory, streams and -- with ``transport="torch"`` -- the collectives; every kernel is a
     gpsjam C-ABI call).
 
+    ``exchange_always``: with ``world_size == 1`` and an initialised process group of one, still issue the slot
+    all-gather and the result gather (what N > 1 ranks do), so that the collective path can be run on one GPU.
     ``aux_slots`` (single-rank use): pre-filled TDOA slots of further antennas, [n_aux, slot_bytes]
     uint8; the rank then solves all pairs over 1 + n_aux antennas itself (BASELINE configs[3]:
     three antennas, three pairs on one GPU).
@@ -362,7 +367,7 @@ class AntennaStream:
                  slice_samples: int = 1 << 19, noise_samples: int = 200000, window: int = 1000,
                  factor: float = 50.0, rssi_threshold: float = 0.0, rank: int = 0, world_size: int = 1,
                  overlap: Optional[bool] = None, aux_slots: Optional[torch.Tensor] = None,
-                 transport="torch", side_device=None):
+                 transport="torch", side_device=None, exchange_always: bool = False):
         assert capture.dtype == torch.uint8 and capture.is_contiguous()
         self.dev, self.cap = dev, capture
         # K2 is bound by VALU issue and leaves ~90 % of the HBM bandwidth idle, the fused scan is HBM
@@ -413,7 +418,10 @@ class AntennaStream:
                 raise ValueError("the Communicator must be made on the context the exchange runs on"
                                  + (" (pass that Device as side_device=)" if self.overlap else ""))
             self.comm = transport
-        self._exchange = world_size > 1 or self.comm is not None   # a communicator is used even when alone
+        # a communicator is used even when alone; ``exchange_always`` does the same for torch.distributed (a process
+        # group of one: every collective of the N > 1 path is issued, on the same streams, on a single GPU)
+        self._always = bool(exchange_always) and self.comm is None
+        self._exchange = world_size > 1 or self.comm is not None or self._always
         # TDOA: the slots of every antenna (all-gathered: every rank holds them all), the pairs THIS rank solves
         self.slot_bytes = dev.tdoa_slot_bytes(slice_samples)
         n_aux = 0 if aux_slots is None else int(aux_slots.shape[0])
@@ -486,7 +494,7 @@ class AntennaStream:
                 if self.comm is not None:
                     self.comm.allgather(self.my_slot, self.slot_bytes, self.slots)
                 else:
-                    allgather_rows(self.my_slot, self.world, out=self.slots[:self.world])
+                    allgather_rows(self.my_slot, self.world, out=self.slots[:self.world], always=self._always)
             if self.pairs:
                 dev.xcorr_slots_dev(self.slots, self.slot_bytes, self.n_ant, self.slice_samples, self.pairs,
                                     self.lags, self.peaks, self.margins)
@@ -529,7 +537,7 @@ class AntennaStream:
                     rows = self._gathered[k]
                     self.comm.gather(vec, vec.numel() * vec.element_size(), rows if self.is_root else None, 0)
                 else:
-                    rows = gather_rows(vec, self.rank, self.world, 0, out=self._gathered[k])
+                    rows = gather_rows(vec, self.rank, self.world, 0, out=self._gathered[k], always=self._always)
                 if self._done[k] is not None:
                     self._done[k].record(self._side)
         if not self.is_root:

@@ -20,8 +20,10 @@ def _env():
 
 
 def _json_line(stdout):
-    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, stdout
+    """stdout carries ONE line, the JSON object, and nothing else (library banners -- RCCL prints one when its first
+    communicator is made -- are sent to stderr by bench.py's guard_stdout)."""
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), stdout
     return json.loads(lines[0])
 
 
@@ -83,3 +85,21 @@ def test_split_bench_two_ranks_share_gpu():
     assert line["self_check"]["passed"] is True, line["self_check"]
     assert line["self_check"]["pairs_checked"] == 3 and line["self_check"]["streams_checked"] == 3
     assert len({p[5] for p in line["config"]["parts"]}) == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_collective_path_over_rccl_on_one_gpu():
+    """`python bench.py --gpus 1 --force-exchange`: a process group of ONE over the nccl backend (= RCCL) -- two RCCL
+    ranks cannot share a device, so this is as far as one GPU goes: the communicator is bootstrapped over the loopback
+    interface, and the slot all-gather (all_gather_into_tensor), the result gather (gather into row views), the
+    barriers and the MAX all-reduce of the N > 1 path are issued on the pipeline's streams exactly as there.  The
+    line must carry the same results as the plain N = 1 run (self_check: known delays, burst spans)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--force-exchange", "--steps", "3", "--warmup", "1",
+                        "--precondition", "2", "--no-cpu-baseline", "--no-end-to-end", "--capture-bytes", str(1 << 28)],
+                       capture_output=True, text=True, env=_env(), timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 1 and line["forced_exchange"] is True and line["rccl_ranks"] == 1
+    assert line["self_check"]["passed"] is True, line["self_check"]
+    assert line["self_check"]["pairs_checked"] == 3 and line["results"]["lags"] and line["value"] > 0
