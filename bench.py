@@ -111,6 +111,11 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="N = 1 only: form a process group of ONE (--backend, default nccl = RCCL) and issue the slot "
                          "all-gather and the result gather of the N > 1 path anyway -- the collective call path on one GPU")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="N = 1 only, rehearsal: give this GPU the per-rank load of a W-antenna deployment -- W - 1 further "
+                         "slots prepared before the timed region, rank 0's share of the pairs (W / 2 of them) instead of "
+                         "all; with --force-exchange the collectives are issued too.  Not the reported configuration")
+    ap.add_argument("--side-priority", type=int, default=0, help="HIP priority of the second stream (0 default, -1 high)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="diagnostic: ranks only form the process group, all-reduce one number and print it")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
@@ -179,12 +184,17 @@ def main():
     # N = 1: the slots of antennas 1 and 2 (BASELINE configs[3]), cut by the same kernels from their
     # own captures before the timed region -- on N ranks they would arrive through the slot gather
     aux, aux_onsets = None, []
+    n_aux = max(args.emulate_world - 1, 2) if args.emulate_world else 2
+    only_pairs = None
+    if args.emulate_world:
+        from gpsjam.sharded import pairs_of_rank
+        only_pairs = pairs_of_rank(0, args.emulate_world)
     if world == 1:
         sb = dev.tdoa_slot_bytes(SLICE)
-        aux = torch.zeros((2, sb), dtype=torch.uint8, device="cuda")
+        aux = torch.zeros((n_aux, sb), dtype=torch.uint8, device="cuda")
         tmp = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
         d_on = torch.zeros(4, dtype=torch.int64, device="cuda")
-        for a in (1, 2):
+        for a in range(1, n_aux + 1):
             dev.synth_dev(stream_spec(StreamSpec, a, nsamp), nsamp, tmp)
             dev.onset_dev(tmp, nbytes, 200000, 1000, 50.0, d_on)
             dev.tdoa_slot_dev(tmp, nbytes, d_on, SLICE, aux[a - 1])
@@ -193,7 +203,8 @@ def main():
         del tmp
     stream = AntennaStream(dev, cap, nperseg=NPERSEG, chunk_samples=CHUNK_SAMPLES, slice_samples=SLICE,
                            rank=rank, world_size=world, overlap=not args.no_overlap, aux_slots=aux,
-                           transport=args.transport, exchange_always=args.force_exchange and world == 1)
+                           transport=args.transport, exchange_always=args.force_exchange and world == 1,
+                           pairs=only_pairs if world == 1 else None, side_priority=args.side_priority)
     torch.cuda.synchronize()
 
     def barrier():
@@ -311,6 +322,7 @@ def main():
                        "transport": args.transport if world > 1 else None},
             "rccl_ranks": world if (grouped and (args.backend == "nccl" or args.transport == "rccl")) else 0,
             "forced_exchange": bool(args.force_exchange and world == 1),
+            "emulated_world": int(args.emulate_world) if world == 1 else 0, "side_priority": args.side_priority,
             "roofline": {"bound": "hbm", "kernel": "welch_kernel<4096> + welch_finalize_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic"], "traffic_unit": "HBM bytes per launch",
@@ -336,7 +348,7 @@ def main():
                         "lag_margins": [round(m, 4) for m in tdoa.margins], "onsets": onsets,
                         "jamming_ranges_rank0": results[0].jamming_byte_ranges()[:4],
                         "baseline_rank0": results[0].baseline, "amp_mean": [r.amp_mean for r in results]},
-            "self_check": self_check(results, tdoa, onsets, nsamp, stream.n_ant),
+            "self_check": self_check(results, tdoa, onsets, nsamp, stream.n_ant, len(stream.pairs) if only_pairs else None),
             "host": host_info(),
         }
         if k5_ms is not None:
@@ -531,7 +543,7 @@ def rendezvous_only(args, torch, world, rank, local_rank):
     return 0 if ok else 1
 
 
-def self_check(results, tdoa, onsets, nsamp, n_ant):
+def self_check(results, tdoa, onsets, nsamp, n_ant, n_pairs=None):
     """The synthetic captures carry a known answer: antenna a sees the common burst DELAYS[a]
     samples late, so for every solved pair  lag(i, j) + onset_j - onset_i == DELAYS[j] - DELAYS[i];
     every stream's jammed byte range must be the burst span (to one 64-KiB chunk)."""
@@ -545,7 +557,8 @@ def self_check(results, tdoa, onsets, nsamp, n_ant):
         want1 = 2 * (int(JAM_SPAN[1] * nsamp) + DELAYS[r.rank % len(DELAYS)])
         ok_ranges.append(len(rng) == 1 and abs(rng[0][0] - want0) <= 65536 and abs(rng[0][1] - want1) <= 65536)
         ok_rank.append(r.rank == k and r.amp_first == 0 and r.amp_count == nsamp and r.onset > 0)
-    n_pairs = n_ant * (n_ant - 1) // 2
+    if n_pairs is None:
+        n_pairs = n_ant * (n_ant - 1) // 2
     return {"tdoa_pairs_ok": bool(ok_pairs) and all(ok_pairs) and len(ok_pairs) == n_pairs,
             "pairs_checked": len(ok_pairs), "jamming_ranges_ok": all(ok_ranges), "streams_ok": all(ok_rank),
             "streams_checked": len(results),

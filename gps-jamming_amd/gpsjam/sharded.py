@@ -352,6 +352,8 @@ class AntennaStream:
 
     ``exchange_always``: with ``world_size == 1`` and an initialised process group of one, still issue the slot
     all-gather and the result gather (what N > 1 ranks do), so that the collective path can be run on one GPU.
+    ``pairs`` (single-rank use): solve only these antenna pairs instead of all of them; ``side_priority``: HIP stream
+    priority of the second stream (0 default, -1 high).
     ``aux_slots`` (single-rank use): pre-filled TDOA slots of further antennas, [n_aux, slot_bytes]
     uint8; the rank then solves all pairs over 1 + n_aux antennas itself (BASELINE configs[3]:
     three antennas, three pairs on one GPU).
@@ -367,7 +369,8 @@ class AntennaStream:
                  slice_samples: int = 1 << 19, noise_samples: int = 200000, window: int = 1000,
                  factor: float = 50.0, rssi_threshold: float = 0.0, rank: int = 0, world_size: int = 1,
                  overlap: Optional[bool] = None, aux_slots: Optional[torch.Tensor] = None,
-                 transport="torch", side_device=None, exchange_always: bool = False):
+                 transport="torch", side_device=None, exchange_always: bool = False, pairs=None,
+                 side_priority: int = 0):
         assert capture.dtype == torch.uint8 and capture.is_contiguous()
         self.dev, self.cap = dev, capture
         # K2 is bound by VALU issue and leaves ~90 % of the HBM bandwidth idle, the fused scan is HBM
@@ -386,7 +389,9 @@ class AntennaStream:
         if self.overlap:
             self.dev_side = side_device if side_device is not None else type(dev)(dev.index)
             self._own_side = side_device is None
-            self._side = torch.cuda.Stream(device=capture.device)
+            # side_priority < 0: a high-priority HIP stream -- its (short) kernels are dispatched ahead of K2's waiting
+            # workgroups, which shortens the scan -> slot -> exchange -> K5 chain without changing the total work
+            self._side = torch.cuda.Stream(device=capture.device, priority=int(side_priority))
             self.dev_side.set_stream(self._side.cuda_stream)
             self._ev_free = torch.cuda.Event()      # main: previous results consumed, buffers may be rewritten
             self._ev_side = torch.cuda.Event()      # side: scan / TDOA results ready
@@ -429,7 +434,10 @@ class AntennaStream:
         self.n_ant = world_size if world_size > 1 else 1 + n_aux
         self.is_root = rank == 0
         self.pairs = all_pairs(self.n_ant) if world_size == 1 else pairs_of_rank(rank, world_size)
-        self.pair_cap = pair_capacity(world_size, self.n_ant)
+        if pairs is not None:                      # single-rank use: solve these pairs only (load rehearsals)
+            assert world_size == 1 and all(0 <= i < self.n_ant and 0 <= j < self.n_ant for i, j in pairs)
+            self.pairs = [tuple(p) for p in pairs]
+        self.pair_cap = max(pair_capacity(world_size, self.n_ant), len(self.pairs))
         self.slots = torch.zeros((self.n_ant, self.slot_bytes), dtype=torch.uint8, device=d)
         if n_aux:
             assert aux_slots.shape[1] == self.slot_bytes and aux_slots.dtype == torch.uint8
