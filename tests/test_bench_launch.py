@@ -103,3 +103,20 @@ def test_collective_path_over_rccl_on_one_gpu():
     assert line["n_gpus"] == 1 and line["forced_exchange"] is True and line["rccl_ranks"] == 1
     assert line["self_check"]["passed"] is True, line["self_check"]
     assert line["self_check"]["pairs_checked"] == 3 and line["results"]["lags"] and line["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_per_rank_load_of_eight_antennas_on_one_gpu():
+    """`--emulate-world 8 --force-exchange`: rank 0's share of an eight-antenna deployment (seven further slots, 4 of the
+    28 pairs in one K5 launch, both collectives over the one-rank RCCL group) -- the lags must come out at the delays
+    the captures were built with."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--emulate-world", "8", "--force-exchange", "--steps", "2",
+                        "--warmup", "1", "--precondition", "2", "--no-cpu-baseline", "--no-end-to-end",
+                        "--capture-bytes", str(1 << 28)],
+                       capture_output=True, text=True, env=_env(), timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["emulated_world"] == 8 and line["config"]["xcorr_antennas"] == 8 and line["config"]["xcorr_pairs"] == 4
+    assert line["results"]["pairs"] == [[0, 1], [0, 2], [0, 3], [0, 4]]
+    assert line["self_check"]["passed"] is True and line["self_check"]["pairs_checked"] == 4, line["self_check"]
