@@ -15,7 +15,7 @@ for mb in (40.96, 245.76):
     dev.ingest(host).free()
     first, again, arr = [], [], []
     for rep in range(5):
-        p = f"/dev/shm/gpsjam_probe_{os.getpid()}_{rep}.bin"
+        p = os.path.join(os.environ.get("GPSJAM_PROBE_DIR", "/dev/shm"), f"gpsjam_probe_{os.getpid()}_{rep}.bin")
         host.tofile(p)
         for out in (first, again):
             t0 = time.perf_counter()
