@@ -72,7 +72,7 @@ def test_capture_from_file_and_array_equals_host_path(dev, tmp_path):
 
 
 def test_large_capture_goes_through_the_bounce_buffers(dev, tmp_path):
-    """Above 64 MiB both upload forms use the pinned bounce pipeline (4 fill threads)."""
+    """Large uploads (every staged copy from 4 MiB up) use the pinned bounce pipeline: pieces sized to the capture, eight fill threads."""
     n = 40_000_000                                          # 80 MB
     raw = np.arange(2 * n, dtype=np.uint32).astype(np.uint8)
     raw[1::7] ^= 0x5a
