@@ -413,7 +413,8 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
         return t
 
     st = split.SplitStreams(dev, [nbytes] * A, make_buffer, make_noise, rank=rank, world_size=world, nperseg=NPERSEG,
-                            chunk_samples=CHUNK_SAMPLES, slice_samples=SLICE, overlap=not args.no_overlap)
+                            chunk_samples=CHUNK_SAMPLES, slice_samples=SLICE, overlap=not args.no_overlap,
+                            exchange_always=args.force_exchange and world == 1)
     torch.cuda.synchronize()
 
     def barrier():
@@ -462,7 +463,8 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
                        "xcorr_slice": SLICE, "sharding": "captures split into parts (gpsjam.split)",
                        "parts": [[p.antenna, p.part, p.parts, p.first_byte, p.own_bytes, p.rank] for p in st.parts],
                        "backend": args.backend if world > 1 else None},
-            "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
+            "rccl_ranks": world if ((world > 1 or args.force_exchange) and args.backend == "nccl") else 0,
+            "forced_exchange": bool(args.force_exchange and world == 1),
             "roofline": {"bound": "hbm", "kernel": "welch_kernel<4096> + welch_finalize_kernel over rank 0's parts",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes_per_launch": own, "avg_launch_ms": welch_ms,

@@ -211,8 +211,10 @@ class SplitStreams:
     def __init__(self, dev, capture_bytes: Sequence[int], make_buffer, make_noise, *, rank: int = 0, world_size: int = 1,
                  chunk_bytes: int = 65536, chunk_samples: int = 2048000, nperseg: int = 4096, fs: float = 2.048e6,
                  slice_samples: int = 1 << 19, noise_samples: int = 200000, window: int = 1000, factor: float = 50.0,
-                 rssi_threshold: float = 0.0, overlap: Optional[bool] = None, device=None):
+                 rssi_threshold: float = 0.0, overlap: Optional[bool] = None, device=None, exchange_always: bool = False):
         self.dev, self.rank, self.world = dev, rank, world_size
+        # a process group of one: still issue the slot all-gather and the part gather (the collective path on one GPU)
+        self._always = bool(exchange_always) and world_size == 1
         self.capture_bytes = [int(b) for b in capture_bytes]
         self.n_ant = len(self.capture_bytes)
         self.chunk_bytes, self.chunk_samples, self.nperseg, self.fs = chunk_bytes, chunk_samples, nperseg, fs
@@ -335,8 +337,8 @@ class SplitStreams:
         with self._on_side():
             for j, s in enumerate(self.streams):
                 s.slot(self.my_slots[j])
-            if self.world > 1:
-                allgather_rows(self.my_slots.view(-1), self.world, out=self.all_slots.view(self.world, -1))
+            if self.world > 1 or self._always:
+                allgather_rows(self.my_slots.view(-1), self.world, out=self.all_slots.view(self.world, -1), always=self._always)
                 slots = self.all_slots
             else:
                 slots = self.my_slots
@@ -381,8 +383,8 @@ class SplitStreams:
         if self.overlap:
             self._side.wait_event(self._ev_packed)
         with self._on_side():
-            if self.world > 1:
-                rows = gather_rows(vec.view(-1), self.rank, self.world, 0, out=self._gathered[k])
+            if self.world > 1 or self._always:
+                rows = gather_rows(vec.view(-1), self.rank, self.world, 0, out=self._gathered[k], always=self._always)
             else:
                 rows = vec.view(1, -1)
             if self.is_root:

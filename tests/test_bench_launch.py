@@ -120,3 +120,17 @@ def test_per_rank_load_of_eight_antennas_on_one_gpu():
     assert line["emulated_world"] == 8 and line["config"]["xcorr_antennas"] == 8 and line["config"]["xcorr_pairs"] == 4
     assert line["results"]["pairs"] == [[0, 1], [0, 2], [0, 3], [0, 4]]
     assert line["self_check"]["passed"] is True and line["self_check"]["pairs_checked"] == 4, line["self_check"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_split_collective_path_over_rccl_on_one_gpu():
+    """`--split --force-exchange` at N = 1: the slot all-gather and the part-vector gather of the split path over the
+    one-rank RCCL group; results as in the plain split run (self_check)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--split", "--force-exchange", "--steps", "2", "--warmup", "1",
+                        "--precondition", "2", "--capture-bytes", str(1 << 27)],
+                       capture_output=True, text=True, env=_env(), timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["scaling"] == "strong" and line["forced_exchange"] is True and line["rccl_ranks"] == 1
+    assert line["self_check"]["passed"] is True, line["self_check"]
