@@ -28,7 +28,7 @@ prices the same launch against the measured VALU issue ceiling (what actually bo
 against what the synthetic captures were built to contain (known delays, known burst span), so a
 wrong multi-GPU exchange cannot print a plausible number.  ``cpu_baseline`` times the
 numpy/scipy oracle (oracle/gpsjam_oracle.py, kind "port") on a bounded prefix of the same
-capture on the host's cores (one process per rank for N > 1).  ``end_to_end`` (N = 1) is the
+capture on the host's cores (rank 0 at N = 1; with --cpu-baseline-all-ranks one process per rank at N > 1).  ``end_to_end`` (N = 1) is the
 file / host buffer -> result rate with PCIe included; it is never ``value``.
 """
 import argparse
@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--capture-bytes", type=int, default=CAPTURE_BYTES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--cpu-baseline-all-ranks", action="store_true",
+                    help="N > 1: every rank times the oracle on a prefix of its capture (default: the CPU baseline is N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--transport", default="torch", choices=("torch", "rccl"),
                     help="collectives through torch.distributed, or through the library's own gj_comm_* (RCCL)")
@@ -287,7 +289,9 @@ def main():
 
     # CPU baseline: every rank times the oracle on a prefix of ITS capture at the same moment
     cpu = None
-    if not args.no_cpu_baseline:
+    # the contract asks for the CPU baseline on rank 0 at N = 1 only; --cpu-baseline-all-ranks times one oracle process
+    # per rank at N > 1 as well
+    if not args.no_cpu_baseline and (world == 1 or args.cpu_baseline_all_ranks or args.cpu_sample_chunks):
         chunks = args.cpu_sample_chunks or (24 if world == 1 else 8)
         barrier()
         cpu = cpu_baseline(np, cap, chunks, stream, gathered if rank == 0 else None, world)
