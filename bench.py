@@ -122,11 +122,15 @@ def main():
                     help="diagnostic: ranks only form the process group, all-reduce one number and print it")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
                     help="seconds the self-launched ranks of --gpus N > 1 may take before they are stopped")
+    ap.add_argument("--no-diagnosis", action="store_true",
+                    help="self-launched ranks that fail are NOT followed by one fresh --rendezvous-only run")
+    ap.add_argument("--fail-rank", type=int, default=-1,
+                    help="diagnostic (tests): this rank exits with status 3 once the process group has formed")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process never touches the GPU, it starts one rank per GPU
-        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout))
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout, args))
 
     guard_stdout()
     import numpy as np
@@ -164,6 +168,10 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
         else:
             dist.init_process_group(backend=args.backend, timeout=limit)
+
+    if grouped and args.fail_rank == rank:
+        print(f"[bench] rank {rank}: --fail-rank, leaving with status 3", file=sys.stderr, flush=True)
+        os._exit(3)
 
     dev = gpsjam.Device(local_rank)
     # one explicit HIP stream for everything in the step: the gpsjam kernels, torch's small
@@ -286,6 +294,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     welch_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+    proof = exchange_proof(args, torch, dist if grouped else None, dev, stream.comm, world, rank)
 
     # CPU baseline: every rank times the oracle on a prefix of ITS capture at the same moment
     cpu = None
@@ -324,7 +333,7 @@ def main():
                        "xcorr_slice": SLICE, "xcorr_antennas": stream.n_ant, "xcorr_pairs": len(tdoa.pairs),
                        "streams": world, "sharding": "one capture per GPU", "backend": args.backend if world > 1 else None,
                        "transport": args.transport if world > 1 else None},
-            "rccl_ranks": world if (grouped and (args.backend == "nccl" or args.transport == "rccl")) else 0,
+            **proof,
             "forced_exchange": bool(args.force_exchange and world == 1),
             "emulated_world": int(args.emulate_world) if world == 1 else 0, "side_priority": args.side_priority,
             "roofline": {"bound": "hbm", "kernel": "welch_kernel<4096> + welch_finalize_kernel",
@@ -352,7 +361,8 @@ def main():
                         "lag_margins": [round(m, 4) for m in tdoa.margins], "onsets": onsets,
                         "jamming_ranges_rank0": results[0].jamming_byte_ranges()[:4],
                         "baseline_rank0": results[0].baseline, "amp_mean": [r.amp_mean for r in results]},
-            "self_check": self_check(results, tdoa, onsets, nsamp, stream.n_ant, len(stream.pairs) if only_pairs else None),
+            "self_check": self_check(results, tdoa, onsets, nsamp, stream.n_ant, len(stream.pairs) if only_pairs else None,
+                                     proof=proof, world=world, share_gpu=args.share_gpu),
             "host": host_info(),
         }
         if k5_ms is not None:
@@ -450,6 +460,7 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
     elapsed = float(t.item())
     welch_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
     own = sum(p.own_bytes for p in st.mine)
+    proof = exchange_proof(args, torch, dist if (world > 1 or args.force_exchange) else None, dev, None, world, rank)
     if rank == 0:
         results, tdoa = got.unpack()
         onsets = [r.onset for r in results]
@@ -467,7 +478,7 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
                        "xcorr_slice": SLICE, "sharding": "captures split into parts (gpsjam.split)",
                        "parts": [[p.antenna, p.part, p.parts, p.first_byte, p.own_bytes, p.rank] for p in st.parts],
                        "backend": args.backend if world > 1 else None},
-            "rccl_ranks": world if ((world > 1 or args.force_exchange) and args.backend == "nccl") else 0,
+            **proof,
             "forced_exchange": bool(args.force_exchange and world == 1),
             "roofline": {"bound": "hbm", "kernel": "welch_kernel<4096> + welch_finalize_kernel over rank 0's parts",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -476,19 +487,76 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
                          "note": "K2 over the bytes rank 0 owns, as run beside the scan / TDOA kernels (DESIGN.md section 5)"},
             "results": {"pairs": [list(p) for p in tdoa.pairs], "lags": tdoa.lags, "onsets": onsets,
                         "amp_mean": [r.amp_mean for r in results], "baseline": [r.baseline for r in results]},
-            "self_check": self_check(results, tdoa, onsets, nsamp, A),
+            "self_check": self_check(results, tdoa, onsets, nsamp, A, proof=proof, world=world, share_gpu=args.share_gpu),
             "host": host_info(),
         }
         emit(line)
     st.close()
 
 
-def launch_ranks(n, argv, limit_s):
-    """`python bench.py --gpus N` without a launcher: start N ranks of this script under
-    torch.distributed.run as a CHILD process (never an exec; this parent has not initialised the GPU
-    and never does), pass their output through -- rank 0's JSON line goes to stdout as it is -- and
-    return their exit status: non-zero when any rank died, when the 300-s collective timeout inside
-    the ranks fired, or when the whole run outlived --launch-timeout."""
+ID_BYTES = 256
+
+
+def parse_identity(text):
+    """'rank=0 pid=1 host=h pci=0000:05:00.0 uuid=ab.. hip=0 torch=..' -> dict (values stay strings but rank / pid / hip)."""
+    out = {}
+    for tok in text.split():
+        k, _, v = tok.partition("=")
+        out[k] = int(v) if k in ("rank", "pid", "hip") and v.lstrip("-").isdigit() else v
+    return out
+
+
+def torch_device_identity(torch, index):
+    """torch's own view of the device a rank computes on (uuid / PCI ids when this torch exposes them)."""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+    except Exception:
+        return "none"
+    bits = [str(getattr(pr, "uuid", "?"))]
+    if hasattr(pr, "pci_bus_id"):
+        bits.append("%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0)))
+    return "/".join(bits)
+
+
+def exchange_proof(args, torch, dist, dev, comm, world, rank):
+    """What the line claims about the exchange, read from the LIVE communicators instead of the command line, and the
+    physical device of every rank, all-gathered as bytes through the same collective path the step uses
+    (torch.distributed all-gather, or gj_comm_allgather_dev with --transport rccl).  A collective: every rank calls it.
+      rccl_ranks   ranks of the RCCL communicator that carried the exchange (0: none did -- gloo, or no group)
+      devices      one record per rank: pid, host, PCI bus id and uuid of the gpsjam context's GPU, torch's view
+      rehearsal    true when the ranks did not have a GPU each over RCCL (--share-gpu, gloo, --emulate-world)"""
+    import socket
+    text = (f"rank={rank} pid={os.getpid()} host={socket.gethostname()} {dev.identity()} "
+            f"torch={torch_device_identity(torch, torch.cuda.current_device())}")
+    raw = text.encode()[:ID_BYTES].ljust(ID_BYTES, b" ")
+    mine = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+    rccl_ranks, via = 0, "none (single process, no group)"
+    if comm is not None:                                    # the library's own RCCL communicator
+        rows = torch.zeros((world, ID_BYTES), dtype=torch.uint8, device="cuda")
+        comm.allgather(mine, ID_BYTES, rows)
+        comm.dev.synchronize()
+        live_rank, rccl_ranks, live_dev = comm.live()
+        via = f"gj_comm_allgather_dev (ncclCommCount {rccl_ranks}, ncclCommUserRank {live_rank}, ncclCommCuDevice {live_dev})"
+    elif dist is not None and dist.is_initialized():
+        n = dist.get_world_size()
+        rows = torch.zeros((n, ID_BYTES), dtype=torch.uint8, device="cuda")
+        dist.all_gather_into_tensor(rows.view(-1), mine)
+        backend = dist.get_backend()
+        rccl_ranks = n if backend == "nccl" else 0
+        via = f"torch.distributed.all_gather_into_tensor over {backend} (get_world_size {n})"
+    else:
+        rows = mine.unsqueeze(0)
+    torch.cuda.synchronize()
+    devices = [parse_identity(bytes(r.tolist()).decode(errors="replace")) for r in rows.cpu()]
+    distinct = len({(d.get("host"), d.get("pci"), d.get("uuid")) for d in devices})
+    rehearsal = bool(args.share_gpu or args.emulate_world or (world > 1 and rccl_ranks != world))
+    return {"rccl_ranks": rccl_ranks, "ranks_seen": len(devices), "devices": devices, "distinct_devices": distinct,
+            "rehearsal": rehearsal, "identity_exchanged_via": via}
+
+
+def run_ranks(n, argv, limit_s, stdout=None):
+    """N ranks of this script under torch.distributed.run as ONE child process; returns (status, its stdout or None).
+    124 = stopped at the limit."""
     import signal
     import socket
     import subprocess
@@ -503,7 +571,7 @@ def launch_ranks(n, argv, limit_s):
     print("[bench] launching " + " ".join(cmd), file=sys.stderr, flush=True)
     # same session and process group as this parent: whatever stops the parent's group stops the ranks too; a
     # SIGTERM / SIGINT sent to the parent alone is handed on (torch.distributed.run takes its workers down on SIGTERM)
-    proc = subprocess.Popen(cmd, env=env)
+    proc = subprocess.Popen(cmd, env=env, stdout=stdout, text=True if stdout is not None else None)
 
     def hand_on(signum, _frame):
         if proc.poll() is None:
@@ -512,16 +580,50 @@ def launch_ranks(n, argv, limit_s):
     for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
         signal.signal(sig, hand_on)
     try:
-        return proc.wait(timeout=limit_s)
+        out, _ = proc.communicate(timeout=limit_s)
+        return proc.returncode, out
     except subprocess.TimeoutExpired:
         print(f"[bench] ranks still running after {limit_s:.0f} s: stopping them", file=sys.stderr, flush=True)
     proc.terminate()                            # exactly the child this call started
     try:
-        proc.wait(timeout=30)
+        out, _ = proc.communicate(timeout=30)
     except subprocess.TimeoutExpired:
         proc.kill()
-        proc.wait()
-    return 124
+        out, _ = proc.communicate()
+    return 124, out
+
+
+def launch_ranks(n, argv, limit_s, args=None):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under
+    torch.distributed.run as a CHILD process (never an exec; this parent has not initialised the GPU
+    and never does), pass their output through -- rank 0's JSON line goes to stdout as it is -- and
+    return their exit status: non-zero when any rank died, when the 300-s collective timeout inside
+    the ranks fired, or when the whole run outlived --launch-timeout.
+    A failed run diagnoses itself: ONE fresh `--rendezvous-only` child with the same rank count, backend and device
+    assignment follows, and its verdict goes to stderr -- "the ranks cannot form a group on this node" and "the group
+    forms, the failure is in the step" are told apart without a second manual run.  The status returned is the first
+    run's."""
+    import subprocess
+    status, _ = run_ranks(n, argv, limit_s)
+    if status == 0 or args is None or args.no_diagnosis:
+        return status
+    probe = ["--gpus", str(n), "--backend", args.backend, "--rendezvous-only", "--no-diagnosis"]
+    if args.share_gpu:
+        probe.append("--share-gpu")
+    print(f"[bench] the ranks ended with status {status}; diagnosis: one fresh --rendezvous-only run of {n} ranks "
+          f"over {args.backend}", file=sys.stderr, flush=True)
+    d_status, out = run_ranks(n, probe, min(240.0, limit_s), stdout=subprocess.PIPE)
+    line = next((ln for ln in (out or "").splitlines() if ln.startswith("{")), None)
+    if d_status == 0 and line:
+        print(f"[bench] diagnosis: rendezvous ok -- {n} ranks formed a {args.backend} group and all-reduced: {line}\n"
+              f"[bench] diagnosis: the failure above is in the run itself (a rank died or a collective of the step "
+              f"never completed), not in forming the group", file=sys.stderr, flush=True)
+    else:
+        print(f"[bench] diagnosis: rendezvous FAILED too (status {d_status}"
+              + (f", said {line}" if line else ", no line from rank 0") + f"): {n} ranks cannot form a {args.backend} "
+              f"group on this node -- look at the launcher / RCCL messages above before anything in the DSP path",
+              file=sys.stderr, flush=True)
+    return status
 
 
 def rendezvous_only(args, torch, world, rank, local_rank):
@@ -542,17 +644,29 @@ def rendezvous_only(args, torch, world, rank, local_rank):
         t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t)
     ok = float(t.item()) == world * (world + 1) / 2
+    # who sat where: every rank's pid and (with a GPU) torch's view of its device, all-gathered over the group just made
+    ident = f"rank={rank} pid={os.getpid()} torch=" + (torch_device_identity(torch, local_rank) if t.is_cuda else "cpu")
+    mine = torch.frombuffer(bytearray(ident.encode()[:ID_BYTES].ljust(ID_BYTES, b" ")), dtype=torch.uint8).to(t.device)
+    rows = torch.zeros((world, ID_BYTES), dtype=torch.uint8, device=t.device)
+    dist.all_gather_into_tensor(rows.view(-1), mine)
+    seats = [parse_identity(bytes(r.tolist()).decode(errors="replace")) for r in rows.cpu()]
+    ok = ok and [d.get("rank") for d in seats] == list(range(world))
     if rank == 0:
-        emit({"rendezvous": "ok" if ok else "wrong sum", "world": world, "backend": args.backend, "sum": float(t.item())})
+        emit({"rendezvous": "ok" if ok else "wrong sum", "world": dist.get_world_size(), "backend": dist.get_backend(),
+              "sum": float(t.item()), "seats": seats})
+    if args.fail_rank == rank:
+        print(f"[bench] rank {rank}: --fail-rank, leaving with status 3", file=sys.stderr, flush=True)
+        os._exit(3)
     dist.barrier()
     dist.destroy_process_group()
     return 0 if ok else 1
 
 
-def self_check(results, tdoa, onsets, nsamp, n_ant, n_pairs=None):
+def self_check(results, tdoa, onsets, nsamp, n_ant, n_pairs=None, proof=None, world=1, share_gpu=False):
     """The synthetic captures carry a known answer: antenna a sees the common burst DELAYS[a]
     samples late, so for every solved pair  lag(i, j) + onset_j - onset_i == DELAYS[j] - DELAYS[i];
-    every stream's jammed byte range must be the burst span (to one 64-KiB chunk)."""
+    every stream's jammed byte range must be the burst span (to one 64-KiB chunk).  N > 1 ranks must have reported N
+    distinct physical devices (unless --share-gpu said they would not): N ranks on one GPU is not an N-GPU run."""
     ok_pairs = []
     for (i, j), lag in zip(tdoa.pairs, tdoa.lags):
         ok_pairs.append(lag + onsets[j] - onsets[i] == DELAYS[j % len(DELAYS)] - DELAYS[i % len(DELAYS)])
@@ -565,10 +679,15 @@ def self_check(results, tdoa, onsets, nsamp, n_ant, n_pairs=None):
         ok_rank.append(r.rank == k and r.amp_first == 0 and r.amp_count == nsamp and r.onset > 0)
     if n_pairs is None:
         n_pairs = n_ant * (n_ant - 1) // 2
+    devices_ok = True
+    if proof is not None:
+        seen = [d.get("rank") for d in proof["devices"]]
+        devices_ok = seen == list(range(world)) and (world == 1 or share_gpu or proof["distinct_devices"] == world)
     return {"tdoa_pairs_ok": bool(ok_pairs) and all(ok_pairs) and len(ok_pairs) == n_pairs,
             "pairs_checked": len(ok_pairs), "jamming_ranges_ok": all(ok_ranges), "streams_ok": all(ok_rank),
-            "streams_checked": len(results),
-            "passed": bool(ok_pairs) and all(ok_pairs) and len(ok_pairs) == n_pairs and all(ok_ranges) and all(ok_rank)}
+            "streams_checked": len(results), "devices_ok": devices_ok,
+            "passed": bool(ok_pairs) and all(ok_pairs) and len(ok_pairs) == n_pairs and all(ok_ranges) and all(ok_rank)
+                      and devices_ok}
 
 
 def host_info():

@@ -250,6 +250,22 @@ int gj_device_info(gj_ctx* ctx, char* name, size_t name_cap, int* compute_units,
     return GJ_OK;
 }
 
+int gj_device_identity(gj_ctx* ctx, char* out, size_t cap) {
+    if (!ctx || !out || cap < 2) return GJ_ERR_INVALID;
+    Guard g(ctx);
+    char pci[32] = "?";
+    GJ_HIP(ctx, hipDeviceGetPCIBusId(pci, (int)sizeof(pci), ctx->device));
+    hipUUID uuid;
+    memset(&uuid, 0, sizeof(uuid));
+    char hex[2 * sizeof(uuid.bytes) + 1] = {0};
+    if (hipDeviceGetUuid(&uuid, ctx->device) == hipSuccess)
+        for (size_t k = 0; k < sizeof(uuid.bytes); ++k) snprintf(hex + 2 * k, 3, "%02x", (unsigned char)uuid.bytes[k]);
+    else
+        (void)hipGetLastError();
+    snprintf(out, cap, "pci=%s uuid=%s hip=%d", pci, hex[0] ? hex : "?", ctx->device);
+    return GJ_OK;
+}
+
 int gj_reserve(gj_ctx* ctx, size_t workspace_bytes) {
     if (!ctx) return GJ_ERR_INVALID;
     int rc;

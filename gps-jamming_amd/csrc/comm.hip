@@ -30,6 +30,9 @@ struct Rccl {
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
     char why[256] = {0};
 };
 
@@ -59,6 +62,9 @@ static Rccl* rccl() {
         GJ_SYM(Broadcast, "ncclBroadcast");
         GJ_SYM(AllGather, "ncclAllGather");
         GJ_SYM(GetErrorString, "ncclGetErrorString");
+        GJ_SYM(CommCount, "ncclCommCount");
+        GJ_SYM(CommUserRank, "ncclCommUserRank");
+        GJ_SYM(CommCuDevice, "ncclCommCuDevice");
 #undef GJ_SYM
     });
     return &r;
@@ -127,40 +133,81 @@ int gj_comm_init_rank(gj_ctx* ctx, const void* id, int rank, int n_ranks, gj_com
 
 int gj_comm_rank(gj_comm* c, int* rank, int* n_ranks) {
     if (!c) return GJ_ERR_INVALID;
-    if (rank) *rank = c->rank;
-    if (n_ranks) *n_ranks = c->n_ranks;
+    // read from the LIVE communicator, not from what gj_comm_init_rank was told: a caller that reports "N ranks"
+    // (bench.py's rccl_ranks) reports what RCCL itself holds.  A communicator whose context is gone answers 0 of 0.
+    int r = -1, n = 0;
+    if (c->comm) {
+        Rccl* lib = rccl();
+        if (lib->CommUserRank(c->comm, &r) != ncclSuccess || lib->CommCount(c->comm, &n) != ncclSuccess) return GJ_ERR_HIP;
+    }
+    if (rank) *rank = r;
+    if (n_ranks) *n_ranks = n;
+    return GJ_OK;
+}
+
+int gj_comm_device(gj_comm* c, int* hip_device) {
+    if (!c || !hip_device) return GJ_ERR_INVALID;
+    *hip_device = -1;
+    if (c->comm && rccl()->CommCuDevice(c->comm, hip_device) != ncclSuccess) return GJ_ERR_HIP;
+    return GJ_OK;
+}
+
+// The collectives: arguments are checked and the stream is read under the context lock; the RCCL call itself is made
+// WITHOUT it.  A communicator's first collective sets up its peer connections inside the call and can block until
+// every peer has arrived -- a host-side wait like any other, and include/gpsjam.h promises that the lock is never
+// held across one (a second thread scanning on the same context must not stall behind a late rank).  The order of
+// collectives on one communicator is the caller's business, as it is with RCCL itself.
+struct CommCall {
+    gj_ctx* ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    int rank = 0, n_ranks = 1;
+};
+
+static int comm_call_begin(gj_comm* c, CommCall& k) {
+    if (!c || !c->ctx || !c->comm) return GJ_ERR_INVALID;   // destroyed, or its context is gone
+    k.ctx = c->ctx;
+    Guard g(k.ctx);
+    if (!c->comm) return GJ_ERR_INVALID;
+    k.comm = c->comm;
+    k.stream = k.ctx->stream;
+    k.rank = c->rank;
+    k.n_ranks = c->n_ranks;
     return GJ_OK;
 }
 
 int gj_comm_gather_dev(gj_comm* c, const void* d_send, size_t bytes, void* d_recv, int root) {
-    if (!c || !c->ctx || !c->comm) return GJ_ERR_INVALID;   // destroyed, or its context is gone
-    gj_ctx* ctx = c->ctx;
-    Guard g(ctx);
-    if (root < 0 || root >= c->n_ranks) return fail(ctx, GJ_ERR_INVALID, "root %d of %d", root, c->n_ranks);
-    if (!d_send || (c->rank == root && !d_recv)) return fail(ctx, GJ_ERR_INVALID, "null buffer");
-    const ncclResult_t rc = rccl()->Gather(d_send, d_recv, bytes, ncclUint8, root, c->comm, ctx->stream);
-    if (rc != ncclSuccess) return rccl_fail(ctx, "ncclGather", rc);
+    CommCall k;
+    if (int rc = comm_call_begin(c, k)) return rc;
+    if (root < 0 || root >= k.n_ranks) return fail(k.ctx, GJ_ERR_INVALID, "root %d of %d", root, k.n_ranks);
+    if (!d_send || (k.rank == root && !d_recv)) return fail(k.ctx, GJ_ERR_INVALID, "null buffer");
+    NoCancel nc;
+    (void)hipSetDevice(k.ctx->device);
+    const ncclResult_t rc = rccl()->Gather(d_send, d_recv, bytes, ncclUint8, root, k.comm, k.stream);
+    if (rc != ncclSuccess) return rccl_fail(k.ctx, "ncclGather", rc);
     return GJ_OK;
 }
 
 int gj_comm_allgather_dev(gj_comm* c, const void* d_send, size_t bytes, void* d_recv) {
-    if (!c || !c->ctx || !c->comm) return GJ_ERR_INVALID;   // destroyed, or its context is gone
-    gj_ctx* ctx = c->ctx;
-    Guard g(ctx);
-    if (!d_send || !d_recv) return fail(ctx, GJ_ERR_INVALID, "null buffer");
-    const ncclResult_t rc = rccl()->AllGather(d_send, d_recv, bytes, ncclUint8, c->comm, ctx->stream);
-    if (rc != ncclSuccess) return rccl_fail(ctx, "ncclAllGather", rc);
+    CommCall k;
+    if (int rc = comm_call_begin(c, k)) return rc;
+    if (!d_send || !d_recv) return fail(k.ctx, GJ_ERR_INVALID, "null buffer");
+    NoCancel nc;
+    (void)hipSetDevice(k.ctx->device);
+    const ncclResult_t rc = rccl()->AllGather(d_send, d_recv, bytes, ncclUint8, k.comm, k.stream);
+    if (rc != ncclSuccess) return rccl_fail(k.ctx, "ncclAllGather", rc);
     return GJ_OK;
 }
 
 int gj_comm_bcast_dev(gj_comm* c, void* d_buf, size_t bytes, int root) {
-    if (!c || !c->ctx || !c->comm) return GJ_ERR_INVALID;   // destroyed, or its context is gone
-    gj_ctx* ctx = c->ctx;
-    Guard g(ctx);
-    if (root < 0 || root >= c->n_ranks) return fail(ctx, GJ_ERR_INVALID, "root %d of %d", root, c->n_ranks);
-    if (!d_buf) return fail(ctx, GJ_ERR_INVALID, "null buffer");
-    const ncclResult_t rc = rccl()->Broadcast(d_buf, d_buf, bytes, ncclUint8, root, c->comm, ctx->stream);
-    if (rc != ncclSuccess) return rccl_fail(ctx, "ncclBroadcast", rc);
+    CommCall k;
+    if (int rc = comm_call_begin(c, k)) return rc;
+    if (root < 0 || root >= k.n_ranks) return fail(k.ctx, GJ_ERR_INVALID, "root %d of %d", root, k.n_ranks);
+    if (!d_buf) return fail(k.ctx, GJ_ERR_INVALID, "null buffer");
+    NoCancel nc;
+    (void)hipSetDevice(k.ctx->device);
+    const ncclResult_t rc = rccl()->Broadcast(d_buf, d_buf, bytes, ncclUint8, root, k.comm, k.stream);
+    if (rc != ncclSuccess) return rccl_fail(k.ctx, "ncclBroadcast", rc);
     return GJ_OK;
 }
 

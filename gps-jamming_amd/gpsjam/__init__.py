@@ -386,6 +386,12 @@ class Device:
         self._check(self._lib.gj_device_info(self._ctx, name, 256, C.byref(cus), C.byref(mem)))
         return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": mem.value}
 
+    def identity(self) -> str:
+        """Which physical GPU this context runs on: ``pci=<bus id> uuid=<hex> hip=<index>`` (gj_device_identity)."""
+        buf = C.create_string_buffer(160)
+        self._check(self._lib.gj_device_identity(self._ctx, buf, 160))
+        return buf.value.decode()
+
     def set_stream(self, stream_handle: Optional[int], external: bool = True):
         """Run on an external HIP stream (``torch.cuda.current_stream().cuda_stream``; 0 is
         the legacy default stream).  ``external=False`` returns to the context's own stream."""

@@ -99,7 +99,7 @@ GJ_MAX_ANTENNAS = 16
 GJ_LAG_INVALID = -(1 << 31)
 GJ_SLOT_HEADER = 16
 GJ_COMM_ID_BYTES = 128
-GJ_VERSION = 120
+GJ_VERSION = 130
 
 _vp, _sz, _i, _f, _d = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double
 _pf, _psz = C.POINTER(C.c_float), C.POINTER(C.c_size_t)
@@ -117,6 +117,7 @@ SIGNATURES = {
     "gj_set_unpack": (_i, [_vp, _d, _d]),
     "gj_get_unpack": (_i, [_vp, C.POINTER(_d), C.POINTER(_d)]),
     "gj_device_info": (_i, [_vp, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(C.c_uint64)]),
+    "gj_device_identity": (_i, [_vp, C.c_char_p, _sz]),
     "gj_reserve": (_i, [_vp, _sz]),
     "gj_debug_set_wait_hook": (_i, [_vp, _vp, _vp]),
     "gj_debug_counters": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
@@ -168,6 +169,7 @@ SIGNATURES = {
     "gj_comm_unique_id": (_i, [_vp]),
     "gj_comm_init_rank": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
     "gj_comm_rank": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "gj_comm_device": (_i, [_vp, C.POINTER(_i)]),
     "gj_comm_gather_dev": (_i, [_vp, _vp, _sz, _vp, _i]),
     "gj_comm_allgather_dev": (_i, [_vp, _vp, _sz, _vp]),
     "gj_comm_bcast_dev": (_i, [_vp, _vp, _sz, _i]),

@@ -79,6 +79,14 @@ class Communicator:
         dev._check(lib.gj_comm_init_rank(dev._ctx, uid, self.rank, self.world, C.byref(h)))
         self._h = h
 
+    def live(self):
+        """(rank, ranks, HIP device) as the live RCCL communicator reports them (ncclCommUserRank / ncclCommCount /
+        ncclCommCuDevice) -- not what this object was constructed with."""
+        r, n, d = C.c_int(-1), C.c_int(0), C.c_int(-1)
+        self.dev._check(self.dev._lib.gj_comm_rank(self._h, C.byref(r), C.byref(n)))
+        self.dev._check(self.dev._lib.gj_comm_device(self._h, C.byref(d)))
+        return r.value, n.value, d.value
+
     def gather(self, d_send, nbytes: int, d_recv=None, root: int = 0):
         """Every rank sends nbytes; ``root`` receives world * nbytes in rank order."""
         self.dev._check(self.dev._lib.gj_comm_gather_dev(self._h, _ptr(d_send), int(nbytes), _ptr(d_recv) or None, root))

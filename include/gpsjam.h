@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GJ_VERSION 120 /* 0.1.2: lanes (no lock across waits), *_u8 take device pointers, result header 32, capture parts */
+#define GJ_VERSION 130 /* 0.1.3: device identity, communicator figures read from the live communicator, batched part combine (result header: 40 fields) */
 
 typedef struct gj_ctx gj_ctx;
 
@@ -78,6 +78,10 @@ int gj_set_unpack(gj_ctx* ctx, double offset, double scale);
 int gj_get_unpack(gj_ctx* ctx, double* offset, double* scale);
 int gj_device_info(gj_ctx* ctx, char* name, size_t name_cap, int* compute_units,
                    uint64_t* hbm_bytes);
+/* Which physical GPU this context runs on, as text: "pci=<domain:bus:device.function> uuid=<hex> hip=<index>".
+ * Ranks of a multi-GPU run exchange these so that the collecting rank can tell N GPUs from N ranks on one
+ * (bench.py's `devices` list). */
+int gj_device_identity(gj_ctx* ctx, char* out, size_t cap);
 /* Pre-size the internal workspace so that later *_dev calls allocate nothing. */
 int gj_reserve(gj_ctx* ctx, size_t workspace_bytes);
 /* Diagnostics.  The hook is called, with NO internal lock held, right before every host-side wait of
@@ -437,13 +441,19 @@ size_t gj_acq_workspace(gj_ctx* ctx, int nsamp, int n_freq, int n_prn, int intg,
  * the other ranks by whatever means the host has (gpsjam/comm.py: one TCP socket on
  * MASTER_ADDR:MASTER_PORT); every rank then calls gj_comm_init_rank on ITS context.
  * Collectives are enqueued on the context's current stream (gj_set_stream) and do not
- * synchronise the host; buffers are device memory.  librccl is bound at run time
- * (GJ_ERR_UNSUPPORTED when it cannot be loaded). */
+ * synchronise the host; buffers are device memory.  The context lock is NOT held across the RCCL
+ * call (a communicator's first collective connects its peers inside the call and may wait for a
+ * late rank): other threads keep using the context meanwhile; the order of collectives on one
+ * communicator is the caller's, and a communicator must not be destroyed while a call on it is in
+ * progress.  librccl is bound at run time (GJ_ERR_UNSUPPORTED when it cannot be loaded). */
 typedef struct gj_comm gj_comm;
 #define GJ_COMM_ID_BYTES 128
 int gj_comm_unique_id(void* id /* [GJ_COMM_ID_BYTES] */);
 int gj_comm_init_rank(gj_ctx* ctx, const void* id, int rank, int n_ranks, gj_comm** out);
+/* rank and size as the LIVE communicator reports them (ncclCommUserRank / ncclCommCount), not as passed at init;
+ * -1 of 0 for a communicator whose context has been destroyed.  gj_comm_device: the HIP device it is bound to. */
 int gj_comm_rank(gj_comm* comm, int* rank, int* n_ranks);
+int gj_comm_device(gj_comm* comm, int* hip_device);
 /* every rank sends `bytes` bytes; root receives n_ranks*bytes in rank order (d_recv may be NULL
  * elsewhere) */
 int gj_comm_gather_dev(gj_comm* comm, const void* d_send, size_t bytes, void* d_recv, int root);

@@ -34,8 +34,28 @@ def test_self_launch_rendezvous_cpu():
                        capture_output=True, text=True, env=_env(), timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
     line = _json_line(r.stdout)
+    seats = line.pop("seats")
     assert line == {"rendezvous": "ok", "world": 2, "backend": "gloo", "sum": 3.0}
+    # who sat where, all-gathered over the group itself: two ranks, two processes
+    assert [d["rank"] for d in seats] == [0, 1] and len({d["pid"] for d in seats}) == 2
     assert "torch.distributed.run" in r.stderr          # the parent says what it started
+    assert "diagnosis" not in r.stderr                  # nothing failed: no second run
+
+
+@pytest.mark.timeout(300)
+def test_failed_run_diagnoses_itself_cpu():
+    """A rank dies after the group has formed (--fail-rank): the parent exits non-zero with the ranks' status and has
+    run ONE fresh --rendezvous-only child whose verdict -- the group forms, so the failure is in the run -- is on
+    stderr.  stdout stays free of any second JSON line."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--rendezvous-only", "--fail-rank", "1"],
+                       capture_output=True, text=True, env=_env(), timeout=280)
+    assert r.returncode != 0
+    assert "--fail-rank, leaving with status 3" in r.stderr
+    assert "diagnosis: one fresh --rendezvous-only run of 2 ranks over gloo" in r.stderr
+    assert "diagnosis: rendezvous ok" in r.stderr and '"rendezvous": "ok"' in r.stderr
+    assert "the failure above is in the run itself" in r.stderr
+    assert r.stderr.count("[bench] launching") == 2     # the run and exactly one diagnosis
+    assert len([ln for ln in r.stdout.splitlines() if ln.startswith("{")]) <= 1   # the failed run's own line at most
 
 
 @pytest.mark.timeout(300)
@@ -45,6 +65,7 @@ def test_self_launch_relays_failure_cpu():
                        capture_output=True, text=True, env=_env(), timeout=280)
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "diagnosis: rendezvous FAILED too" in r.stderr   # the same backend cannot form a group either
 
 
 def test_parent_does_not_import_torch_before_launch():
@@ -69,6 +90,29 @@ def test_self_launch_two_ranks_share_gpu():
     assert line["self_check"]["passed"] is True, line["self_check"]
     assert line["self_check"]["pairs_checked"] == 1 and line["self_check"]["streams_checked"] == 2
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
+    # what the line says about the exchange is read from the live group: gloo carried it (no RCCL rank), two ranks were
+    # seen, they sat on ONE physical device -- a rehearsal, and the line says so
+    assert line["rccl_ranks"] == 0 and line["ranks_seen"] == 2 and line["rehearsal"] is True
+    assert [d["rank"] for d in line["devices"]] == [0, 1] and len({d["pid"] for d in line["devices"]}) == 2
+    assert line["distinct_devices"] == 1 and line["devices"][0]["pci"] == line["devices"][1]["pci"]
+    assert line["self_check"]["devices_ok"] is True     # --share-gpu announced it
+
+
+def test_self_check_refuses_ranks_on_one_device():
+    """N ranks that report fewer than N physical devices without --share-gpu fail the line's self_check."""
+    sys.path.insert(0, REPO)
+    import bench
+    two_on_one = {"devices": [{"rank": 0, "pci": "0000:05:00.0", "uuid": "a"}, {"rank": 1, "pci": "0000:05:00.0", "uuid": "a"}],
+                  "distinct_devices": 1}
+    assert bench.self_check([], type("T", (), {"pairs": [], "lags": []})(), [], 0, 2, 0, proof=two_on_one, world=2)["devices_ok"] is False
+    assert bench.self_check([], type("T", (), {"pairs": [], "lags": []})(), [], 0, 2, 0, proof=two_on_one, world=2,
+                            share_gpu=True)["devices_ok"] is True
+    two_on_two = {"devices": [{"rank": 0, "pci": "0000:05:00.0"}, {"rank": 1, "pci": "0000:06:00.0"}], "distinct_devices": 2}
+    assert bench.self_check([], type("T", (), {"pairs": [], "lags": []})(), [], 0, 2, 0, proof=two_on_two, world=2)["devices_ok"] is True
+    lost_rank = {"devices": [{"rank": 0, "pci": "a"}, {"rank": 0, "pci": "b"}], "distinct_devices": 2}
+    assert bench.self_check([], type("T", (), {"pairs": [], "lags": []})(), [], 0, 2, 0, proof=lost_rank, world=2)["devices_ok"] is False
+    ident = bench.parse_identity("rank=3 pid=77 host=box pci=0000:05:00.0 uuid=00ff hip=2 torch=x/0000:05:00")
+    assert ident == {"rank": 3, "pid": 77, "host": "box", "pci": "0000:05:00.0", "uuid": "00ff", "hip": 2, "torch": "x/0000:05:00"}
 
 
 @pytest.mark.gpu
@@ -100,7 +144,12 @@ def test_collective_path_over_rccl_on_one_gpu():
                        capture_output=True, text=True, env=_env(), timeout=850)
     assert r.returncode == 0, r.stderr[-3000:]
     line = _json_line(r.stdout)
-    assert line["n_gpus"] == 1 and line["forced_exchange"] is True and line["rccl_ranks"] == 1
+    assert line["n_gpus"] == 1 and line["forced_exchange"] is True
+    # read from the live group (dist.get_world_size() of an nccl group), with the one device it ran on
+    assert line["rccl_ranks"] == 1 and line["ranks_seen"] == 1 and line["distinct_devices"] == 1
+    assert "over nccl" in line["identity_exchanged_via"] and line["rehearsal"] is False
+    d = line["devices"][0]
+    assert d["rank"] == 0 and d["pci"].count(":") == 2 and d["pid"] > 0 and d["hip"] == 0
     assert line["self_check"]["passed"] is True, line["self_check"]
     assert line["self_check"]["pairs_checked"] == 3 and line["results"]["lags"] and line["value"] > 0
 
