@@ -378,10 +378,10 @@ def main():
                 "note": "PMC: about half of the four-step floor reaches HBM -- the spectra are written through "
                         "(50 MB) and about a third of the reads miss L2 / Infinity Cache (56 MB)"}
         if acq_ms is not None:
-            n_prn, n_freq, intg, nsamp = acq_shape
+            n_prn, n_freq, intg, acq_nsamp = acq_shape
             n_fft = intg * n_freq * (1 + n_prn) + n_prn
             line["secondary"]["acquisition search (SURVEY 8(f)-4), solo"] = {
-                "what": f"{n_prn} PRNs x {n_freq} Doppler bins x {intg} ms non-coherent, {2 * nsamp}-pt FFT . conj(code) . IFFT, "
+                "what": f"{n_prn} PRNs x {n_freq} Doppler bins x {intg} ms non-coherent, {2 * acq_nsamp}-pt FFT . conj(code) . IFFT, "
                         f"peak test per step; quiet input: all {intg} steps run ({acq_found} false acquisitions)",
                 "avg_search_ms": acq_ms, "transforms_per_search": n_fft,
                 "transforms_per_s": n_fft / (acq_ms / 1e3),

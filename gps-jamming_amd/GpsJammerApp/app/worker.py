@@ -104,6 +104,9 @@ class GPSAnalysisThread(QThread):
         self.POWER_CHUNK_SIZE = 32768
         # the reference ignores power_threshold in favour of a fixed +6 dB (worker.py:85-86)
         self.THRESHOLD_POWER_RISE_DB = 6.0
+        # what this thread's own triangulation passes to triangulate_jammer_location (the reference: worker.py:598);
+        # the power scan asks for the amplitude statistics at THIS threshold while the first file uploads
+        self.TRIANGULATION_RSSI_THRESHOLD = 0.0
         print(f"[GPS THREAD] Próg detekcji mocy (ITU-R): {self.THRESHOLD_POWER_RISE_DB} dB")
         self.THRESHOLD_CN0_DROP_DB = 8.0
         self.THRESHOLD_RESIDUALS_MEDIAN_M = 40.0
@@ -197,11 +200,13 @@ class GPSAnalysisThread(QThread):
                 self.power_map = np.array([])
             else:
                 # one upload; the power scan runs on the pieces of the file while the rest is still uploading, and
-                # the amplitude statistics the triangulation will ask for (its default threshold) come out of the
-                # same pass over the bytes
+                # the amplitude statistics THIS thread's triangulation will ask for -- it calls
+                # triangulate_jammer_location(threshold=TRIANGULATION_RSSI_THRESHOLD), as the reference does
+                # (worker.py:598: threshold=0.0) -- come out of the same pass over the bytes and ride on the capture
                 dev = gpsjam.default_device()
                 dev.last_kernel_ms = 0.0
-                cap = gpsjam.resident_capture(path, chunk_bytes=chunk_bytes, eps=1e-10, rssi_threshold=0.1)
+                cap = gpsjam.resident_capture(path, chunk_bytes=chunk_bytes, eps=1e-10,
+                                              rssi_threshold=self.TRIANGULATION_RSSI_THRESHOLD)
                 self.power_map = dev.chunk_power(cap, chunk_bytes=chunk_bytes, eps=1e-10)
                 self.scan_kernel_ms = dev.last_kernel_ms
                 if self.scan_kernel_ms > 0:
@@ -466,7 +471,7 @@ class GPSAnalysisThread(QThread):
                     antenna_positions_meters=[np.array(self.antenna_positions[k])
                                               for k in ('antenna1', 'antenna2', 'antenna3')],
                     reference_lat=ref_lat, reference_lon=ref_lon, tx_power=40.0, path_loss_exp=3.0,
-                    frequency_mhz=1575.42, threshold=0.0, verbose=False)
+                    frequency_mhz=1575.42, threshold=self.TRIANGULATION_RSSI_THRESHOLD, verbose=False)
                 if result['success'] and anchor['valid']:
                     result['reference_position'] = anchor
                 self.triangulation_result = result

@@ -89,8 +89,17 @@ gj_lane* lane_checkout(gj_ctx* ctx) {
             }
         }
         if (taken) {
-            // what the dead caller queued may still be reading or writing the lane's buffers
-            if (reclaimed) (void)wait_stream(ctx, drain);
+            if (reclaimed) {
+                // what the dead caller queued may still be reading or writing the lane's buffers: kernels on the
+                // context's stream, and -- if it died inside gj_ingest_* / a staged upload -- H2D copies on the lane's own
+                // copy stream or out of its bounce buffers.  Reclaims are rare: drain them all, holding no
+                // lock.  (Fill threads of a caller that was killed outright may still be writing a bounce buffer for a
+                // few milliseconds; INTEGRATION.md says that a hard kill DURING a staged copy is not covered.)
+                (void)wait_stream(ctx, drain);
+                if (taken->copy_stream) (void)wait_stream(ctx, taken->copy_stream);
+                for (int k = 0; k < gj_lane::kPinBufs; ++k)
+                    if (taken->pin_ev[k]) (void)wait_event(ctx, taken->pin_ev[k]);
+            }
             return taken;
         }
         wait_hook(ctx, kWaitLane);   // every lane is held by a live caller: wait for one, holding nothing
@@ -593,12 +602,24 @@ int ingest_impl(gj_ctx* ctx, size_t nbytes, Fill&& fill, const gj_ingest_plan& p
         if (fused) rc = scan_start(ctx, sj);
     }
     if (rc) return bail(rc);
+    // Another thread may switch the context's stream while this call is between two lock sections (gj_set_stream:
+    // AntennaStream / SplitStreams do at construction).  The scan / Welch helpers launch on ctx->stream as it is in THEIR
+    // lock section, while the piece events were waited for on `s`: chain the new stream behind everything queued on the
+    // old one and carry on there (HostCall::run handles the same case).  Called under the Guard.
+    auto follow = [&]() -> int {
+        if (ctx->stream == s) return GJ_OK;
+        if (hipEventRecord(L->ev_done, s) != hipSuccess || hipStreamWaitEvent(ctx->stream, L->ev_done, 0) != hipSuccess)
+            return fail(ctx, GJ_ERR_HIP, "following a stream switch failed");
+        s = ctx->stream;
+        return GJ_OK;
+    };
 
     // kernels on everything that is complete once the first `landed` bytes are in HBM
     size_t tiles_done = 0, chunks_done = 0;
     auto launch_upto = [&](size_t landed, bool last) -> int {
         Guard g(ctx);
-        int r = GJ_OK;
+        int r = follow();
+        if (r) return r;
         if (fused) {
             const size_t t1 = last ? sj.ntiles : landed / 65536;
             if (t1 > tiles_done) r = scan_range(ctx, sj, tiles_done, t1);
@@ -652,7 +673,9 @@ int ingest_impl(gj_ctx* ctx, size_t nbytes, Fill&& fill, const gj_ingest_plan& p
     }
     {
         Guard g(ctx);
-        if (fused) rc = scan_end(ctx, sj);
+        rc = follow();
+        if (rc) {
+        } else if (fused) rc = scan_end(ctx, sj);
         else if (want_scan && n_chunks) {   // odd chunk sizes / unaligned: the three separate passes
             rc = launch_chunk_power(ctx, d_cap, nbytes, plan.chunk_bytes, plan.eps, plan.power_flags, d_power);
             if (!rc) rc = launch_amp_stats(ctx, d_cap, nbytes, plan.rssi_threshold, d_amp);

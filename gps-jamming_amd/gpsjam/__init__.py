@@ -212,7 +212,7 @@ class Capture:
         """A Capture around a device pointer the library has just handed out (gj_ingest_*)."""
         self = cls.__new__(cls)
         self.dev, self.ptr, self.nbytes, self.path = dev, int(ptr or 0), int(nbytes), path
-        self.results, self.ingest_ms = {}, None
+        self.results, self.ingest_ms, self.results_unpack = {}, None, None
         Capture.uploads += 1
         return self
 
@@ -222,7 +222,7 @@ class Capture:
         # results computed while the capture was uploaded (Device.ingest), keyed by the call that would recompute
         # them: ("chunk_power", chunk_bytes, eps, odd_chunk_zero), ("amp_stats", threshold), ("onset", noise_samples,
         # window, factor), ("welch", chunk_samples, nperseg, fs, shift)
-        self.results, self.ingest_ms = {}, None
+        self.results, self.ingest_ms, self.results_unpack = {}, None, None
         p, n = C.c_void_p(), C.c_size_t(0)
         if isinstance(source, (str, bytes, os.PathLike)):
             self.path = os.fspath(source)
@@ -281,6 +281,8 @@ class Device:
         self._ctx = ctx
         self.index = int(index)
         self.last_kernel_ms = 0.0
+        self.cache_hits = 0        # calls answered from a Capture's ride-along results (no kernel ran)
+        self.kernel_calls = {}     # name -> host-array / resident-capture calls that DID reach the library
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc: int):
@@ -335,6 +337,7 @@ class Device:
             self._check(self._lib.gj_ingest_u8(self._ctx, raw.ctypes.data if raw.size else None, raw.size, *args))
         cap = Capture._adopt(self, p.value, res.nbytes, path)
         cap.ingest_ms = (float(res.upload_ms), float(res.total_ms))
+        cap.results_unpack = self.get_unpack()               # the convention the ride-along results were computed under
         for a in (power, psd, db):
             if a is not None:
                 a.flags.writeable = False                    # handed out as they are on every matching call
@@ -345,6 +348,25 @@ class Device:
         if welch and rows:
             cap.results[("welch", int(welch[0]), nper, float(fs), bool(shift))] = (psd, db)
         return cap
+
+    def _cached(self, raw, key):
+        """Ride-along result of ``Device.ingest`` for this call, or None.  The results were computed under the unpack
+        convention in force at ingest time: after a ``set_unpack`` to anything else they are dropped (gj_set_unpack
+        promises to affect every later call on the context), and the call recomputes.  A hit ran no kernel:
+        ``last_kernel_ms`` says so."""
+        if not isinstance(raw, Capture) or not raw.results:
+            return None
+        if raw.results_unpack is not None and raw.dev is self and raw.results_unpack != self.get_unpack():
+            raw.results.clear()
+            return None
+        hit = raw.results.get(key)
+        if hit is not None:
+            self.last_kernel_ms = 0.0
+            self.cache_hits += 1
+        return hit
+
+    def _count(self, name):
+        self.kernel_calls[name] = self.kernel_calls.get(name, 0) + 1
 
     @staticmethod
     def _input(raw):
@@ -427,10 +449,10 @@ class Device:
     # ------------------------------------------------------------------ host arrays
     def chunk_power(self, raw, chunk_bytes: int = 65536, eps: float = 1e-10,
                     odd_chunk_zero: bool = False) -> np.ndarray:
-        if isinstance(raw, Capture):
-            hit = raw.results.get(("chunk_power", int(chunk_bytes), float(np.float32(eps)), bool(odd_chunk_zero)))
-            if hit is not None:
-                return hit                                   # read-only array computed while the capture uploaded
+        hit = self._cached(raw, ("chunk_power", int(chunk_bytes), float(np.float32(eps)), bool(odd_chunk_zero)))
+        if hit is not None:
+            return hit                                       # read-only array computed while the capture uploaded
+        self._count("chunk_power")
         ptr, nbytes, _keep = self._input(raw)
         n = self._lib.gj_chunk_count(nbytes, chunk_bytes)
         out = np.empty(n, np.float32)
@@ -445,10 +467,12 @@ class Device:
     def welch(self, raw, chunk_samples: int = 2048000, nperseg: int = 1024, fs: float = 2.048e6,
               shift: bool = True, want_db: bool = True):
         """(psd[rows, nperseg], psd_db[rows, nperseg] | None), float32."""
-        if isinstance(raw, Capture):
-            hit = raw.results.get(("welch", int(chunk_samples), int(nperseg), float(fs), bool(shift)))
-            if hit is not None and (hit[1] is not None or not want_db):
+        key = ("welch", int(chunk_samples), int(nperseg), float(fs), bool(shift))
+        if isinstance(raw, Capture) and raw.results.get(key) is not None and (raw.results[key][1] is not None or not want_db):
+            hit = self._cached(raw, key)
+            if hit is not None:
                 return hit[0], (hit[1] if want_db else None)   # read-only arrays computed while the capture uploaded
+        self._count("welch")
         ptr, nbytes, _keep = self._input(raw)
         rows = self._lib.gj_welch_rows(nbytes, chunk_samples, nperseg)
         psd = np.empty((rows, nperseg), np.float32)
@@ -462,10 +486,10 @@ class Device:
         return psd, db
 
     def amp_stats(self, raw, threshold: float) -> AmpStats:
-        if isinstance(raw, Capture):
-            hit = raw.results.get(("amp_stats", float(np.float32(threshold))))
-            if hit is not None:
-                return AmpStats.from_buffer_copy(bytes(hit))
+        hit = self._cached(raw, ("amp_stats", float(np.float32(threshold))))
+        if hit is not None:
+            return AmpStats.from_buffer_copy(bytes(hit))
+        self._count("amp_stats")
         ptr, nbytes, _keep = self._input(raw)
         out, ms = AmpStats(), C.c_float(0)
         self._check(self._lib.gj_amp_stats_u8(self._ctx, ptr, nbytes, threshold,
@@ -475,10 +499,10 @@ class Device:
 
     def onset(self, raw, noise_samples: int = 200000, window: int = 1000,
               factor: float = 50.0) -> Onset:
-        if isinstance(raw, Capture):
-            hit = raw.results.get(("onset", int(noise_samples), int(window), float(np.float32(factor))))
-            if hit is not None:
-                return Onset.from_buffer_copy(bytes(hit))
+        hit = self._cached(raw, ("onset", int(noise_samples), int(window), float(np.float32(factor))))
+        if hit is not None:
+            return Onset.from_buffer_copy(bytes(hit))
+        self._count("onset")
         ptr, nbytes, _keep = self._input(raw)
         out, ms = Onset(), C.c_float(0)
         self._check(self._lib.gj_onset_u8(self._ctx, ptr, nbytes, noise_samples,
