@@ -426,9 +426,17 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
         dev.synth_dev(specs[antenna], n // 2, t, first_sample=0)
         return t
 
-    st = split.SplitStreams(dev, [nbytes] * A, make_buffer, make_noise, rank=rank, world_size=world, nperseg=NPERSEG,
-                            chunk_samples=CHUNK_SAMPLES, slice_samples=SLICE, overlap=not args.no_overlap,
-                            exchange_always=args.force_exchange and world == 1)
+    emulated = int(args.emulate_world) if (world == 1 and args.emulate_world > 1) else 0
+    if emulated:
+        # rehearsal: this GPU is rank 0 of `emulated` -- 1/emulated of the bytes, its share of the pairs and the combine over
+        # all ranks' part vectors; what the other ranks would send was computed here, once, before the timed region
+        st = split.emulated_rank0(dev, [nbytes] * A, make_buffer, make_noise, emulated, nperseg=NPERSEG,
+                                  chunk_samples=CHUNK_SAMPLES, slice_samples=SLICE, overlap=not args.no_overlap,
+                                  exchange_always=args.force_exchange)
+    else:
+        st = split.SplitStreams(dev, [nbytes] * A, make_buffer, make_noise, rank=rank, world_size=world, nperseg=NPERSEG,
+                                chunk_samples=CHUNK_SAMPLES, slice_samples=SLICE, overlap=not args.no_overlap,
+                                exchange_always=args.force_exchange and world == 1)
     torch.cuda.synchronize()
 
     def barrier():
@@ -460,6 +468,35 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
     elapsed = float(t.item())
     welch_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
     own = sum(p.own_bytes for p in st.mine)
+    # the second stream's chain (scan, slots, [all-gather], K5, [gather], combine) against K2, one step in isolation:
+    # does the chain end inside K2 or does it stick out?
+    chain = None
+    if rank == 0 and st.overlap and world == 1:
+        torch.cuda.synchronize()
+        e0, e1, e2, e3 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+        reps, k2_ms, front_ms, tail_ms = 5, 0.0, 0.0, 0.0
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            e0.record(work_stream)
+            st.stream_scan()
+            st.welch()
+            e1.record(work_stream)
+            st.tdoa()
+            e3.record(st._side)
+            st.exchange(0)
+            e2.record(st._side)
+            torch.cuda.synchronize()
+            k2_ms += e0.elapsed_time(e1) / reps
+            front_ms += e0.elapsed_time(e3) / reps
+            tail_ms += e1.elapsed_time(e2) / reps
+        chain = {"k2_ms": k2_ms, "scan_to_k5_ms": front_ms, "pack_gather_combine_ms": tail_ms,
+                 "hidden_under_k2": bool(front_ms + tail_ms <= k2_ms), "slack_ms": k2_ms - front_ms - tail_ms,
+                 "combine_launches": getattr(st, "combine_launches", None),
+                 "note": "one step alone.  scan_to_k5: the second stream's front chain (fused scan, tail kernels, slots, "
+                         "[all-gather], pick, K5) from the step's start; pack_gather_combine: from the end of K2 to the end "
+                         "of the combine (pack on the first stream, then [gather] + assemble / statistics / pack on the "
+                         "second).  In steady state step k's combine and step k+1's front chain share the second stream "
+                         "under step k+1's K2: hidden when their sum fits into K2"}
     proof = exchange_proof(args, torch, dist if (world > 1 or args.force_exchange) else None, dev, None, world, rank)
     if rank == 0:
         results, tdoa = got.unpack()
@@ -468,6 +505,7 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
         achieved = (own / 1e9) / (welch_ms / 1e3) if welch_ms > 0 else 0.0
         line = {
             "metric": "Msamples/s uint8 I/Q through PSD+TDOA xcorr", "value": total_samples / elapsed / 1e6,
+            "projected": bool(emulated), "emulated_world": emulated,
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "precondition_steps": args.precondition, "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -475,7 +513,12 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
                                    "worker.py:586-600) through K1-K5, cut into contiguous runs of 8 192 000-byte units over "
                                    f"{world} GPU(s) (SURVEY 8(e)); all {len(tdoa.pairs)} pairs solved; total work is the same at every N",
                        "capture_bytes": nbytes, "antennas": A, "nperseg": NPERSEG, "chunk_samples": CHUNK_SAMPLES,
-                       "xcorr_slice": SLICE, "sharding": "captures split into parts (gpsjam.split)",
+                       "xcorr_slice": SLICE, "sharding": "captures split into parts (gpsjam.split)"
+                       + (f"; REHEARSAL: this GPU is rank 0 of {emulated} (its parts only, the other ranks' slots and part "
+                          f"vectors prepared before the timed region); value = the whole job's samples over rank 0's step "
+                          f"time, i.e. what {emulated} GPUs would deliver if the other ranks keep pace and the wire is free"
+                          if emulated else ""),
+                       "own_bytes_rank0": own, "pairs_rank0": [list(p) for p in st.pairs],
                        "parts": [[p.antenna, p.part, p.parts, p.first_byte, p.own_bytes, p.rank] for p in st.parts],
                        "backend": args.backend if world > 1 else None},
             **proof,
@@ -490,6 +533,8 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
             "self_check": self_check(results, tdoa, onsets, nsamp, A, proof=proof, world=world, share_gpu=args.share_gpu),
             "host": host_info(),
         }
+        if chain is not None:
+            line["second_stream_chain"] = chain
         emit(line)
     st.close()
 

@@ -564,6 +564,36 @@ int gj_pack_part_dev(gj_ctx* ctx, const gj_part_pack* a, double* d_out) {
     return launch_pack_part(ctx, *a, d_out);
 }
 
+int gj_combine_plan_create(gj_ctx* ctx, const gj_combine_copy* copies, int n_copies, const gj_combine_capture* captures,
+                           int n_captures, size_t rows_bytes, const void* d_arena, size_t arena_bytes, int nperseg, float pct,
+                           float rise_db, const int32_t* d_pairs, const int32_t* d_lags, const float* d_peaks,
+                           const float* d_margins, gj_combine_plan** out) {
+    if (!ctx || !out) return GJ_ERR_INVALID;
+    *out = nullptr;
+    if (!copies || !captures || !d_arena) return fail(ctx, GJ_ERR_INVALID, "null argument");
+    if (n_copies < 1 || n_copies > 65535 || n_captures < 1 || n_captures > 1024)
+        return fail(ctx, GJ_ERR_INVALID, "%d copies, %d captures", n_copies, n_captures);
+    if (nperseg < 16 || nperseg > 4096 || (nperseg & (nperseg - 1))) return fail(ctx, GJ_ERR_UNSUPPORTED, "nperseg %d", nperseg);
+    Guard g(ctx);
+    return combine_plan_create(ctx, copies, n_copies, captures, n_captures, rows_bytes, d_arena, arena_bytes, nperseg, pct, rise_db,
+                               d_pairs, d_lags, d_peaks, d_margins, out);
+}
+
+int gj_split_combine_dev(gj_ctx* ctx, const gj_combine_plan* plan, const double* d_rows) {
+    GJ_ENTER(ctx);
+    if (!plan || !d_rows) return fail(ctx, GJ_ERR_INVALID, "null argument");
+    return launch_split_combine(ctx, plan, d_rows);
+}
+
+int gj_combine_plan_destroy(gj_ctx* ctx, gj_combine_plan* plan) {
+    if (!plan) return GJ_OK;
+    if (!ctx) return GJ_ERR_INVALID;
+    (void)wait_stream(ctx, current_stream(ctx));   // queued launches read the plan's device arrays
+    Guard g(ctx);
+    combine_plan_destroy(plan);
+    return GJ_OK;
+}
+
 int gj_acq_search_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t first_sample, int nsamp, int intg,
                       const int16_t* d_codes, int n_prn, const uint8_t* d_phase, int n_freq, int nsampchip, double ctime,
                       float threshold, gj_acq_result* d_out, double* d_power) {

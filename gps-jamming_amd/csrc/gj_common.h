@@ -235,6 +235,27 @@ __device__ __forceinline__ void wave_sum_pair_u16(float a, float b, float& sum_a
     sum_b = (float)((r0 >> 16) + (r1 >> 16) + (r2 >> 16) + (r3 >> 16));
 }
 
+// The capture's onset from its parts' (each already in capture coordinates): the part with the smallest start >= 0
+// decides index and margin_hit; guard = smallest guard >= 0; margin_before = the smallest reported by the parts up to
+// and including that one (all of them when nothing crossed); noise and threshold are the same on every part.  One thread.
+__device__ __forceinline__ void onset_combine(const gj_onset* __restrict__ parts, int n, gj_onset* __restrict__ out) {
+    int best = -1;
+    for (int k = 0; k < n; ++k)
+        if (parts[k].start_index >= 0 && (best < 0 || parts[k].start_index < parts[best].start_index)) best = k;
+    long long guard = -1;
+    float mb = parts[0].margin_before;
+    for (int k = 0; k < n; ++k) {
+        if (parts[k].guard_index >= 0 && (guard < 0 || parts[k].guard_index < guard)) guard = parts[k].guard_index;
+        if ((best < 0 || k <= best) && parts[k].margin_before < mb) mb = parts[k].margin_before;
+    }
+    gj_onset o = parts[0];
+    o.start_index = best >= 0 ? parts[best].start_index : -1;
+    o.margin_hit = best >= 0 ? parts[best].margin_hit : 0.f;
+    o.margin_before = mb;
+    o.guard_index = guard;
+    *out = o;
+}
+
 }   // namespace gj
 
 // entry points implemented per translation unit (called from api.hip)
@@ -280,6 +301,11 @@ size_t amp_tile_count(size_t nbytes);
 int launch_amp_combine(gj_ctx*, const void*, size_t, const gj_amp_part*, int, size_t, gj_amp_stats*);
 int launch_onset_combine(gj_ctx*, const gj_onset*, int, gj_onset*);
 int launch_pack_part(gj_ctx*, const gj_part_pack&, double*);
+int launch_combine_stats(gj_ctx*, const gj_combine_capture*, int, float, float);
+int combine_plan_create(gj_ctx*, const gj_combine_copy*, int, const gj_combine_capture*, int, size_t, const void*, size_t, int, float,
+                        float, const int32_t*, const int32_t*, const float*, const float*, gj_combine_plan**);
+void combine_plan_destroy(gj_combine_plan*);
+int launch_split_combine(gj_ctx*, const gj_combine_plan*, const double*);
 int launch_acq_search(gj_ctx*, const uint8_t*, size_t, size_t, int, int, const int16_t*, int, const uint8_t*, int, int, double,
                       float, gj_acq_result*, double*);
 size_t acq_workspace(int, int, int, int, bool);

@@ -245,10 +245,9 @@ __device__ unsigned block_select(const unsigned (&reg)[kThrPerThread], const flo
     return prefix;
 }
 
-__global__ __launch_bounds__(kThrThreads) __attribute__((amdgpu_num_vgpr(104))) void power_threshold_kernel(const float* __restrict__ power, size_t n, float pct,
-                                                                      float ratio, float* __restrict__ stats,
-                                                                      uint8_t* __restrict__ mask) {
-    __shared__ ThrShared sh;
+// whole 256-thread workgroup; `sh` is the workgroup's scratch
+__device__ __forceinline__ void power_threshold_body(const float* __restrict__ power, size_t n, float pct, float ratio,
+                                                     float* __restrict__ stats, uint8_t* __restrict__ mask, ThrShared& sh) {
     const int tid = threadIdx.x;
     const bool cached = n <= (size_t)kThrCache;
     if (tid == 0) { sh.nan_flag = 0; sh.above = 0; sh.count_le = 0; sh.next_key = 0xffffffffu; }
@@ -321,6 +320,13 @@ __global__ __launch_bounds__(kThrThreads) __attribute__((amdgpu_num_vgpr(104))) 
     if ((tid & 63) == 0) atomicAdd(&sh.above, (unsigned long long)cnt);
     __syncthreads();
     if (tid == 0) stats[2] = (float)sh.above;
+}
+
+__global__ __launch_bounds__(kThrThreads) __attribute__((amdgpu_num_vgpr(104))) void power_threshold_kernel(const float* __restrict__ power, size_t n, float pct,
+                                                                      float ratio, float* __restrict__ stats,
+                                                                      uint8_t* __restrict__ mask) {
+    __shared__ ThrShared sh;
+    power_threshold_body(power, n, pct, ratio, stats, mask, sh);
 }
 
 int launch_power_threshold(gj_ctx* ctx, const float* d_power, size_t n, float pct, float rise_db, float* d_stats,
@@ -577,10 +583,9 @@ __global__ __launch_bounds__(256) void amp_part_finalize_kernel(const uint8_t* _
 }
 
 // The combining rank: tile sums of the WHOLE capture (gathered, in tile order) + the parts' first hits and tails.
-__global__ __launch_bounds__(256) void amp_combine_kernel(const AmpTile* __restrict__ tiles, size_t ntiles,
-                                                           const gj_amp_part* __restrict__ parts, int n_parts,
-                                                           size_t nsamples, gj_amp_stats* __restrict__ out) {
-    __shared__ double sh[16];
+__device__ __forceinline__ void amp_combine_body(const AmpTile* __restrict__ tiles, size_t ntiles,
+                                                 const gj_amp_part* __restrict__ parts, int n_parts, size_t nsamples,
+                                                 gj_amp_stats* __restrict__ out, double* sh) {
     long long first = 0x7fffffffffffffffll;
     double tail = 0.0;
     for (int p = 0; p < n_parts; ++p)        // every thread: n_parts is small
@@ -601,6 +606,41 @@ __global__ __launch_bounds__(256) void amp_combine_kernel(const AmpTile* __restr
         out->mean = (float)(total / (double)cnt);
         out->reserved = 0.f;
     }
+}
+
+__global__ __launch_bounds__(256) void amp_combine_kernel(const AmpTile* __restrict__ tiles, size_t ntiles,
+                                                           const gj_amp_part* __restrict__ parts, int n_parts,
+                                                           size_t nsamples, gj_amp_stats* __restrict__ out) {
+    __shared__ double sh[16];
+    amp_combine_body(tiles, ntiles, parts, n_parts, nsamples, out, sh);
+}
+
+// Rank 0 of a split run, EVERY capture in one launch (gj_split_combine_dev): workgroup a < n_captures runs the
+// noise-floor threshold of capture a, workgroup n_captures + a its amplitude totals and its onset -- the bodies of
+// power_threshold_kernel, amp_combine_kernel and onset_combine_kernel as they are (same code, same order, same bits),
+// one workgroup each, side by side instead of three launches per antenna one after the other.
+__global__ __launch_bounds__(kThrThreads) __attribute__((amdgpu_num_vgpr(104))) void combine_stats_kernel(
+    const gj_combine_capture* __restrict__ caps, int n_captures, float pct, float ratio) {
+    __shared__ ThrShared sh_thr;
+    __shared__ double sh_amp[16];
+    const int b = blockIdx.x;
+    if (b < n_captures) {
+        const gj_combine_capture c = caps[b];
+        power_threshold_body(c.d_power, (size_t)c.n_chunks, pct, ratio, c.d_stats, nullptr, sh_thr);
+    } else {
+        const gj_combine_capture c = caps[b - n_captures];
+        amp_combine_body(static_cast<const AmpTile*>(c.d_tiles), (size_t)c.n_tiles, c.d_amp_parts, c.n_parts,
+                         (size_t)(c.total_bytes / 2), c.d_amp, sh_amp);
+        if (threadIdx.x == 0) onset_combine(c.d_onset_parts, c.n_parts, c.d_onset);
+    }
+}
+
+int launch_combine_stats(gj_ctx* ctx, const gj_combine_capture* d_caps, int n_captures, float pct, float rise_db) {
+    const float ratio = (float)pow(10.0, (double)rise_db / 10.0);
+    hipLaunchKernelGGL(combine_stats_kernel, dim3(2u * (unsigned)n_captures), dim3(kThrThreads), 0, ctx->stream, d_caps,
+                       n_captures, pct, ratio);
+    GJ_LAUNCH_CHECK(ctx);
+    return GJ_OK;
 }
 
 int launch_amp_stats(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, float threshold, gj_amp_stats* d_out) {

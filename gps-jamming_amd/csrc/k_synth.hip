@@ -67,15 +67,14 @@ __global__ __launch_bounds__(256) void synth_kernel(gj_synth_params p, long long
 // ---------------------------------------------------------------------------------------
 // block = 64 bins x 16 row lanes; blocks [0, nperseg/64) reduce the waterfall to its mean
 // spectrum, the following blocks copy the header, the power map and the pair block
-__global__ __launch_bounds__(1024) void pack_result_kernel(size_t n_chunks, const float* __restrict__ power,
-                                                           const float* __restrict__ stats,
-                                                           const gj_amp_stats* __restrict__ amp,
-                                                           const gj_onset* __restrict__ onset, const float* __restrict__ psd,
-                                                           size_t rows, int nperseg, int rank, int n_pairs, int pair_cap,
-                                                           const int* __restrict__ pairs, const int* __restrict__ lags,
-                                                           const float* __restrict__ peaks, const float* __restrict__ margins,
-                                                           double* __restrict__ out) {
-    __shared__ float part[16][64];
+// (blockIdx.x / gridDim.x: the position inside ONE result vector's grid row; blockIdx.y is the caller's)
+__device__ __forceinline__ void pack_result_body(size_t n_chunks, const float* __restrict__ power,
+                                                 const float* __restrict__ stats, const gj_amp_stats* __restrict__ amp,
+                                                 const gj_onset* __restrict__ onset, const float* __restrict__ psd,
+                                                 size_t rows, int nperseg, int rank, int n_pairs, int pair_cap,
+                                                 const int* __restrict__ pairs, const int* __restrict__ lags,
+                                                 const float* __restrict__ peaks, const float* __restrict__ margins,
+                                                 double* __restrict__ out, float (*part)[64]) {
     const unsigned spec_blocks = (unsigned)((nperseg + 63) / 64);
     if (blockIdx.x < spec_blocks) {
         const int kx = threadIdx.x & 63, ry = threadIdx.x >> 6;
@@ -149,6 +148,19 @@ __global__ __launch_bounds__(1024) void pack_result_kernel(size_t n_chunks, cons
         }
         out[dst] = v;
     }
+}
+
+__global__ __launch_bounds__(1024) void pack_result_kernel(size_t n_chunks, const float* __restrict__ power,
+                                                           const float* __restrict__ stats,
+                                                           const gj_amp_stats* __restrict__ amp,
+                                                           const gj_onset* __restrict__ onset, const float* __restrict__ psd,
+                                                           size_t rows, int nperseg, int rank, int n_pairs, int pair_cap,
+                                                           const int* __restrict__ pairs, const int* __restrict__ lags,
+                                                           const float* __restrict__ peaks, const float* __restrict__ margins,
+                                                           double* __restrict__ out) {
+    __shared__ float part[16][64];
+    pack_result_body(n_chunks, power, stats, amp, onset, psd, rows, nperseg, rank, n_pairs, pair_cap, pairs, lags, peaks,
+                     margins, out, part);
 }
 
 int launch_pack_result(gj_ctx* ctx, size_t n_chunks, const float* d_power, const float* d_stats, const gj_amp_stats* d_amp,
@@ -248,31 +260,156 @@ int launch_pack_part(gj_ctx* ctx, const gj_part_pack& a, double* d_out) {
     return GJ_OK;
 }
 
-// The capture's onset from its parts' (each already in capture coordinates): the part with the smallest start >= 0
-// decides index and margin_hit; guard = smallest guard >= 0; margin_before = the smallest reported by the parts up to
-// and including that one (all of them when nothing crossed); noise and threshold are the same on every part.
 __global__ void onset_combine_kernel(const gj_onset* __restrict__ parts, int n, gj_onset* __restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int best = -1;
-    for (int k = 0; k < n; ++k)
-        if (parts[k].start_index >= 0 && (best < 0 || parts[k].start_index < parts[best].start_index)) best = k;
-    long long guard = -1;
-    float mb = parts[0].margin_before;
-    for (int k = 0; k < n; ++k) {
-        if (parts[k].guard_index >= 0 && (guard < 0 || parts[k].guard_index < guard)) guard = parts[k].guard_index;
-        if ((best < 0 || k <= best) && parts[k].margin_before < mb) mb = parts[k].margin_before;
-    }
-    gj_onset o = parts[0];
-    o.start_index = best >= 0 ? parts[best].start_index : -1;
-    o.margin_hit = best >= 0 ? parts[best].margin_hit : 0.f;
-    o.margin_before = mb;
-    o.guard_index = guard;
-    *out = o;
+    onset_combine(parts, n, out);
 }
 
 int launch_onset_combine(gj_ctx* ctx, const gj_onset* d_parts, int n_parts, gj_onset* d_out) {
     if (n_parts < 1) return fail(ctx, GJ_ERR_INVALID, "n_parts must be >= 1");
     hipLaunchKernelGGL(onset_combine_kernel, dim3(1), dim3(64), 0, ctx->stream, d_parts, n_parts, d_out);
+    GJ_LAUNCH_CHECK(ctx);
+    return GJ_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Rank 0 of a split run (gj_split_combine_dev): every capture rebuilt from the gathered part vectors and finished in
+// THREE launches whatever the number of antennas -- assemble (all copies of all captures), statistics (threshold |
+// amplitude totals + onset, one workgroup each per capture: k_scan.hip), pack (one grid row per capture).  The copy
+// list and the capture descriptors are static for a deployment: validated on the host and uploaded once
+// (gj_combine_plan_create).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void combine_assemble_kernel(const unsigned char* __restrict__ rows,
+                                                               const gj_combine_copy* __restrict__ copies) {
+    const gj_combine_copy c = copies[blockIdx.y];
+    const unsigned char* src = rows + c.src_byte;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < c.count; i += stride) {
+        const unsigned char* p = src + i * (size_t)c.src_stride;
+        switch (c.kind) {
+            case GJ_COPY_F64_F32: reinterpret_cast<float*>(c.dst)[i] = (float)*reinterpret_cast<const double*>(p); break;
+            case GJ_COPY_F64: reinterpret_cast<double*>(c.dst)[i] = *reinterpret_cast<const double*>(p); break;
+            case GJ_COPY_F32: reinterpret_cast<float*>(c.dst)[i] = *reinterpret_cast<const float*>(p); break;
+            default: reinterpret_cast<int*>(c.dst)[i] = (int)*reinterpret_cast<const double*>(p);   // GJ_COPY_F64_I32
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void pack_result_batch_kernel(const gj_combine_capture* __restrict__ caps, int nperseg,
+                                                                 const int* __restrict__ pairs, const int* __restrict__ lags,
+                                                                 const float* __restrict__ peaks,
+                                                                 const float* __restrict__ margins) {
+    __shared__ float part[16][64];
+    const gj_combine_capture c = caps[blockIdx.y];
+    pack_result_body((size_t)c.n_chunks, c.d_power, c.d_stats, c.d_amp, c.d_onset, c.d_psd, (size_t)c.rows, nperseg, c.antenna,
+                     c.n_pairs, c.pair_cap, pairs, lags, peaks, margins, c.d_out, part);
+}
+
+}   // namespace gj
+
+struct gj_combine_plan {
+    gj_combine_copy* d_copies = nullptr;
+    gj_combine_capture* d_caps = nullptr;
+    int n_copies = 0, n_caps = 0, nperseg = 0;
+    size_t max_count = 0, max_chunks = 0, rows_bytes = 0;
+    int max_pair_cap = 0;
+    float pct = 5.f, rise_db = 6.f;
+    const int32_t *d_pairs = nullptr, *d_lags = nullptr;
+    const float *d_peaks = nullptr, *d_margins = nullptr;
+};
+
+namespace gj {
+
+static size_t copy_dst_bytes(uint32_t kind) { return kind == GJ_COPY_F64 ? 8 : 4; }
+static size_t copy_src_bytes(uint32_t kind) { return kind == GJ_COPY_F32 ? 4 : 8; }
+
+int combine_plan_create(gj_ctx* ctx, const gj_combine_copy* copies, int n_copies, const gj_combine_capture* caps, int n_caps,
+                        size_t rows_bytes, const void* d_arena, size_t arena_bytes, int nperseg, float pct, float rise_db,
+                        const int32_t* d_pairs, const int32_t* d_lags, const float* d_peaks, const float* d_margins,
+                        gj_combine_plan** out) {
+    // Everything the three kernels will index is checked HERE, once, on the host: a copy that reads outside the gathered
+    // vectors or writes outside the arena, or a descriptor whose arrays do not fit, never reaches the GPU.
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(d_arena), a1 = a0 + arena_bytes;
+    auto inside = [&](const void* p, size_t bytes, size_t align) {
+        const uintptr_t u = reinterpret_cast<uintptr_t>(p);
+        return p && u % align == 0 && u >= a0 && bytes <= arena_bytes && u + bytes <= a1;
+    };
+    size_t max_count = 0;
+    for (int k = 0; k < n_copies; ++k) {
+        const gj_combine_copy& c = copies[k];
+        if (c.kind > GJ_COPY_F64_I32) return fail(ctx, GJ_ERR_INVALID, "copy %d: kind %u", k, c.kind);
+        if (c.count == 0) continue;
+        const size_t se = copy_src_bytes(c.kind), de = copy_dst_bytes(c.kind);
+        if (c.src_stride < se || c.src_byte % se || c.src_stride % se)
+            return fail(ctx, GJ_ERR_INVALID, "copy %d: source offset / stride not aligned to its element", k);
+        const size_t last = c.src_byte + (c.count - 1) * (size_t)c.src_stride + se;
+        if (last > rows_bytes) return fail(ctx, GJ_ERR_INVALID, "copy %d reads to byte %zu of %zu gathered", k, last, rows_bytes);
+        if (!inside(reinterpret_cast<const void*>(c.dst), c.count * de, de))
+            return fail(ctx, GJ_ERR_INVALID, "copy %d writes outside the arena", k);
+        if (c.count > max_count) max_count = c.count;
+    }
+    size_t max_chunks = 0;
+    int max_pair_cap = 0;
+    for (int a = 0; a < n_caps; ++a) {
+        const gj_combine_capture& c = caps[a];
+        if (c.n_chunks == 0 || c.n_parts < 1 || c.n_pairs < 0 || c.n_pairs > c.pair_cap)
+            return fail(ctx, GJ_ERR_INVALID, "capture %d: empty power map, no parts or more pairs than capacity", a);
+        if (c.n_tiles != amp_tile_count(c.total_bytes))
+            return fail(ctx, GJ_ERR_INVALID, "capture %d of %llu bytes has %zu tiles, not %llu", a, (unsigned long long)c.total_bytes,
+                        amp_tile_count(c.total_bytes), (unsigned long long)c.n_tiles);
+        const size_t out_len = GJ_RESULT_HEADER + c.n_chunks + (size_t)nperseg + (size_t)GJ_RESULT_PAIR_FIELDS * c.pair_cap;
+        if (!inside(c.d_power, c.n_chunks * 4, 4) || !inside(c.d_stats, 12, 4) || !inside(c.d_tiles, c.n_tiles * 16, 8) ||
+            !inside(c.d_amp_parts, (size_t)c.n_parts * sizeof(gj_amp_part), 8) ||
+            !inside(c.d_onset_parts, (size_t)c.n_parts * sizeof(gj_onset), 8) || !inside(c.d_amp, sizeof(gj_amp_stats), 8) ||
+            !inside(c.d_onset, sizeof(gj_onset), 8) || !inside(c.d_psd, (c.rows ? c.rows : 1) * (size_t)nperseg * 4, 4) ||
+            !inside(c.d_out, out_len * 8, 8))
+            return fail(ctx, GJ_ERR_INVALID, "capture %d: an array lies outside the arena", a);
+        if (c.n_pairs && (!d_pairs || !d_lags || !d_peaks || !d_margins)) return fail(ctx, GJ_ERR_INVALID, "null pair buffer");
+        if (c.n_chunks > max_chunks) max_chunks = c.n_chunks;
+        if (c.pair_cap > max_pair_cap) max_pair_cap = c.pair_cap;
+    }
+    gj_combine_plan* p = new (std::nothrow) gj_combine_plan();
+    if (!p) return GJ_ERR_NOMEM;
+    p->n_copies = n_copies; p->n_caps = n_caps; p->nperseg = nperseg; p->max_count = max_count; p->max_chunks = max_chunks;
+    p->max_pair_cap = max_pair_cap; p->rows_bytes = rows_bytes; p->pct = pct; p->rise_db = rise_db;
+    p->d_pairs = d_pairs; p->d_lags = d_lags; p->d_peaks = d_peaks; p->d_margins = d_margins;
+    if (hipMalloc(&p->d_copies, (size_t)n_copies * sizeof(gj_combine_copy)) != hipSuccess ||
+        hipMalloc(&p->d_caps, (size_t)n_caps * sizeof(gj_combine_capture)) != hipSuccess ||
+        hipMemcpy(p->d_copies, copies, (size_t)n_copies * sizeof(gj_combine_copy), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(p->d_caps, caps, (size_t)n_caps * sizeof(gj_combine_capture), hipMemcpyHostToDevice) != hipSuccess) {
+        if (p->d_copies) (void)hipFree(p->d_copies);
+        if (p->d_caps) (void)hipFree(p->d_caps);
+        delete p;
+        return fail(ctx, GJ_ERR_NOMEM, "combine plan");
+    }
+    *out = p;
+    return GJ_OK;
+}
+
+void combine_plan_destroy(gj_combine_plan* p) {
+    if (!p) return;
+    (void)hipFree(p->d_copies);
+    (void)hipFree(p->d_caps);
+    delete p;
+}
+
+int launch_split_combine(gj_ctx* ctx, const gj_combine_plan* p, const double* d_rows) {
+    // 1. every copy of every capture: grid row = one copy, 256-thread workgroups striding over its elements
+    size_t bx = (p->max_count + 255) / 256;
+    if (bx > 64) bx = 64;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(combine_assemble_kernel, dim3((unsigned)bx, (unsigned)p->n_copies), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const unsigned char*>(d_rows), p->d_copies);
+    GJ_LAUNCH_CHECK(ctx);
+    // 2. threshold | amplitude totals + onset, two workgroups per capture
+    int rc = launch_combine_stats(ctx, p->d_caps, p->n_caps, p->pct, p->rise_db);
+    if (rc) return rc;
+    // 3. one result vector per capture
+    const unsigned spec_blocks = (unsigned)((p->nperseg + 63) / 64);
+    size_t copy_blocks = (GJ_RESULT_HEADER + p->max_chunks + (size_t)GJ_RESULT_PAIR_FIELDS * p->max_pair_cap + 1023) / 1024;
+    if (copy_blocks > 256) copy_blocks = 256;
+    hipLaunchKernelGGL(pack_result_batch_kernel, dim3(spec_blocks + (unsigned)copy_blocks, (unsigned)p->n_caps), dim3(1024), 0,
+                       ctx->stream, p->d_caps, p->nperseg, p->d_pairs, p->d_lags, p->d_peaks, p->d_margins);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
 }

@@ -685,6 +685,27 @@ class Device:
     def pack_part_dev(self, args, d_out):
         self._check(self._lib.gj_pack_part_dev(self._ctx, C.byref(args), _ptr(d_out)))
 
+    def combine_plan(self, copies, captures, rows_bytes, arena, nperseg, d_pairs, d_lags, d_peaks, d_margins,
+                     pct=5.0, rise_db=6.0):
+        """gj_combine_plan_create: ``copies`` / ``captures`` are lists of _ffi.CombineCopy / _ffi.CombineCapture; ``arena``
+        the one device allocation (torch uint8 tensor or DevBuf) every destination lies in.  Returns the plan handle."""
+        cs = (_ffi.CombineCopy * len(copies))(*copies)
+        ca = (_ffi.CombineCapture * len(captures))(*captures)
+        nbytes = arena.numel() if hasattr(arena, "numel") else arena.nbytes
+        h = C.c_void_p()
+        self._check(self._lib.gj_combine_plan_create(self._ctx, cs, len(copies), ca, len(captures), int(rows_bytes), _ptr(arena),
+                                                     int(nbytes), int(nperseg), pct, rise_db, _ptr(d_pairs), _ptr(d_lags),
+                                                     _ptr(d_peaks), _ptr(d_margins), C.byref(h)))
+        return h
+
+    def split_combine_dev(self, plan, d_rows):
+        """Every capture of a split run rebuilt and finished in three launches (gj_split_combine_dev)."""
+        self._check(self._lib.gj_split_combine_dev(self._ctx, plan, _ptr(d_rows)))
+
+    def combine_plan_destroy(self, plan):
+        if getattr(self, "_ctx", None):
+            self._lib.gj_combine_plan_destroy(self._ctx, plan)
+
     def synth_dev(self, spec, n_samples: int, d_out, first_sample: int = 0):
         """Fill d_out[2*n_samples] with the capture described by a synth.StreamSpec."""
         p = SynthParams(spec.key_noise, spec.key_common, spec.delay, spec.jam_start,

@@ -87,6 +87,24 @@ class PartPack(C.Structure):
                 ("d_margins", C.c_void_p)]
 
 
+class CombineCopy(C.Structure):
+    """gj_combine_copy: one run of elements from the gathered part vectors into a capture-order array."""
+    _fields_ = [("src_byte", C.c_uint64), ("dst", C.c_uint64), ("count", C.c_uint64), ("src_stride", C.c_uint32),
+                ("kind", C.c_uint32)]
+
+
+class CombineCapture(C.Structure):
+    """gj_combine_capture: the arrays of one capture on the combining rank."""
+    _fields_ = [("n_chunks", C.c_uint64), ("rows", C.c_uint64), ("n_tiles", C.c_uint64), ("total_bytes", C.c_uint64),
+                ("n_parts", C.c_int32), ("antenna", C.c_int32), ("n_pairs", C.c_int32), ("pair_cap", C.c_int32),
+                ("d_power", C.c_void_p), ("d_stats", C.c_void_p), ("d_tiles", C.c_void_p), ("d_amp_parts", C.c_void_p),
+                ("d_onset_parts", C.c_void_p), ("d_amp", C.c_void_p), ("d_onset", C.c_void_p), ("d_psd", C.c_void_p),
+                ("d_out", C.c_void_p)]
+
+
+GJ_COPY_F64_F32, GJ_COPY_F64, GJ_COPY_F32, GJ_COPY_F64_I32 = 0, 1, 2, 3
+
+
 class SynthParams(C.Structure):
     _fields_ = [("key_noise", C.c_uint64), ("key_common", C.c_uint64), ("delay", C.c_int64),
                 ("jam_start", C.c_int64), ("jam_end", C.c_int64), ("noise_k", C.c_int32),
@@ -164,6 +182,10 @@ SIGNATURES = {
     "gj_onset_combine_dev": (_i, [_vp, _vp, _i, _vp]),
     "gj_part_result_len": (_sz, [_sz, _sz, _sz, _i, _i]),
     "gj_pack_part_dev": (_i, [_vp, C.POINTER(PartPack), _vp]),
+    "gj_combine_plan_create": (_i, [_vp, C.POINTER(CombineCopy), _i, C.POINTER(CombineCapture), _i, _sz, _vp, _sz, _i, _f, _f,
+                                    _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "gj_split_combine_dev": (_i, [_vp, _vp, _vp]),
+    "gj_combine_plan_destroy": (_i, [_vp, _vp]),
     "gj_acq_search_dev": (_i, [_vp, _vp, _sz, _sz, _i, _i, _vp, _i, _vp, _i, _i, _d, _f, _vp, _vp]),
     "gj_acq_workspace": (_sz, [_vp, _i, _i, _i, _i, _i]),
     "gj_comm_unique_id": (_i, [_vp]),

@@ -22,8 +22,14 @@ What a part computes, and why the combined result is bit-identical to the unspli
                                  slot cut at the smallest onset: the bytes the unsplit capture would have cut
 Exchange: ONE all-gather of the parts' slots, then every rank solves its share of the antenna pairs; ONE
 gather of the part vectors to rank 0, which rebuilds each capture's arrays in HBM and runs the same tail
-kernels (threshold, mean spectrum, packing) as a single-GPU stream.  ``StepResults`` comes out as from
-``gpsjam.sharded.AntennaStream``: one result vector per ANTENNA.
+kernels (threshold, mean spectrum, packing) as a single-GPU stream -- for ALL captures in three launches
+(gj_split_combine_dev: assemble, statistics, pack; the copy list is static and validated once).  ``StepResults`` comes
+out as from ``gpsjam.sharded.AntennaStream``: one result vector per ANTENNA.
+
+``emulate=True`` (bench.py --split --emulate-world W): this process is ONE rank of a W-rank plan on a single GPU --
+it holds only that rank's parts, the exchange is local copies into the W-rank buffers, and what the other ranks would
+have sent is put there beforehand (``adopt_remote``).  Rank 0's step then carries the per-rank load of W GPUs: its
+own 1/W of the bytes, its share of the pairs, and the combine over all W ranks' part vectors.
 """
 from __future__ import annotations
 
@@ -162,6 +168,40 @@ def from_files(dev, paths: Sequence[str], *, rank: int = 0, world_size: int = 1,
     return SplitStreams(dev, sizes, make_buffer, make_noise, rank=rank, world_size=world_size, device=d, **kw)
 
 
+def emulated_rank0(dev, capture_bytes: Sequence[int], make_buffer, make_noise, world: int, **kw) -> "SplitStreams":
+    """Rank 0 of a ``world``-rank split run, alone on ONE GPU, with what the other ranks would have sent already in
+    place (bench.py --split --emulate-world W; tests): every other rank of the plan is walked once on this GPU -- its
+    parts scanned, transformed, its slots cut; then, over everybody's slots, its share of the pairs solved and its part
+    vectors packed -- and its slots and vectors are handed to rank 0 (``adopt_remote``).  Rank 0's steps afterwards do
+    what rank 0 of ``world`` GPUs does: 1/world of the bytes, its pairs, and the combine over ALL ranks' vectors."""
+    root_kw = dict(kw)
+    other_kw = dict(kw, overlap=False, exchange_always=False)
+    root = SplitStreams(dev, capture_bytes, make_buffer, make_noise, rank=0, world_size=world, emulate=True, **root_kw)
+    others = [SplitStreams(dev, capture_bytes, make_buffer, make_noise, rank=r, world_size=world, emulate=True, **other_kw)
+              for r in range(1, world)]
+    everyone = [root] + others
+    for st in everyone:                                   # pass 1: what needs no other rank
+        st.scan()
+        with st._on_side():
+            st.cut_slots()
+    torch.cuda.synchronize()
+    for st in others:
+        root.all_slots[st.rank * st.pmax:(st.rank + 1) * st.pmax].copy_(st.my_slots)
+    root.all_slots[0:root.pmax].copy_(root.my_slots)
+    for st in others:                                     # pass 2: over everybody's slots
+        st.all_slots.copy_(root.all_slots)
+        st.solve(st.all_slots)
+        vec = st.pack()
+        torch.cuda.synchronize()
+        root.adopt_remote(st.rank, st.my_slots, vec)
+    torch.cuda.synchronize()
+    for st in others:
+        st.close()
+    if root._main is not None:                            # the walked ranks pointed the shared context at their streams
+        dev.set_stream(root._main.cuda_stream)
+    return root
+
+
 class PartStream:
     """One part on this GPU: its buffers and the three per-part kernels (no host synchronisation anywhere)."""
 
@@ -211,10 +251,13 @@ class SplitStreams:
     def __init__(self, dev, capture_bytes: Sequence[int], make_buffer, make_noise, *, rank: int = 0, world_size: int = 1,
                  chunk_bytes: int = 65536, chunk_samples: int = 2048000, nperseg: int = 4096, fs: float = 2.048e6,
                  slice_samples: int = 1 << 19, noise_samples: int = 200000, window: int = 1000, factor: float = 50.0,
-                 rssi_threshold: float = 0.0, overlap: Optional[bool] = None, device=None, exchange_always: bool = False):
+                 rssi_threshold: float = 0.0, overlap: Optional[bool] = None, device=None, exchange_always: bool = False,
+                 emulate: bool = False):
         self.dev, self.rank, self.world = dev, rank, world_size
+        # one rank of a world_size-rank plan alone on its GPU: no collective, local copies into the world-size buffers
+        self.emulate = bool(emulate)
         # a process group of one: still issue the slot all-gather and the part gather (the collective path on one GPU)
-        self._always = bool(exchange_always) and world_size == 1
+        self._always = bool(exchange_always) and (world_size == 1 or self.emulate)
         self.capture_bytes = [int(b) for b in capture_bytes]
         self.n_ant = len(self.capture_bytes)
         self.chunk_bytes, self.chunk_samples, self.nperseg, self.fs = chunk_bytes, chunk_samples, nperseg, fs
@@ -288,8 +331,15 @@ class SplitStreams:
         self.rows_of = [dev.welch_rows(b, chunk_samples, nperseg) for b in self.capture_bytes]
         self.total_pairs = self.n_ant * (self.n_ant - 1) // 2
         self.final_len = max(result_len(n, nperseg, self.total_pairs) for n in self.n_chunks_of)
-        self._final = ([torch.zeros((self.n_ant, self.final_len), dtype=torch.float64, device=d) for _ in range(2)]
-                       if self.is_root else [None, None])
+        # rank 0: two arenas (used alternately, like the vectors) with every capture's assembled arrays and result
+        # vectors, and the static plan of the three-launch combine over each
+        self._final, self._psd_views, self._plans, self._arenas = [None, None], [None, None], [None, None], [None, None]
+        if self.is_root:
+            for k in range(2):
+                self._build_combine(k)
+        if self.emulate and self._always:      # the collectives of a one-rank group, issued beside the local copies
+            self._one_slots = torch.zeros((1, self.pmax * self.slot_bytes), dtype=torch.uint8, device=d)
+            self._one_vec = torch.zeros((1, self.pmax * self.part_len), dtype=torch.float64, device=d)
         self._done = [torch.cuda.Event() for _ in range(2)] if d.type == "cuda" else [None, None]
         self._ev_vec_free = [None, None]
         self._idx = 0
@@ -332,20 +382,37 @@ class SplitStreams:
         self.stream_scan()
         self.welch()
 
+    def cut_slots(self):
+        """Slots of this rank's parts (current stream)."""
+        for j, s in enumerate(self.streams):
+            s.slot(self.my_slots[j])
+
+    def solve(self, slots: torch.Tensor):
+        """One slot per antenna out of everybody's, then this rank's share of the pairs (current stream)."""
+        self.dev_side.slots_pick_dev(slots, self.slot_bytes, self.d_offsets, self.d_members, self.n_ant, self.ant_slots)
+        if self.pairs:
+            self.dev_side.xcorr_slots_dev(self.ant_slots, self.slot_bytes, self.n_ant, self.slice_samples, self.pairs,
+                                          self.lags, self.peaks, self.margins)
+
     def tdoa(self):
         """Slots of this rank's parts -> ONE all-gather -> one slot per antenna -> this rank's pairs."""
         with self._on_side():
-            for j, s in enumerate(self.streams):
-                s.slot(self.my_slots[j])
-            if self.world > 1 or self._always:
+            self.cut_slots()
+            if self.emulate:
+                # alone on the GPU: this rank's rows of the world-size buffer are filled by a copy (the other ranks'
+                # rows were put there by adopt_remote); with exchange_always the all-gather of a one-rank group is
+                # issued as well, so that the RCCL call sits in the chain where N ranks have it
+                src = self.my_slots
+                if self._always:
+                    src = allgather_rows(self.my_slots.view(-1), 1, out=self._one_slots, always=True).view(self.pmax, -1)
+                self.all_slots[self.rank * self.pmax:(self.rank + 1) * self.pmax].copy_(src)
+                slots = self.all_slots
+            elif self.world > 1 or self._always:
                 allgather_rows(self.my_slots.view(-1), self.world, out=self.all_slots.view(self.world, -1), always=self._always)
                 slots = self.all_slots
             else:
                 slots = self.my_slots
-            self.dev_side.slots_pick_dev(slots, self.slot_bytes, self.d_offsets, self.d_members, self.n_ant, self.ant_slots)
-            if self.pairs:
-                self.dev_side.xcorr_slots_dev(self.ant_slots, self.slot_bytes, self.n_ant, self.slice_samples, self.pairs,
-                                              self.lags, self.peaks, self.margins)
+            self.solve(slots)
             if self.overlap:
                 self._ev_side.record(self._side)
 
@@ -383,12 +450,19 @@ class SplitStreams:
         if self.overlap:
             self._side.wait_event(self._ev_packed)
         with self._on_side():
-            if self.world > 1 or self._always:
+            if self.emulate:
+                src = vec.view(-1)
+                if self._always:
+                    src = gather_rows(vec.view(-1), 0, 1, 0, out=self._one_vec, always=True)[0]
+                rows = self._gathered[k]
+                if rows is not None:
+                    rows[self.rank].copy_(src)
+            elif self.world > 1 or self._always:
                 rows = gather_rows(vec.view(-1), self.rank, self.world, 0, out=self._gathered[k], always=self._always)
             else:
                 rows = vec.view(1, -1)
             if self.is_root:
-                final = self._combine(rows, self._final[k])
+                final = self._combine(rows, k)
                 if self._done[k] is not None:
                     self._done[k].record(self._side)
             if self.overlap:
@@ -405,57 +479,94 @@ class SplitStreams:
         return self.exchange(0)
 
     # ---------------------------------------------------------------- rank 0: parts -> captures
-    def _combine(self, rows: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-        """Rebuild each capture's device arrays from its parts' vectors and run the tail kernels a single-GPU stream
-        runs (threshold, amplitude totals, onset, mean spectrum, packing): second stream, no host synchronisation."""
-        dev, L = self.dev_side, self.part_len
-        vec = lambda p: rows[p.rank, p.local * L:(p.local + 1) * L]          # noqa: E731
-        # every solved pair, in rank order (which rank solved what is static)
-        lag_l, peak_l, marg_l, pair_l = [], [], [], []
-        for r in sorted(self.deal):
-            n = len(self.deal[r])
-            if n:
-                blk = rows[r, self.o_pairs:self.o_pairs + PAIR_FIELDS * n].view(n, PAIR_FIELDS)
-                lag_l.append(blk[:, 2].to(torch.int32))
-                peak_l.append(blk[:, 3].to(torch.float32))
-                marg_l.append(blk[:, 4].to(torch.float32))
-                pair_l += self.deal[r]
-        if pair_l:
-            d_pairs = self._d_all_pairs          # made once: a host-to-device copy here would stall the host every step
-            lags, peaks, margs = torch.cat(lag_l), torch.cat(peak_l), torch.cat(marg_l)
-        out.zero_()
+    def _build_combine(self, k: int):
+        """Arena k (every capture's assembled arrays + the result vectors) and the static plan of its combine: the copy
+        list part vector -> capture-order array and one descriptor per capture, checked on the host and uploaded once
+        (gj_combine_plan_create).  Which rank holds which part, and which rank solved which pair, never changes."""
+        dev, nper, L8 = self.dev_side, self.nperseg, 8 * self.part_len
+        off = 0
+
+        def take(nbytes: int) -> int:
+            nonlocal off
+            o = (off + 255) // 256 * 256
+            off = o + max(int(nbytes), 8)
+            return o
+
+        lay = []
         for a in range(self.n_ant):
-            parts = [p for p in self.parts if p.antenna == a]
-            power = torch.cat([vec(p)[HEADER:HEADER + dev.chunk_count(p.own_bytes, self.chunk_bytes)] for p in parts]).to(torch.float32)
-            tiles = torch.cat([vec(p)[self.o_tiles:self.o_tiles + 2 * dev.amp_tile_count(p.own_bytes)] for p in parts]).contiguous()
-            onset_parts = torch.stack([vec(p)[32:36] for p in parts]).contiguous()
-            amp_parts = torch.stack([vec(p)[36:40] for p in parts]).contiguous()
-            rows_l = []
-            for p in parts:
-                nr = dev.welch_rows(p.own_bytes, self.chunk_samples, self.nperseg)
+            mine = [p for p in self.parts if p.antenna == a]
+            lay.append(dict(parts=mine, n_tiles=dev.amp_tile_count(self.capture_bytes[a]),
+                            power=take(4 * self.n_chunks_of[a]), stats=take(12),
+                            tiles=take(16 * dev.amp_tile_count(self.capture_bytes[a])), amp_parts=take(32 * len(mine)),
+                            onset_parts=take(32 * len(mine)), amp=take(32), onset=take(32),
+                            psd=take(4 * max(self.rows_of[a], 1) * nper)))
+        o_final = take(8 * self.n_ant * self.final_len)
+        solved = [(r, self.deal[r]) for r in sorted(self.deal) if self.deal[r]]     # rank order = _d_all_pairs' order
+        n_solved = sum(len(v) for _, v in solved)
+        o_lags, o_peaks, o_margs = take(4 * max(n_solved, 1)), take(4 * max(n_solved, 1)), take(4 * max(n_solved, 1))
+        arena = torch.zeros(off, dtype=torch.uint8, device=self.device)
+        base = arena.data_ptr()
+        copies, caps = [], []
+        for a, ly in enumerate(lay):
+            c_off = t_off = r_off = 0
+            for g, p in enumerate(ly["parts"]):
+                src = (p.rank * self.pmax + p.local) * L8                         # this part's vector in the gathered rows
+                nc, nt = dev.chunk_count(p.own_bytes, self.chunk_bytes), dev.amp_tile_count(p.own_bytes)
+                nr = dev.welch_rows(p.own_bytes, self.chunk_samples, nper)
+                copies.append(_ffi.CombineCopy(src + 8 * HEADER, base + ly["power"] + 4 * c_off, nc, 8, _ffi.GJ_COPY_F64_F32))
+                copies.append(_ffi.CombineCopy(src + 8 * self.o_tiles, base + ly["tiles"] + 16 * t_off, 2 * nt, 8, _ffi.GJ_COPY_F64))
+                copies.append(_ffi.CombineCopy(src + 8 * 32, base + ly["onset_parts"] + 32 * g, 4, 8, _ffi.GJ_COPY_F64))
+                copies.append(_ffi.CombineCopy(src + 8 * 36, base + ly["amp_parts"] + 32 * g, 4, 8, _ffi.GJ_COPY_F64))
                 if nr:
-                    rows_l.append(vec(p)[self.o_rows:].view(torch.float32)[:nr * self.nperseg])
-            n_rows = self.rows_of[a]
-            psd = torch.cat(rows_l).view(n_rows, self.nperseg) if rows_l else torch.zeros((1, self.nperseg), dtype=torch.float32, device=rows.device)
-            n_chunks = self.n_chunks_of[a]
-            assert power.numel() == n_chunks and tiles.numel() == 2 * dev.amp_tile_count(self.capture_bytes[a])
-            stats = torch.empty(3, dtype=torch.float32, device=rows.device)
-            amp = torch.empty(4, dtype=torch.int64, device=rows.device)
-            onset = torch.empty(4, dtype=torch.int64, device=rows.device)
-            dev.power_threshold_dev(power, n_chunks, stats)
-            dev.amp_combine_dev(tiles, tiles.numel() // 2, amp_parts, len(parts), self.capture_bytes[a], amp)
-            dev.onset_combine_dev(onset_parts, len(parts), onset)
-            carries = a == 0 and bool(pair_l)
-            dev.pack_result_dev(n_chunks, power, stats, amp, onset, psd, n_rows, self.nperseg, a,
-                                len(pair_l) if carries else 0, self.total_pairs,
-                                d_pairs if carries else None, lags if carries else None, peaks if carries else None,
-                                margs if carries else None, out[a])
-            self.last_psd[a] = psd[:n_rows]
-            if rows.is_cuda:                       # the temporaries above are read by kernels queued on this stream
-                for t in (power, tiles, onset_parts, amp_parts, psd, stats, amp, onset):
-                    t.record_stream(self._side)
-        return out
+                    copies.append(_ffi.CombineCopy(src + 8 * self.o_rows, base + ly["psd"] + 4 * r_off * nper, nr * nper, 4,
+                                                   _ffi.GJ_COPY_F32))
+                c_off, t_off, r_off = c_off + nc, t_off + nt, r_off + nr
+            assert c_off == self.n_chunks_of[a] and t_off == ly["n_tiles"] and r_off == self.rows_of[a], (a, c_off, t_off, r_off)
+            carries = a == 0 and n_solved > 0
+            caps.append(_ffi.CombineCapture(self.n_chunks_of[a], self.rows_of[a], ly["n_tiles"], self.capture_bytes[a],
+                                            len(ly["parts"]), a, n_solved if carries else 0, self.total_pairs,
+                                            base + ly["power"], base + ly["stats"], base + ly["tiles"], base + ly["amp_parts"],
+                                            base + ly["onset_parts"], base + ly["amp"], base + ly["onset"], base + ly["psd"],
+                                            base + o_final + 8 * a * self.final_len))
+        q = 0
+        for r, prs in solved:                    # the pairs a rank solved ride on its FIRST part's vector
+            src = (r * self.pmax) * L8 + 8 * self.o_pairs
+            stride = 8 * PAIR_FIELDS
+            copies.append(_ffi.CombineCopy(src + 8 * 2, base + o_lags + 4 * q, len(prs), stride, _ffi.GJ_COPY_F64_I32))
+            copies.append(_ffi.CombineCopy(src + 8 * 3, base + o_peaks + 4 * q, len(prs), stride, _ffi.GJ_COPY_F64_F32))
+            copies.append(_ffi.CombineCopy(src + 8 * 4, base + o_margs + 4 * q, len(prs), stride, _ffi.GJ_COPY_F64_F32))
+            q += len(prs)
+        self._arenas[k] = arena
+        self._final[k] = arena[o_final:o_final + 8 * self.n_ant * self.final_len].view(torch.float64).view(self.n_ant, self.final_len)
+        self._psd_views[k] = [arena[ly["psd"]:ly["psd"] + 4 * max(self.rows_of[a], 1) * nper].view(torch.float32)
+                              .view(max(self.rows_of[a], 1), nper)[:self.rows_of[a]] for a, ly in enumerate(lay)]
+        rows_bytes = self.world * self.pmax * L8
+        self._plans[k] = dev.combine_plan(copies, caps, rows_bytes, arena, nper, self._d_all_pairs, base + o_lags,
+                                          base + o_peaks, base + o_margs)
+        self.combine_launches = 3                # assemble, statistics, pack -- whatever the number of antennas
+
+    def _combine(self, rows: torch.Tensor, k: int) -> torch.Tensor:
+        """Every capture rebuilt from its parts' vectors and finished (threshold, amplitude totals, onset, mean
+        spectrum, packing) in three launches on the second stream, no host synchronisation, no allocation."""
+        assert rows.is_contiguous() and rows.numel() * 8 == self.world * self.pmax * 8 * self.part_len
+        self.dev_side.split_combine_dev(self._plans[k], rows)
+        self.last_psd = self._psd_views[k]
+        return self._final[k]
+
+    def adopt_remote(self, rank: int, slots: torch.Tensor, vec: torch.Tensor):
+        """``emulate`` only: what rank ``rank`` of the plan would have contributed -- its parts' slots ([pmax,
+        slot_bytes]) and its packed part vectors ([pmax, part_len]) -- placed where the collectives would have put
+        them, once, before the steps."""
+        assert self.emulate and rank != self.rank and 0 <= rank < self.world
+        self.all_slots[rank * self.pmax:(rank + 1) * self.pmax].copy_(slots)
+        for g in self._gathered:
+            if g is not None:
+                g[rank].copy_(vec.reshape(-1))
 
     def close(self):
+        for k, pl in enumerate(self._plans):
+            if pl is not None:
+                self.dev_side.combine_plan_destroy(pl)
+                self._plans[k] = None
         if self.overlap and self.dev_side is not self.dev:
             self.dev_side.close()

@@ -400,6 +400,51 @@ typedef struct gj_part_pack {
 size_t gj_part_result_len(size_t chunk_cap, size_t tile_cap, size_t rows_cap, int nperseg, int pair_cap);
 int gj_pack_part_dev(gj_ctx* ctx, const gj_part_pack* args, double* d_out);
 
+/* The combining rank, every capture at once.  gj_amp_combine_dev / gj_onset_combine_dev / gj_power_threshold_dev /
+ * gj_pack_result_dev finish ONE capture and want its arrays contiguous; with three antennas cut into ten parts that is
+ * a chain of some forty small launches and copies on the combining rank -- the critical path once a rank's own K2 has
+ * shrunk to 1/8.  gj_split_combine_dev does the same work in THREE launches whatever the number of antennas:
+ *   1. assemble: every copy of `copies` (part vector -> capture-order array) in one grid;
+ *   2. statistics: one workgroup per capture for the noise-floor threshold, one for amplitude totals + onset;
+ *   3. pack: one grid row per capture (the layout of gj_pack_result_dev).
+ * The kernels' bodies are those of the one-capture entry points (same code, same order, same bits).  The copy list and
+ * the capture descriptors are static for a deployment: gj_combine_plan_create checks on the HOST that every copy
+ * reads inside the gathered vectors (rows_bytes) and that every destination / array lies inside the caller's arena
+ * (one device allocation holding all assembled arrays and result vectors), then keeps device copies of both. */
+typedef struct gj_combine_copy {
+    uint64_t src_byte;   /* offset of the first source element in the gathered part vectors */
+    uint64_t dst;        /* DEVICE address of the first destination element (inside the arena) */
+    uint64_t count;      /* elements */
+    uint32_t src_stride; /* bytes between source elements (8 for a run of doubles, 40 for one field of the pair block) */
+    uint32_t kind;       /* GJ_COPY_* */
+} gj_combine_copy;
+#define GJ_COPY_F64_F32 0 /* double -> float32 (chunk powers, pair peaks / margins) */
+#define GJ_COPY_F64 1     /* 8-byte copy (amplitude tile records, gj_onset / gj_amp_part records) */
+#define GJ_COPY_F32 2     /* 4-byte copy (PSD rows) */
+#define GJ_COPY_F64_I32 3 /* double -> int32 (pair lags) */
+typedef struct gj_combine_capture {
+    uint64_t n_chunks, rows, n_tiles, total_bytes;
+    int32_t n_parts, antenna;
+    int32_t n_pairs, pair_cap; /* pairs this capture's vector carries (all of them on antenna 0, none elsewhere) */
+    float* d_power;            /* [n_chunks]        assembled */
+    float* d_stats;            /* [3]               written by step 2 */
+    void* d_tiles;             /* [n_tiles] x 16 B  assembled */
+    gj_amp_part* d_amp_parts;  /* [n_parts]         assembled */
+    gj_onset* d_onset_parts;   /* [n_parts]         assembled */
+    gj_amp_stats* d_amp;       /* written by step 2 */
+    gj_onset* d_onset;         /* written by step 2 */
+    float* d_psd;              /* [max(rows,1)][nperseg] assembled */
+    double* d_out;             /* [40 + n_chunks + nperseg + 5 pair_cap] written by step 3 */
+} gj_combine_capture;
+typedef struct gj_combine_plan gj_combine_plan;
+int gj_combine_plan_create(gj_ctx* ctx, const gj_combine_copy* copies, int n_copies, const gj_combine_capture* captures,
+                           int n_captures, size_t rows_bytes, const void* d_arena, size_t arena_bytes, int nperseg,
+                           float pct, float rise_db, const int32_t* d_pairs /* every solved pair, static */,
+                           const int32_t* d_lags, const float* d_peaks, const float* d_margins /* assembled */,
+                           gj_combine_plan** out);
+int gj_split_combine_dev(gj_ctx* ctx, const gj_combine_plan* plan, const double* d_rows);
+int gj_combine_plan_destroy(gj_ctx* ctx, gj_combine_plan* plan); /* idempotent on NULL; synchronises the context's stream */
+
 /* ------------------------------------------------- GNSS acquisition search ----------- */
 /* the reference receiver's parallel code-phase search, batched over every
  * PRN and Doppler bin.  Replaces, per call, what each of its channel threads does on its own:

@@ -183,3 +183,22 @@ def test_split_collective_path_over_rccl_on_one_gpu():
     line = _json_line(r.stdout)
     assert line["scaling"] == "strong" and line["forced_exchange"] is True and line["rccl_ranks"] == 1
     assert line["self_check"]["passed"] is True, line["self_check"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_split_rank0_load_of_eight_gpus_on_one():
+    """`--split --emulate-world 8 --force-exchange`: rank 0 of eight on ONE GPU -- its own eighth of the three captures, its
+    share of the pairs, both collectives over the one-rank RCCL group, and the three-launch combine over ALL eight ranks'
+    part vectors (the other seven's prepared before the timed region).  Known delays and burst spans come back."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--split", "--emulate-world", "8", "--force-exchange", "--steps", "3",
+                        "--warmup", "1", "--precondition", "2", "--capture-bytes", str(1 << 28)],
+                       capture_output=True, text=True, env=_env(), timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["scaling"] == "strong" and line["emulated_world"] == 8 and line["projected"] is True and line["rehearsal"] is True
+    assert len({p[5] for p in line["config"]["parts"]}) == 8 and len(line["config"]["parts"]) == 10
+    assert line["config"]["own_bytes_rank0"] * 8 <= 3 * (1 << 28) + 8 * 8192000
+    assert line["self_check"]["passed"] is True and line["self_check"]["pairs_checked"] == 3, line["self_check"]
+    ch = line["second_stream_chain"]
+    assert ch["combine_launches"] == 3 and ch["k2_ms"] > 0 and ch["pack_gather_combine_ms"] > 0

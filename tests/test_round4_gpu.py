@@ -27,7 +27,7 @@ def test_ride_along_results_follow_the_unpack_convention(dev):
     """Device.ingest leaves results on the Capture; gj_set_unpack promises to affect every later call on the context.
     After set_unpack(128, 1/128) a call on the ingested capture must NOT hand out numbers computed with 127.5: it
     recomputes, and equals a fresh computation under the new convention.  A cache hit ran no kernel and says so."""
-    raw = generate(StreamSpec(seed=91, jam_start=150000, jam_end=1 << 40, jam_sigma=50.0), 300000)
+    raw = generate(StreamSpec(seed=91, jam_start=250000, jam_end=1 << 40, jam_sigma=50.0), 400000)
     try:
         with dev.ingest(raw, rssi_threshold=0.0, welch=(100000, 1024)) as cap:
             dev.last_kernel_ms = 123.0

@@ -307,3 +307,77 @@ def test_split_from_capture_files(dev, tmp_path):
     finally:
         torch.cuda.set_stream(torch.cuda.default_stream())
         dev.set_stream(None, external=False)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_emulated_world_rank0_is_bit_identical(dev, world):
+    """gpsjam.split.emulated_rank0 (bench.py --split --emulate-world W): rank 0 of a W-rank plan alone on the GPU, the
+    other ranks' slots and part vectors put in place beforehand.  Its combined results -- every capture rebuilt from
+    the parts of ALL ranks by the three-launch combine -- are byte for byte those of the single-GPU run, step after
+    step (the two arenas alternate)."""
+    import torch
+    from gpsjam import split
+    caps, kw = scenarios()["syn3"]
+    work = torch.cuda.Stream()
+    torch.cuda.set_stream(work)
+    dev.set_stream(work.cuda_stream)
+    try:
+        want = _single_gpu(dev, caps, kw)
+
+        def make_buffer(part, b0, b1):
+            return _device_range(dev, caps[part.antenna], b0, b1)
+
+        def make_noise(antenna, nbytes):
+            return _device_range(dev, caps[antenna], 0, nbytes)
+
+        st = split.emulated_rank0(dev, [_nbytes(c) for c in caps], make_buffer, make_noise, world, **kw)
+        assert st.world == world and st.rank == 0 and all(p.rank == 0 for p in st.mine)
+        assert len({p.rank for p in st.parts}) == world and len(st.parts) > len(caps)
+        assert st.combine_launches == 3                        # whatever the number of antennas and parts
+        for step in range(4):
+            got = st.step()
+            res, td = got.unpack()
+            _assert_identical(f"emulated world {world} step {step}",
+                              _collect(res, td, [p.cpu().numpy().copy() for p in st.last_psd]), want)
+        st.close()
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        dev.set_stream(None, external=False)
+
+
+def test_combine_plan_is_validated_on_the_host(dev):
+    """gj_combine_plan_create refuses, on the host, a copy that reads outside the gathered vectors or writes outside
+    the arena and a capture whose arrays do not fit -- nothing of the kind ever reaches a kernel."""
+    import gpsjam
+    from gpsjam import _ffi
+    arena = dev.alloc(1 << 16)
+    base = arena.ptr
+    n_chunks, nper = 10, 64
+    tiles = dev.amp_tile_count(10 * 65536)
+
+    def cap(**over):
+        kw = dict(n_chunks=n_chunks, rows=1, n_tiles=tiles, total_bytes=10 * 65536, n_parts=1, antenna=0, n_pairs=0, pair_cap=0,
+                  d_power=base, d_stats=base + 256, d_tiles=base + 512, d_amp_parts=base + 1024, d_onset_parts=base + 1280,
+                  d_amp=base + 1536, d_onset=base + 1792, d_psd=base + 2048, d_out=base + 4096)
+        kw.update(over)
+        return _ffi.CombineCapture(*[kw[f[0]] for f in _ffi.CombineCapture._fields_])
+
+    ok_copy = _ffi.CombineCopy(8 * 40, base, n_chunks, 8, _ffi.GJ_COPY_F64_F32)
+    rows_bytes = 8 * 4096
+    plan = dev.combine_plan([ok_copy], [cap()], rows_bytes, arena, nper, None, None, None, None)
+    dev.combine_plan_destroy(plan)
+    bad = [
+        ([_ffi.CombineCopy(rows_bytes - 8, base, 2, 8, _ffi.GJ_COPY_F64)], [cap()]),            # reads past the gathered rows
+        ([_ffi.CombineCopy(0, base + (1 << 16) - 4, 2, 8, _ffi.GJ_COPY_F64_F32)], [cap()]),     # writes past the arena
+        ([_ffi.CombineCopy(0, base - 256, 2, 8, _ffi.GJ_COPY_F64_F32)], [cap()]),               # writes in front of it
+        ([_ffi.CombineCopy(4, base, 2, 8, _ffi.GJ_COPY_F64)], [cap()]),                         # misaligned source
+        ([_ffi.CombineCopy(0, base, 2, 8, 7)], [cap()]),                                        # unknown kind
+        ([ok_copy], [cap(d_out=base + (1 << 16) - 64)]),                                        # result vector does not fit
+        ([ok_copy], [cap(n_tiles=tiles + 1)]),                                                  # tile count of another capture
+        ([ok_copy], [cap(n_pairs=2, pair_cap=1)]),                                              # more pairs than capacity
+        ([ok_copy], [cap(n_pairs=1, pair_cap=1)]),                                              # pairs without pair arrays
+    ]
+    for copies, caps_ in bad:
+        with pytest.raises(gpsjam.GpsJamError):
+            dev.combine_plan(copies, caps_, rows_bytes, arena, nper, None, None, None, None)
+    arena.free()
