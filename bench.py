@@ -53,6 +53,11 @@ DELAYS = (0, 3, -5, 7, -2, 4, -6, 1)
 # (sigma_jam > 7 sigma_noise = 43.75 LSB), so the gains stay near 1 (sigma 60 / 54 / 51 / 57 LSB)
 JAM_GAIN = (1.0, 0.9, 0.85, 0.95)
 JAM_SPAN = (0.4, 0.7)      # burst in source time, as fractions of the capture
+# the reference's own operating point (VERDICT r03 missing 3): FFT_SIZE = 1024 (skrypty/widmo_plot.py:10,48), TDOA
+# slices of 50 000 samples (skrypty/triangulateTDOA.py:26), three antenna captures of 10 s (worker.py:184-196, 586-600)
+REF_NPERSEG = 1024
+REF_SLICE = 50000
+REF_CAPTURE_BYTES = 40960000
 
 
 _LINE_FD = None
@@ -92,6 +97,8 @@ def main():
     ap.add_argument("--capture-bytes", type=int, default=CAPTURE_BYTES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-reference-point", action="store_true",
+                    help="skip the secondary figures at the reference's own operating point (nperseg 1024, 3 x 10-s deployment)")
     ap.add_argument("--cpu-baseline-all-ranks", action="store_true",
                     help="N > 1: every rank times the oracle on a prefix of its capture (default: the CPU baseline is N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -289,6 +296,19 @@ def main():
             print(f"[bench] acquisition search skipped: {e!r}", file=sys.stderr)
             acq_ms = None
 
+    # the reference's own operating point, in the driver-run line: K2 at nperseg 1024 on the same capture, and the
+    # three-antenna 10-s deployment (N = 1 only; secondary figures must never cost the primary line)
+    ref_point = None
+    if rank == 0 and world == 1 and not args.no_reference_point:
+        try:
+            psd_ref = torch.empty((dev.welch_rows(nbytes, CHUNK_SAMPLES, REF_NPERSEG), REF_NPERSEG), dtype=torch.float32, device="cuda")
+            dev.reserve(max(dev.welch_workspace(nbytes, CHUNK_SAMPLES, REF_NPERSEG), dev.welch_workspace(nbytes, CHUNK_SAMPLES, NPERSEG)))
+            k2_ref_ms = timed(lambda: dev.welch_dev(cap, nbytes, CHUNK_SAMPLES, REF_NPERSEG, 2.048e6, psd_ref), work_stream)
+            ref_point = {"k2_ms": k2_ref_ms, "psd": psd_ref, "deployment": deployment(np, torch, gpsjam, dev, StreamSpec)}
+        except Exception as e:
+            print(f"[bench] reference operating point skipped: {e!r}", file=sys.stderr)
+            ref_point = None
+
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if grouped:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -303,7 +323,7 @@ def main():
     if not args.no_cpu_baseline and (world == 1 or args.cpu_baseline_all_ranks or args.cpu_sample_chunks):
         chunks = args.cpu_sample_chunks or (24 if world == 1 else 8)
         barrier()
-        cpu = cpu_baseline(np, cap, chunks, stream, gathered if rank == 0 else None, world)
+        cpu = cpu_baseline(np, cap, chunks, stream, gathered if rank == 0 else None, world, ref_point if rank == 0 else None)
         if world > 1:
             r = torch.tensor([cpu["value"]], dtype=torch.float64, device="cuda")
             dist.all_reduce(r, op=dist.ReduceOp.SUM)
@@ -389,6 +409,20 @@ def main():
                 "k2_transforms_per_s_for_scale": (nbytes / 2 / (NPERSEG // 2)) / (solo_ms / 1e3),
                 **family_traffic("profiles/r03_pmc_acq/summary.json", nbytes),
                 "parity": "unpinned (gnssdec unbuildable here); oracle = numpy restatement of sdracq.c / sdrcmn.c"}
+        if ref_point is not None:
+            k2r = ref_point["k2_ms"]
+            par = (cpu or {}).pop("reference_point_parity", None)
+            line["secondary"][f"K2 welch_kernel<{REF_NPERSEG}> + finalize at the reference's FFT size (widmo_plot.py:10,48), same capture, solo"] = {
+                "bound": "hbm", "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": k2r,
+                "achieved": (nbytes / 1e9) / (k2r / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (nbytes / 1e9) / (k2r / 1e3) / HBM_PEAK_GBS, "msamples_per_s": nbytes / 2 / (k2r / 1e3) / 1e6,
+                **welch_ref_traffic(nbytes),
+                "parity_on_sample": None if par is None else par["psd_1024"]}
+            dep = ref_point["deployment"]["line"]
+            if par is not None:
+                dep["parity_vs_oracle"] = par["deployment"]
+            line["secondary"]["deployment at the reference's sizes: 3 antennas x 10 s (40.96 MB each), scan + K2 at 1024 + "
+                              "K5 at N = 50 000 (triangulateTDOA.py:26), 3 pairs"] = dep
         if cpu is not None:
             line["cpu_baseline"] = cpu
         if world == 1 and not args.no_end_to_end:
@@ -851,6 +885,144 @@ def valu_roofline(pmc, welch_ms, solo_ms):
                        "ceiling_source": "profiles/r01_ubench_valu_lds.txt (packed f32 issue, all CUs)"}}
 
 
+def welch_ref_traffic(nbytes):
+    """HBM bytes / VALU instructions per welch_kernel<1024> launch from its committed PMC summary
+    (tools/pmc_welch.sh <dir> 1024 + tools/pmc_summarize.py), stamped like the 4096-point one."""
+    out = {"traffic": None, "traffic_unit": "HBM bytes per launch", "traffic_source": "no PMC summary found",
+           "traffic_measured_on_this_source": None}
+    rel = "profiles/r04_pmc_welch1024/summary.json"
+    try:
+        with open(os.path.join(REPO, rel)) as f:
+            js = json.load(f)
+        corr = js["_hbm_bytes_corrected"]
+    except (OSError, KeyError, ValueError):
+        return out
+    if nbytes != CAPTURE_BYTES:
+        out["traffic_source"] = "PMC summary is for the 1-GiB capture only"
+        return out
+    out["traffic"] = corr.get("hbm_bytes_per_launch")
+    out["valu_insts"] = js.get("_valu", {}).get("sq_insts_valu_per_launch")
+    out["traffic_source"] = rel + " (commit " + str(js.get("_commit", "not recorded")) + ")"
+    out["traffic_measured_on_this_source"] = (js.get("_source_hash") == source_hash()) if js.get("_source_hash") else None
+    return out
+
+
+def deployment(np, torch, gpsjam, dev, StreamSpec, reps=20):
+    """The reference's deployment at the reference's sizes (worker.py:184-196,586-600): THREE antenna
+    captures of 10 s (40 960 000 bytes each).  Two figures:
+      resident_step_ms   captures in HBM; per capture the fused scan (K1 power map + K3 + K4) + noise-floor threshold + K2 at
+                         nperseg 1024 + TDOA slot, then K5 over the three slots at N = 50 000 (FFT length 131 072), 3 pairs --
+                         K2 on one stream, everything else on a second one, host waits once per step;
+      file_to_results_ms three capture FILES -> everything on the host: gj_ingest_file per file (the kernels run on the pieces
+                         as they land), then K5 on the resident captures -- what a user of the drop-ins waits for.
+    Returns the line entry and the GPU results (for the parity check against the oracle on the same bytes)."""
+    import tempfile
+    nb, ns = REF_CAPTURE_BYTES, REF_CAPTURE_BYTES // 2
+    pairs = [(0, 1), (0, 2), (1, 2)]
+    caps = []
+    for a in range(3):
+        c = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        dev.synth_dev(stream_spec(StreamSpec, a, ns), ns, c)
+        caps.append(c)
+    nch, rows = dev.chunk_count(nb, 65536), dev.welch_rows(nb, CHUNK_SAMPLES, REF_NPERSEG)
+    sb = dev.tdoa_slot_bytes(REF_SLICE)
+    side_dev = gpsjam.Device(dev.index)
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    side_dev.set_stream(side.cuda_stream)
+    power = [torch.empty(nch, dtype=torch.float32, device="cuda") for _ in range(3)]
+    stats = [torch.empty(3, dtype=torch.float32, device="cuda") for _ in range(3)]
+    amp = [torch.zeros(4, dtype=torch.int64, device="cuda") for _ in range(3)]
+    onset = [torch.zeros(4, dtype=torch.int64, device="cuda") for _ in range(3)]
+    psd = [torch.empty((rows, REF_NPERSEG), dtype=torch.float32, device="cuda") for _ in range(3)]
+    slots = torch.zeros((3, sb), dtype=torch.uint8, device="cuda")
+    lags = torch.zeros(3, dtype=torch.int32, device="cuda")
+    peaks, margins = torch.zeros(3, dtype=torch.float32, device="cuda"), torch.zeros(3, dtype=torch.float32, device="cuda")
+    dev.reserve(dev.welch_workspace(nb, CHUNK_SAMPLES, REF_NPERSEG))
+    side_dev.reserve(max(side_dev.xcorr_workspace(3, REF_SLICE, 3), nb // 48 + (1 << 20)))
+    ev_go, ev_side = torch.cuda.Event(), torch.cuda.Event()
+
+    def step():
+        ev_go.record(main)
+        side.wait_event(ev_go)
+        for a in range(3):
+            side_dev.stream_scan_dev(caps[a], nb, 65536, power[a], 0.0, amp[a], 200000, 1000, 50.0, onset[a])
+            side_dev.power_threshold_dev(power[a], nch, stats[a])
+            side_dev.tdoa_slot_dev(caps[a], nb, onset[a], REF_SLICE, slots[a])
+            dev.welch_dev(caps[a], nb, CHUNK_SAMPLES, REF_NPERSEG, 2.048e6, psd[a])
+        side_dev.xcorr_slots_dev(slots, sb, 3, REF_SLICE, pairs, lags, peaks, margins)
+        ev_side.record(side)
+        main.wait_event(ev_side)
+
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    resident_ms = (time.perf_counter() - t0) / reps * 1e3
+    one = []
+    for _ in range(5):                  # the latency of ONE step (host waits for it), not the rate of many
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        one.append((time.perf_counter() - t0) * 1e3)
+    gpu = {"power": [p.cpu().numpy() for p in power], "stats": [x.cpu().numpy() for x in stats],
+           "amp_mean": [float(x[3:4].view(torch.float32)[0]) for x in amp], "onset": [int(x[0]) for x in onset],
+           "psd0": psd[0].cpu().numpy(), "lags": lags.cpu().tolist(), "host": [c.cpu().numpy() for c in caps]}
+
+    # file -> results
+    d = tempfile.gettempdir()
+    if os.path.isdir("/dev/shm") and not os.access(d, os.W_OK):
+        d = "/dev/shm"
+    paths = [os.path.join(d, f"gpsjam_bench_{os.getpid()}_ant{a}.bin") for a in range(3)]
+    file_ms, same = [], None
+    try:
+        for a in range(3):
+            gpu["host"][a].tofile(paths[a])
+
+        def from_files():
+            t0 = time.perf_counter()
+            held = [dev.ingest(pth, rssi_threshold=0.0, welch=(CHUNK_SAMPLES, REF_NPERSEG), want_db=False) for pth in paths]
+            pm = [dev.chunk_power(c) for c in held]
+            ps = [dev.welch(c, chunk_samples=CHUNK_SAMPLES, nperseg=REF_NPERSEG, want_db=False)[0] for c in held]
+            am = [dev.amp_stats(c, 0.0) for c in held]
+            on = [dev.onset(c).start_index for c in held]
+            lg, _ = dev.xcorr_lags_at(held, on, REF_SLICE, pairs)
+            ms = (time.perf_counter() - t0) * 1e3
+            for c in held:
+                c.free()
+            return ms, (pm, ps, am, on, lg.tolist())
+
+        from_files()                                           # lanes, pinned buffers, page cache warm
+        for _ in range(3):
+            ms, got = from_files()
+            file_ms.append(ms)
+        same = bool(all(np.array_equal(got[0][a], gpu["power"][a]) for a in range(3)) and got[1][0].tobytes() == gpu["psd0"].tobytes()
+                    and got[3] == gpu["onset"] and got[4] == gpu["lags"])
+    finally:
+        for pth in paths:
+            try:
+                os.remove(pth)
+            except OSError:
+                pass
+    side_dev.close()
+    total = 3 * ns
+    line = {"captures": 3, "capture_bytes": nb, "nperseg": REF_NPERSEG, "xcorr_slice": REF_SLICE, "pairs": [list(p) for p in pairs],
+            "resident_step_ms": resident_ms, "resident_step_latency_ms": min(one),
+            "resident_msamples_per_s": total / (resident_ms / 1e3) / 1e6,
+            "file_to_results_ms": min(file_ms) if file_ms else None, "file_to_results_ms_all": file_ms,
+            "file_msamples_per_s": (total / (min(file_ms) / 1e3) / 1e6) if file_ms else None,
+            "files_where": d, "file_results_identical_to_resident": same,
+            "results": {"lags": gpu["lags"], "onsets": gpu["onset"], "amp_mean": gpu["amp_mean"],
+                        "baseline": [float(x[0]) for x in gpu["stats"]]},
+            "what": "resident_step: back-to-back steps over three captures already in HBM (rate) and one step alone (latency); "
+                    "file_to_results: three page-cache-resident files through gj_ingest_file (pieces sized to the capture, kernels "
+                    "on what has landed) + K5 on the resident captures, wall clock with PCIe, best of three"}
+    return {"line": line, "gpu": gpu}
+
+
 def end_to_end(np, dev, cap, nbytes):
     """File / host buffer -> results, wall clock, PCIe included (never `value`): one upload of the
     capture (pinned bounce buffers, eight fill threads) + scan + threshold + Welch + the D2H of the
@@ -932,7 +1104,7 @@ def end_to_end(np, dev, cap, nbytes):
     return out
 
 
-def cpu_baseline(np, cap, n_chunks, stream, gathered, world):
+def cpu_baseline(np, cap, n_chunks, stream, gathered, world, ref_point=None):
     """The oracle (a numpy/scipy port of the reference path) on a bounded prefix of the same
     capture, single process / single thread per rank, with parity of the GPU results on that
     prefix (rank 0)."""
@@ -975,6 +1147,38 @@ def cpu_baseline(np, cap, n_chunks, stream, gathered, world):
             "power_map_max_rel_err": float(np.max(np.abs(results[0].power_map[:pm.size] - pm) / pm))}
         if slices is not None:
             out["parity_on_sample"]["lags_equal"] = cpu_lags == tdoa.lags
+    if ref_point is not None:
+        # the reference's own operating point against the oracle on the same bytes (not part of the timed sample above)
+        lin_r, _, _ = orc.widmo_waterfall(raw, nperseg=REF_NPERSEG)
+        got = ref_point["psd"][:lin_r.shape[0]].cpu().numpy()
+        keep = lin_r > 1e-12
+        par = {"psd_1024": {"rows": int(lin_r.shape[0]),
+                            "psd_max_rel_err": float(np.max(np.abs(got[keep] - lin_r[keep]) / lin_r[keep]))}}
+        g = ref_point["deployment"]["gpu"]
+        t0 = time.perf_counter()
+        pm_err, on_cpu, amp_err, zs = [], [], [], []
+        for a in range(3):
+            h = g["host"][a]
+            pm_a = orc.chunk_power(h)
+            pm_err.append(float(np.max(np.abs(g["power"][a] - pm_a) / pm_a)))
+            z = orc.tdoa_unpack(h)
+            on_cpu.append(int(orc.tdoa_onset(z)))
+            zs.append(z)
+            _, avg = orc.rssi_amp_stats(h, 0.0)
+            amp_err.append(abs(g["amp_mean"][a] - float(avg)) / float(avg))
+        base = [float(orc.power_threshold(orc.chunk_power(g["host"][a]))[0]) for a in range(3)]
+        lin_d, _, _ = orc.widmo_waterfall(g["host"][0], nperseg=REF_NPERSEG)
+        keep = lin_d > 1e-12
+        lags_cpu = [int(orc.xcorr_lag(zs[j][on_cpu[j]:on_cpu[j] + REF_SLICE], zs[i][on_cpu[i]:on_cpu[i] + REF_SLICE])[0])
+                    for i, j in ((0, 1), (0, 2), (1, 2))]
+        par["deployment"] = {"power_map_max_rel_err": max(pm_err), "onsets_equal": on_cpu == g["onset"],
+                             "lags_equal": lags_cpu == g["lags"], "amp_mean_max_rel_err": max(amp_err),
+                             "baseline_max_rel_err": max(abs(float(g["stats"][a][0]) - base[a]) / base[a] for a in range(3)),
+                             "psd_1024_max_rel_err_capture0": float(np.max(np.abs(g["psd0"][keep] - lin_d[keep]) / lin_d[keep])),
+                             "cpu_oracle_s": time.perf_counter() - t0,
+                             "note": "the oracle (numpy/scipy port, one core) on the same three captures; its time is for power maps, "
+                                     "onsets, amplitude means, one capture's Welch 1024 and the three 50 000-sample correlations"}
+        out["reference_point_parity"] = par
     return out
 
 

@@ -62,9 +62,12 @@ __constant__ signed char kAcqSin[16] = {0, 12, 23, 30, 32, 30, 23, 12, 0, -12, -
 // one transform per workgroup (N = 4096) or 4096 / N of them (smaller N): `which` = transform index
 template <int N>
 __global__ __launch_bounds__(kBlockThreads) void acq_code_kernel(const short* __restrict__ codes, int nsamp, int n_prn,
-                                                                 const cf* __restrict__ twtab, cf* __restrict__ cspec) {
+                                                                 const cf* __restrict__ twtab, cf* __restrict__ cspec,
+                                                                 unsigned long long* __restrict__ gmax, int n_gmax) {
     constexpr int TF = N / 16, B = kBlockPoints / N;
     __shared__ cf lds[B * lds_span(N)];
+    // first kernel of a search: clear the running row maxima of acq_inv_all_kernel (two launches ahead in stream order)
+    for (int i = blockIdx.x * kBlockThreads + threadIdx.x; i < n_gmax; i += gridDim.x * kBlockThreads) gmax[i] = 0ull;
     const int tid = threadIdx.x, b = tid / TF, jl = tid % TF;
     const int p = blockIdx.x * B + b;
     const bool live = p < n_prn;
@@ -76,8 +79,14 @@ __global__ __launch_bounds__(kBlockThreads) void acq_code_kernel(const short* __
     }
     acq_passes<N, 0>(v, lds, b * lds_span(N), jl, twtab);
     if (live) {
+        // Stored as -C_p / m.  1/m: cpxconv's |.|^2 / m^2 (sdrcmn.c:141-143) then needs no multiply per lag; m = N is a
+        // power of two, so the scaling is exact and commutes with every float operation behind it.  The sign, together
+        // with the CONJUGATED data spectrum acq_fwd_kernel stores, turns cpxconv's product (real = -p0 q0 - p1 q1,
+        // imag = p0 q1 - p1 q0, conjugated for the forward-FFT inverse: sdrcmn.c:131-135) into one plain complex multiply
+        // conj(X) * (-C): four multiply-adds per point and no sign flips (five operations before).
+        constexpr float inv_m = -1.0f / (float)N;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) cspec[(size_t)p * N + jl + TF * s] = to_cf(v[s]);
+        for (int s = 0; s < 16; ++s) cspec[(size_t)p * N + jl + TF * s] = to_cf(make_c2(v[s].x * inv_m, v[s].y * inv_m));
     }
 }
 
@@ -106,7 +115,7 @@ __global__ __launch_bounds__(kBlockThreads) void acq_fwd_kernel(AcqParams P, con
     acq_passes<N, 0>(v, lds, b * lds_span(N), jl, twtab);
     if (live) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) xspec[(size_t)t * N + jl + TF * s] = to_cf(v[s]);
+        for (int s = 0; s < 16; ++s) xspec[(size_t)t * N + jl + TF * s] = to_cf(make_c2(v[s].x, -v[s].y));   // conj(X): see acq_code_kernel
     }
 }
 
@@ -128,9 +137,10 @@ __global__ __launch_bounds__(kBlockThreads) void acq_inv_kernel(AcqParams P, int
     c2 v[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        const cf a = x[jl + TF * s], q = c[jl + TF * s];
         // sdrcmn.c:131-135: real = -p0 q0 - p1 q1, imag = p0 q1 - p1 q0; conjugated for the forward-FFT inverse
-        v[s] = make_c2(-a.x * q.x - a.y * q.y, -(a.x * q.y - a.y * q.x));
+        // = conj(X) * (-C), with conj(X) and -C / m as stored
+        const cf a = x[jl + TF * s], q = c[jl + TF * s];
+        v[s] = make_c2(a.x * q.x - a.y * q.y, a.x * q.y + a.y * q.x);
     }
     acq_passes<N, 0>(v, lds, b * lds_span(N), jl, twtab);
     if (live) {
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(kBlockThreads) void acq_inv_kernel(AcqParams P, int
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int k = jl + TF * s;
-            if (k < P.nsamp) dst[k] += (double)((v[s].x * v[s].x + v[s].y * v[s].y) * P.inv_m2);   // flagsum = 1 (:141-143)
+            if (k < P.nsamp) dst[k] += (double)(v[s].x * v[s].x + v[s].y * v[s].y);   // flagsum = 1 (:141-143); 1/m^2 rides on C_p
         }
     }
 }
@@ -274,6 +284,12 @@ __device__ __forceinline__ T acq_group_reduce(T v, F&& op, T* sh /* [kBlockThrea
     return r;
 }
 
+struct AcqMax {     // a row's maximum alone: what EVERY row needs every step
+    double v;
+    __device__ __forceinline__ AcqMax moved(int k) const { return AcqMax{acq_dpp(v, k)}; }
+    __device__ __forceinline__ AcqMax lane(int l) const { return AcqMax{acq_lane(v, l)}; }
+};
+
 struct AcqBestS : AcqBest {
     __device__ __forceinline__ AcqBestS moved(int k) const {
         AcqBestS o;
@@ -321,20 +337,39 @@ __device__ __forceinline__ void acq_transform(c2 (&v)[16], cf* lds, int tid, int
 // are dealt over the eight residues of b and the PRN runs fastest inside a residue, so the ~96 workgroups an XCD holds
 // at a time read the same three bins' data spectra (10 steps x 32 KB each) and the 1 MB of code spectra out of their
 // own L2 instead of each XCD streaming all 23 MB of data spectra from the Infinity Cache.
+//
+// Round 4 -- the peak bookkeeping only where it can matter.  checkacquisition looks at ONE row per (PRN, step): the row
+// that holds the step's largest power.  Rounds 2-3 had every one of the 71 rows work out, every step, what the check
+// would need IF it were that row (first maximum with its index, then -- around that index -- the second peak and the
+// mean outside the +-2-chip zone: two group reductions of (double, int) / (double, double) records, as many vector
+// instructions as the transform itself).  Now every row reduces its MAXIMUM only (one value), and thread 0 of the row
+// offers it to gmax[PRN][step], the running maximum over the rows seen so far (one L2 atomic, the bits of a
+// non-negative double order like an unsigned integer).  A row whose maximum is below the running one cannot be the
+// step's winner whatever comes later and skips the rest; a row that raises or equals it works the statistics out
+// exactly as before.  The step's true winner -- and every row that ties with it -- always does (nothing larger can
+// have been offered before it), so acq_summary_kernel finds the same record with the same bits; with the rows arriving
+// in arbitrary order about ln 71 = 4-5 of the 71 do the full bookkeeping instead of all.  Records of skipped rows
+// carry their maximum and cnt = 0.
 template <int N>
-__global__ __launch_bounds__(kBlockThreads, 3) void acq_inv_all_kernel(AcqParams P, int nsampchip, const cf* __restrict__ twtab,
+__global__ __launch_bounds__(kBlockThreads, N == 2048 ? 2 : 3) void acq_inv_all_kernel(AcqParams P, int nsampchip, const cf* __restrict__ twtab,
                                                                     const cf* __restrict__ xspec,
                                                                     const cf* __restrict__ cspec,
-                                                                    AcqRow* __restrict__ rows /* [n_prn][intg][n_freq] */) {
+                                                                    AcqRow* __restrict__ rows /* [n_prn][intg][n_freq] */,
+                                                                    unsigned long long* __restrict__ gmax /* [n_prn][intg] */) {
     constexpr int TF = N / 16, B = kBlockPoints / N;
     constexpr bool XP = N == 4096;
     __shared__ cf lds[XP ? X4096::kSpan : B * lds_span(N)];
+    __shared__ AcqMax shm[kBlockThreads / 64];
     __shared__ AcqBestS shb[kBlockThreads / 64];
     __shared__ AcqTail sht[kBlockThreads / 64];
+    __shared__ int sh_need[2][B];               // [step parity][transform]: this row may hold the step's peak
+    __shared__ unsigned long long sh_seen[2];   // (one transform per workgroup) the running maximum as read when the step began
     const int slot = blockIdx.x >> 3;
     const int p = slot % P.n_prn, fg = (int)(blockIdx.x & 7) + 8 * (slot / P.n_prn);
     if (fg * B >= P.n_freq) return;            // the whole workgroup: the grid is padded to a multiple of eight groups
-    const int tid = threadIdx.x, b = tid / TF, jl0 = tid % TF;
+    // one transform per workgroup (N = 4096): b is 0 by construction -- said so explicitly, the spectra's addresses are
+    // then workgroup-uniform (scalar base + one per-thread offset instead of a 64-bit address pair per load)
+    const int tid = threadIdx.x, b = (B == 1) ? 0 : tid / TF, jl0 = (B == 1) ? tid : tid % TF;
     const int jl = XP ? X4096::jl1(tid) : jl0;   // butterfly of the later passes = the bins jl + TF s held at the end
     const int f = fg * B + b;
     const bool live = f < P.n_freq;
@@ -353,27 +388,117 @@ __global__ __launch_bounds__(kBlockThreads, 3) void acq_inv_all_kernel(AcqParams
     // every index outside the +-2-chip zone around the peak counts towards the mean: nsamp - (4 nsampchip + 1) of them,
     // wrapped or not (launch_acq_search checks 4 nsampchip < nsamp)
     const int cnt = P.nsamp - 4 * nsampchip - 1;
-    for (int step = 0; step < P.intg; ++step) {
-        c2 v[16];
+    // Optional (GJ_ACQ_AHEAD > 0): part of a step's data spectrum and the running maximum of its (PRN, step) fetched ONE
+    // STEP AHEAD, right behind the previous step's accumulation, so that the loads travel while the row's maximum is
+    // reduced and exchanged.  Measured, see below; the shipped form reads everything at the step's start.
+#ifndef GJ_ACQ_AHEAD
+#define GJ_ACQ_AHEAD 0    // loads of the data spectrum held one step ahead, of 16 (A/B knob, tools/ab_build.sh).  0 ships: the kernel sits
+                          // at 168 VGPRs = three workgroups per CU, and every pair held ahead spills (2: 8 B ... 16: 140 B of scratch);
+                          // 4-6 ahead gained 7-9 % with the old five-operation product and LOSE 15 % with the present one
+                          // (profiles/r04_ab_acq.txt)
+#endif
+    constexpr int AH = GJ_ACQ_AHEAD;
+    cf xa[AH > 0 ? AH : 1];
+    unsigned long long seen = 0ull;
+    auto fetch = [&](int step) {
         const cf* x = xspec + ((size_t)step * P.n_freq + (live ? f : 0)) * N;
 #pragma unroll
+        for (int s = 0; s < AH; ++s) xa[s] = x[jl0 + TF * s];
+        // read past the L1 by the transform's first thread; possibly stale by the time it is used -- gmax only grows
+        if (AH > 0 && jl == 0 && live) seen = __hip_atomic_load(&gmax[(size_t)p * P.intg + step], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    fetch(0);
+    for (int step = 0; step < P.intg; ++step) {
+        c2 v[16];
+        if (AH == 0 && jl == 0 && live) seen = __hip_atomic_load(&gmax[(size_t)p * P.intg + step], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long seen_now = seen;
+        const cf* xnow = xspec + ((size_t)step * P.n_freq + (live ? f : 0)) * N;
+#pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const cf a = x[jl0 + TF * s], q = c[jl0 + TF * s];
-            v[s] = make_c2(-a.x * q.x - a.y * q.y, -(a.x * q.y - a.y * q.x));   // as in acq_inv_kernel
+            const cf a = s < AH ? xa[s] : xnow[jl0 + TF * s], q = c[jl0 + TF * s];
+            // conj(X) * (-C / m) as stored = cpxconv's product, as in acq_inv_kernel.  Plain arithmetic on purpose: the
+            // packed form (v_pk_mul + v_pk_fma per point, alone or two points interleaved) measured 18-19 % SLOWER here
+            // (profiles/r04_ab_acq.txt) -- the loads arrive one by one and the scalar form consumes them as they come
+            v[s] = make_c2(a.x * q.x - a.y * q.y, a.x * q.y + a.y * q.x);
         }
         acq_transform<N>(v, lds, tid, b * lds_span(N), jl, tw);
+        AcqMax mine{-1.0};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            acc[s] += (double)(v[s].x * v[s].x + v[s].y * v[s].y);   // 1/m^2 rides on the code spectrum (acq_code_kernel)
+            mine.v = __builtin_fmax(mine.v, acc[s]);
+        }
+        if (step + 1 < P.intg) fetch(step + 1);
+#ifdef GJ_ACQ_ABLATE_CHECK   // timing only (tools/ab_build.sh): no peak bookkeeping at all
+        if (step + 1 == P.intg && live && jl == 0) rows[((size_t)p * P.intg + step) * P.n_freq + f].maxv = mine.v;
+        continue;
+#endif
+        // The row's maximum (value only) AND what the transform's first thread read of the running maximum when the step
+        // began, both known to every thread of the transform after ONE exchange.  The early read may be stale, but gmax
+        // only grows: a row below even the stale value cannot be the step's winner and goes straight on -- no atomic,
+        // no second barrier (N = 4096; the shapes with several transforms per workgroup agree on the branch through LDS).
+        const int par = step & 1;
+        bool mine_maybe, maybe;
+        AcqMax rowmax;
+        unsigned long long bits;
+        if constexpr (B == 1) {
+            if (tid == 0) sh_seen[par] = seen_now;   // published by the barrier inside the reduction
+            rowmax = acq_group_reduce<N>(mine, [](AcqMax a, AcqMax o) { return AcqMax{__builtin_fmax(a.v, o.v)}; }, shm, b);
+            bits = (unsigned long long)__double_as_longlong(rowmax.v);
+            mine_maybe = bits >= sh_seen[par];       // live: a workgroup with one transform has returned already otherwise
+            maybe = mine_maybe;
+        } else {
+            rowmax = acq_group_reduce<N>(mine, [](AcqMax a, AcqMax o) { return AcqMax{__builtin_fmax(a.v, o.v)}; }, shm, b);
+            bits = (unsigned long long)__double_as_longlong(rowmax.v);
+            if (jl == 0) sh_need[par][b] = (live && bits >= seen_now) ? 1 : 0;
+            __syncthreads();
+            mine_maybe = sh_need[par][b] != 0;
+            maybe = false;
+#pragma unroll
+            for (int k = 0; k < B; ++k) maybe |= sh_need[par][k] != 0;
+            __syncthreads();                         // sh_need[par] is written again below
+        }
+        if (!mine_maybe && live && jl == 0) {
+            AcqRow r;
+            r.maxv = rowmax.v;
+            r.max2 = 0.0;
+            r.sum = 0.0;
+            r.argk = 0;
+            r.cnt = 0;
+            rows[((size_t)p * P.intg + step) * P.n_freq + f] = r;
+        }
+        if (!maybe) continue;
+        // may be the winner: offer the maximum; only a row that raises or equals the running maximum does the bookkeeping
+        if (jl == 0) {
+            int need = 0;
+            if (mine_maybe) {
+                const unsigned long long old = atomicMax(&gmax[(size_t)p * P.intg + step], bits);
+                need = bits >= old;
+                if (!need) {
+                    AcqRow r;
+                    r.maxv = rowmax.v;
+                    r.max2 = 0.0;
+                    r.sum = 0.0;
+                    r.argk = 0;
+                    r.cnt = 0;
+                    rows[((size_t)p * P.intg + step) * P.n_freq + f] = r;
+                }
+            }
+            sh_need[par][b] = need;
+        }
+        __syncthreads();
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < B; ++k) any |= sh_need[par][k] != 0;    // workgroup-uniform: the reductions below hold barriers
+        if (!any) continue;
+        const bool need = sh_need[par][b] != 0;
+        // ---- the full bookkeeping, for the few rows that may hold the step's peak (as in rounds 2-3) ----
         AcqBestS best;
         best.val = -1.0;
         best.idx = 0x7fffffff;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            acc[s] += (double)((v[s].x * v[s].x + v[s].y * v[s].y) * P.inv_m2);
+        for (int s = 0; s < 8; ++s)
             if (acc[s] > best.val) { best.val = acc[s]; best.idx = jl + TF * s; }   // indices rise with s: '>' keeps the first
-        }
-#ifdef GJ_ACQ_ABLATE_CHECK   // timing only (tools/ab_build.sh): no peak bookkeeping at all
-        if (step + 1 == P.intg && live && jl == 0) rows[((size_t)p * P.intg + step) * P.n_freq + f].maxv = best.val;
-        continue;
-#endif
         best = acq_group_reduce<N>(best, [](AcqBestS a, AcqBestS o) {
             return (o.val > a.val || (o.val == a.val && o.idx < a.idx)) ? o : a; }, shb, b);
         int exinds = best.idx - 2 * nsampchip, exinde = best.idx + 2 * nsampchip;
@@ -390,7 +515,7 @@ __global__ __launch_bounds__(kBlockThreads, 3) void acq_inv_all_kernel(AcqParams
             }
         }
         t = acq_group_reduce<N>(t, [](AcqTail a, AcqTail o) { return AcqTail{a.sum + o.sum, a.mx2 > o.mx2 ? a.mx2 : o.mx2}; }, sht, b);
-        if (live && jl == 0) {
+        if (live && need && jl == 0) {
             AcqRow r;
             r.maxv = best.val;
             r.max2 = t.mx2;
@@ -458,7 +583,8 @@ size_t acq_workspace(int nsamp, int n_freq, int n_prn, int intg, bool own_power)
     b += align_up((size_t)n_prn * nfft * sizeof(cf), 256);                 // code spectra
     b += align_up((size_t)intg * n_freq * nfft * sizeof(cf), 256);         // data spectra
     // no power array requested: the single-launch form keeps P in registers and needs the row records only
-    if (own_power) b += align_up((size_t)n_prn * intg * n_freq * sizeof(AcqRow), 256);
+    if (own_power) b += align_up((size_t)n_prn * intg * n_freq * sizeof(AcqRow), 256) +
+                        align_up((size_t)n_prn * intg * sizeof(unsigned long long), 256);   // row records + running maxima
     return b;
 }
 
@@ -473,17 +599,18 @@ static int acq_run(gj_ctx* ctx, const AcqParams& P, const short* d_codes, const 
     w += align_up((size_t)P.n_prn * N * sizeof(cf), 256);
     cf* xspec = reinterpret_cast<cf*>(w);
     w += align_up((size_t)P.intg * P.n_freq * N * sizeof(cf), 256);
+    AcqRow* rows = reinterpret_cast<AcqRow*>(w);
+    unsigned long long* gmax = reinterpret_cast<unsigned long long*>(w + align_up((size_t)P.n_prn * P.intg * P.n_freq * sizeof(AcqRow), 256));
     hipLaunchKernelGGL((acq_code_kernel<N>), dim3((unsigned)((P.n_prn + B - 1) / B)), dim3(kBlockThreads), 0, ctx->stream,
-                       d_codes, P.nsamp, P.n_prn, ctx->d_twiddle, cspec);
+                       d_codes, P.nsamp, P.n_prn, ctx->d_twiddle, cspec, d_power ? nullptr : gmax, d_power ? 0 : P.n_prn * P.intg);
     GJ_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL((acq_fwd_kernel<N>), dim3((unsigned)((P.intg * P.n_freq + B - 1) / B)), dim3(kBlockThreads), 0,
                        ctx->stream, P, d_phase, ctx->d_twiddle, xspec);
     GJ_LAUNCH_CHECK(ctx);
     if (!d_power) {
-        AcqRow* rows = reinterpret_cast<AcqRow*>(w);
         const unsigned groups = (unsigned)((P.n_freq + B - 1) / B);
         hipLaunchKernelGGL((acq_inv_all_kernel<N>), dim3(8u * (unsigned)P.n_prn * ((groups + 7u) / 8u)), dim3(kBlockThreads), 0,
-                           ctx->stream, P, nsampchip, ctx->d_twiddle, xspec, cspec, rows);
+                           ctx->stream, P, nsampchip, ctx->d_twiddle, xspec, cspec, rows, gmax);
         GJ_LAUNCH_CHECK(ctx);
         const unsigned waves = (unsigned)(P.intg < 16 ? P.intg : 16);
         hipLaunchKernelGGL(acq_summary_kernel, dim3((unsigned)P.n_prn), dim3(64u * waves), 0, ctx->stream, P, ctime, threshold,

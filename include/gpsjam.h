@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GJ_VERSION 130 /* 0.1.3: device identity, communicator figures read from the live communicator, batched part combine (result header: 40 fields) */
+#define GJ_VERSION 130 /* 0.1.3: device identity, communicator figures read from the live communicator, three-launch part combine; the result header has 40 fields (GJ_RESULT_HEADER) */
 
 typedef struct gj_ctx gj_ctx;
 

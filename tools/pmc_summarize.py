@@ -4,7 +4,7 @@ dispatch of welch_kernel) with the HBM byte counts corrected as MI355X_MICROARCH
 FETCH_SIZE is in KiB and, on gfx950, tallies 128-B requests at 64 B for wide streaming reads;
 the factor for K2's own 2-byte-per-lane pattern is calibrated by tools/calib_fetch (1 GiB read
 exactly once with each pattern) in the same session.
-    python tools/pmc_summarize.py gpurun_out/<dir> [measured-on-commit] > profiles/r02_pmc_welch/summary.json
+    python tools/pmc_summarize.py gpurun_out/<dir> [measured-on-commit [nperseg]] > profiles/r02_pmc_welch/summary.json
 The summary is stamped with the commit it was measured on and with a hash of the K2 sources
 (bench.py compares that hash with the sources it runs on)."""
 import collections
@@ -69,7 +69,9 @@ def main():
         except Exception:
             out["_commit"] = "unknown"
     out["_source_hash"] = source_hash()
-    out["_note"] = ("rocprofv3 --pmc, separate passes (tools/pmc_welch.sh), welch_kernel<4096> on 2^30 bytes, "
+    nper = sys.argv[3] if len(sys.argv) > 3 else "4096"
+    out["_nperseg"] = int(nper)
+    out["_note"] = (f"rocprofv3 --pmc, separate passes (tools/pmc_welch.sh <dir> {nper}), welch_kernel<{nper}> on 2^30 bytes, "
                     "averages per dispatch")
     print(json.dumps(out, indent=1))
 
