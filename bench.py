@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--split", action="store_true",
                     help="strong scaling (SURVEY 8(e)): --antennas captures of --capture-bytes each are cut into parts "
                          "over the N GPUs (gpsjam.split) instead of one capture per GPU")
+    ap.add_argument("--emulate-rank", type=int, default=0,
+                    help="--split --emulate-world W: which rank of the W this GPU plays (rank 0 also gathers and combines)")
     ap.add_argument("--antennas", type=int, default=3,
                     help="captures in --split mode (the reference's deployment has three, worker.py:586-600)")
     ap.add_argument("--force-exchange", action="store_true",
@@ -140,6 +142,11 @@ def main():
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout, args))
 
     guard_stdout()
+    # The step uses two streams (three on rank 0 of --split) beside torch's and the contexts' own.  The HIP runtime deals
+    # streams over GPU_MAX_HW_QUEUES hardware queues (four by default), and two of the step's streams on one queue run
+    # one after the other (seen in the kernel trace: the combine stream on the main stream's queue, K2 queued behind it).
+    # Eight queues keep them apart; the one-capture-per-GPU step is indifferent (1.301 against 1.308 ms).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import numpy as np
     import torch
     import gpsjam
@@ -464,7 +471,7 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
     if emulated:
         # rehearsal: this GPU is rank 0 of `emulated` -- 1/emulated of the bytes, its share of the pairs and the combine over
         # all ranks' part vectors; what the other ranks would send was computed here, once, before the timed region
-        st = split.emulated_rank0(dev, [nbytes] * A, make_buffer, make_noise, emulated, nperseg=NPERSEG,
+        st = split.emulated_rank(dev, [nbytes] * A, make_buffer, make_noise, emulated, args.emulate_rank, nperseg=NPERSEG,
                                   chunk_samples=CHUNK_SAMPLES, slice_samples=SLICE, overlap=not args.no_overlap,
                                   exchange_always=args.force_exchange)
     else:
@@ -505,7 +512,7 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
     # the second stream's chain (scan, slots, [all-gather], K5, [gather], combine) against K2, one step in isolation:
     # does the chain end inside K2 or does it stick out?
     chain = None
-    if rank == 0 and st.overlap and world == 1:
+    if rank == 0 and st.overlap and world == 1 and st.is_root:
         torch.cuda.synchronize()
         e0, e1, e2, e3 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
         reps, k2_ms, front_ms, tail_ms = 5, 0.0, 0.0, 0.0
@@ -518,7 +525,7 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
             st.tdoa()
             e3.record(st._side)
             st.exchange(0)
-            e2.record(st._side)
+            e2.record(st._comb)
             torch.cuda.synchronize()
             k2_ms += e0.elapsed_time(e1) / reps
             front_ms += e0.elapsed_time(e3) / reps
@@ -532,6 +539,21 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
                          "second).  In steady state step k's combine and step k+1's front chain share the second stream "
                          "under step k+1's K2: hidden when their sum fits into K2"}
     proof = exchange_proof(args, torch, dist if (world > 1 or args.force_exchange) else None, dev, None, world, rank)
+    if emulated and args.emulate_rank != 0:
+        # a rank that only sends: no results arrive here; its step time is what the rehearsal is after
+        emit({"metric": "Msamples/s uint8 I/Q through PSD+TDOA xcorr", "value": float(nsamp) * A * args.steps / elapsed / 1e6,
+              "unit": "Msamples/s", "projected": True, "emulated_world": emulated, "emulated_rank": args.emulate_rank,
+              "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+              "scaling": "strong", "higher_is_better": True, "dtype": "f32", "data": "synthetic", "vs_baseline": None,
+              "config": {"workload": f"REHEARSAL: rank {args.emulate_rank} of {emulated} of the split run (its parts only; sends its slots "
+                                     "and part vectors, receives nothing)", "own_bytes": own,
+                         "pairs": [list(p) for p in st.pairs]},
+              "roofline": {"bound": "hbm", "kernel": "welch_kernel<4096> + welch_finalize_kernel over this rank's parts",
+                           "achieved": (own / 1e9) / (welch_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": (own / 1e9) / (welch_ms / 1e3) / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": welch_ms},
+              **proof})
+        st.close()
+        return
     if rank == 0:
         results, tdoa = got.unpack()
         onsets = [r.onset for r in results]
@@ -646,6 +668,7 @@ def run_ranks(n, argv, limit_s, stdout=None):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")                 # see main(): the step's streams on hardware queues of their own
     env.setdefault("OMP_NUM_THREADS", "1")
     print("[bench] launching " + " ".join(cmd), file=sys.stderr, flush=True)
     # same session and process group as this parent: whatever stops the parent's group stops the ranks too; a

@@ -6,8 +6,8 @@
 //   cpxconv             sdrcmn.c:124-147                      (FFT . conj(code FFT) . IFFT -> |.|^2 / m^2, summed)
 //   checkacquisition    sdracq.c:52-84                        (peak, +-2 chip exclusion, peak ratio > 3)
 // on the block FFT of fft_core.h (the machinery of K2 / K5):
-//   acq_code_kernel : C_p   = FFT(resampled code of PRN p, zero-padded to nfft)            once per search
-//   acq_fwd_kernel  : X_s,f = FFT(mix(data window s, Doppler bin f) * CSCALE/m)            n_freq x intg transforms
+//   acq_prep_kernel : C_p   = FFT(resampled code of PRN p, zero-padded to nfft)            once per search
+//                     X_s,f = FFT(mix(data window s, Doppler bin f) * CSCALE/m)            n_freq x intg transforms, same launch
 //   acq_inv_kernel  : P_p,f += |IFFT(-X_s,f conj(C_p))|^2 / m^2 over the first nsamp lags   n_freq x n_prn per step
 //   acq_check_kernel: per PRN the reference's peak test; a PRN that passes stops integrating (device flag)
 // The data FFT does not depend on the PRN, so it is computed once per (step, bin) and reused by all PRNs
@@ -60,16 +60,16 @@ __constant__ signed char kAcqCos[16] = {32, 30, 23, 12, 0, -12, -23, -30, -32, -
 __constant__ signed char kAcqSin[16] = {0, 12, 23, 30, 32, 30, 23, 12, 0, -12, -23, -30, -32, -30, -23, -12};
 
 // one transform per workgroup (N = 4096) or 4096 / N of them (smaller N): `which` = transform index
+// (blk of nblk: the workgroup's index among those that transform codes)
 template <int N>
-__global__ __launch_bounds__(kBlockThreads) void acq_code_kernel(const short* __restrict__ codes, int nsamp, int n_prn,
-                                                                 const cf* __restrict__ twtab, cf* __restrict__ cspec,
-                                                                 unsigned long long* __restrict__ gmax, int n_gmax) {
+__device__ __forceinline__ void acq_code_body(const short* __restrict__ codes, int nsamp, int n_prn, const cf* __restrict__ twtab,
+                                              cf* __restrict__ cspec, unsigned long long* __restrict__ gmax, int n_gmax, cf* lds,
+                                              int blk, int nblk) {
     constexpr int TF = N / 16, B = kBlockPoints / N;
-    __shared__ cf lds[B * lds_span(N)];
-    // first kernel of a search: clear the running row maxima of acq_inv_all_kernel (two launches ahead in stream order)
-    for (int i = blockIdx.x * kBlockThreads + threadIdx.x; i < n_gmax; i += gridDim.x * kBlockThreads) gmax[i] = 0ull;
+    // first launch of a search: clear the running row maxima of acq_inv_all_kernel (the next launch in stream order)
+    for (int i = blk * kBlockThreads + threadIdx.x; i < n_gmax; i += nblk * kBlockThreads) gmax[i] = 0ull;
     const int tid = threadIdx.x, b = tid / TF, jl = tid % TF;
-    const int p = blockIdx.x * B + b;
+    const int p = blk * B + b;
     const bool live = p < n_prn;
     c2 v[16];
 #pragma unroll
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kBlockThreads) void acq_code_kernel(const short* __
     if (live) {
         // Stored as -C_p / m.  1/m: cpxconv's |.|^2 / m^2 (sdrcmn.c:141-143) then needs no multiply per lag; m = N is a
         // power of two, so the scaling is exact and commutes with every float operation behind it.  The sign, together
-        // with the CONJUGATED data spectrum acq_fwd_kernel stores, turns cpxconv's product (real = -p0 q0 - p1 q1,
+        // with the CONJUGATED data spectrum acq_fwd_body stores, turns cpxconv's product (real = -p0 q0 - p1 q1,
         // imag = p0 q1 - p1 q0, conjugated for the forward-FFT inverse: sdrcmn.c:131-135) into one plain complex multiply
         // conj(X) * (-C): four multiply-adds per point and no sign flips (five operations before).
         constexpr float inv_m = -1.0f / (float)N;
@@ -91,12 +91,11 @@ __global__ __launch_bounds__(kBlockThreads) void acq_code_kernel(const short* __
 }
 
 template <int N>
-__global__ __launch_bounds__(kBlockThreads) void acq_fwd_kernel(AcqParams P, const uint8_t* __restrict__ phase,
-                                                                const cf* __restrict__ twtab, cf* __restrict__ xspec) {
+__device__ __forceinline__ void acq_fwd_body(const AcqParams& P, const uint8_t* __restrict__ phase, const cf* __restrict__ twtab,
+                                             cf* __restrict__ xspec, cf* lds, int blk) {
     constexpr int TF = N / 16, B = kBlockPoints / N;
-    __shared__ cf lds[B * lds_span(N)];
     const int tid = threadIdx.x, b = tid / TF, jl = tid % TF;
-    const int t = blockIdx.x * B + b;          // transform = step * n_freq + bin
+    const int t = blk * B + b;                 // transform = step * n_freq + bin
     const bool live = t < P.intg * P.n_freq;
     const int s_idx = live ? t / P.n_freq : 0, f = live ? t % P.n_freq : 0;
     const uint16_t* src = reinterpret_cast<const uint16_t*>(P.iq) + P.first_sample + (size_t)s_idx * P.nsamp;
@@ -115,8 +114,21 @@ __global__ __launch_bounds__(kBlockThreads) void acq_fwd_kernel(AcqParams P, con
     acq_passes<N, 0>(v, lds, b * lds_span(N), jl, twtab);
     if (live) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) xspec[(size_t)t * N + jl + TF * s] = to_cf(make_c2(v[s].x, -v[s].y));   // conj(X): see acq_code_kernel
+        for (int s = 0; s < 16; ++s) xspec[(size_t)t * N + jl + TF * s] = to_cf(make_c2(v[s].x, -v[s].y));   // conj(X): see acq_code_body
     }
+}
+// ONE launch for everything a search transforms before the correlations: the first code_blocks workgroups the PRNs'
+// codes, the others the mixed data windows (independent work; two launches of a few microseconds each cost a
+// launch-to-launch gap in a chain that is 0.18 ms long)
+template <int N>
+__global__ __launch_bounds__(kBlockThreads) void acq_prep_kernel(AcqParams P, const short* __restrict__ codes,
+                                                                 const uint8_t* __restrict__ phase, const cf* __restrict__ twtab,
+                                                                 cf* __restrict__ cspec, cf* __restrict__ xspec,
+                                                                 unsigned long long* __restrict__ gmax, int n_gmax, int code_blocks) {
+    constexpr int B = kBlockPoints / N;
+    __shared__ cf lds[B * lds_span(N)];
+    if ((int)blockIdx.x < code_blocks) acq_code_body<N>(codes, P.nsamp, P.n_prn, twtab, cspec, gmax, n_gmax, lds, (int)blockIdx.x, code_blocks);
+    else acq_fwd_body<N>(P, phase, twtab, xspec, lds, (int)blockIdx.x - code_blocks);
 }
 
 // grid.x = ceil(n_freq / B), grid.y = PRN.  |IFFT(Y)|^2 = |FFT(conj Y)|^2, Y = -X conj(C)  (cpxconv's product).
@@ -425,7 +437,7 @@ __global__ __launch_bounds__(kBlockThreads, N == 2048 ? 2 : 3) void acq_inv_all_
         AcqMax mine{-1.0};
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            acc[s] += (double)(v[s].x * v[s].x + v[s].y * v[s].y);   // 1/m^2 rides on the code spectrum (acq_code_kernel)
+            acc[s] += (double)(v[s].x * v[s].x + v[s].y * v[s].y);   // 1/m^2 rides on the code spectrum (acq_code_body)
             mine.v = __builtin_fmax(mine.v, acc[s]);
         }
         if (step + 1 < P.intg) fetch(step + 1);
@@ -601,11 +613,10 @@ static int acq_run(gj_ctx* ctx, const AcqParams& P, const short* d_codes, const 
     w += align_up((size_t)P.intg * P.n_freq * N * sizeof(cf), 256);
     AcqRow* rows = reinterpret_cast<AcqRow*>(w);
     unsigned long long* gmax = reinterpret_cast<unsigned long long*>(w + align_up((size_t)P.n_prn * P.intg * P.n_freq * sizeof(AcqRow), 256));
-    hipLaunchKernelGGL((acq_code_kernel<N>), dim3((unsigned)((P.n_prn + B - 1) / B)), dim3(kBlockThreads), 0, ctx->stream,
-                       d_codes, P.nsamp, P.n_prn, ctx->d_twiddle, cspec, d_power ? nullptr : gmax, d_power ? 0 : P.n_prn * P.intg);
-    GJ_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL((acq_fwd_kernel<N>), dim3((unsigned)((P.intg * P.n_freq + B - 1) / B)), dim3(kBlockThreads), 0,
-                       ctx->stream, P, d_phase, ctx->d_twiddle, xspec);
+    const int code_blocks = (P.n_prn + B - 1) / B, fwd_blocks = (P.intg * P.n_freq + B - 1) / B;
+    hipLaunchKernelGGL((acq_prep_kernel<N>), dim3((unsigned)(code_blocks + fwd_blocks)), dim3(kBlockThreads), 0, ctx->stream, P,
+                       d_codes, d_phase, ctx->d_twiddle, cspec, xspec, d_power ? nullptr : gmax, d_power ? 0 : P.n_prn * P.intg,
+                       code_blocks);
     GJ_LAUNCH_CHECK(ctx);
     if (!d_power) {
         const unsigned groups = (unsigned)((P.n_freq + B - 1) / B);

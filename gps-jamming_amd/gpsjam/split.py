@@ -71,7 +71,9 @@ class Part:
 def plan_parts(capture_bytes: Sequence[int], world: int, unit: int) -> List[Part]:
     """Lay the captures end to end in units and cut the line into ``world`` contiguous runs of (almost) equal
     length; a run that crosses the boundary between two captures gives its rank one part of each.  The ragged
-    end of a capture belongs to its last unit.  Ranks beyond the number of units get nothing."""
+    end of a capture belongs to its last unit.  Ranks beyond the number of units get nothing.
+    (Equal runs on purpose: giving rank 0 -- which also gathers and combines -- a shorter run was measured and buys
+    nothing, every rank's step is its K2 plus the same fixed chain of small kernels: profiles/r04_split_emulated.txt.)"""
     units = [max(1, -(-int(b) // unit)) for b in capture_bytes]
     total = sum(units)
     bounds = [(r * total) // world for r in range(world + 1)]
@@ -168,38 +170,41 @@ def from_files(dev, paths: Sequence[str], *, rank: int = 0, world_size: int = 1,
     return SplitStreams(dev, sizes, make_buffer, make_noise, rank=rank, world_size=world_size, device=d, **kw)
 
 
-def emulated_rank0(dev, capture_bytes: Sequence[int], make_buffer, make_noise, world: int, **kw) -> "SplitStreams":
-    """Rank 0 of a ``world``-rank split run, alone on ONE GPU, with what the other ranks would have sent already in
-    place (bench.py --split --emulate-world W; tests): every other rank of the plan is walked once on this GPU -- its
-    parts scanned, transformed, its slots cut; then, over everybody's slots, its share of the pairs solved and its part
-    vectors packed -- and its slots and vectors are handed to rank 0 (``adopt_remote``).  Rank 0's steps afterwards do
-    what rank 0 of ``world`` GPUs does: 1/world of the bytes, its pairs, and the combine over ALL ranks' vectors."""
-    root_kw = dict(kw)
+def emulated_rank(dev, capture_bytes: Sequence[int], make_buffer, make_noise, world: int, rank: int = 0, **kw) -> "SplitStreams":
+    """Rank ``rank`` of a ``world``-rank split run, alone on ONE GPU, with what the other ranks would have sent already in
+    place (bench.py --split --emulate-world W [--emulate-rank R]; tests): every other rank of the plan is walked once on
+    this GPU -- its parts scanned, transformed, its slots cut; then, over everybody's slots, its share of the pairs
+    solved and its part vectors packed -- and its slots (and, for rank 0, its vectors) are handed to the timed rank
+    (``adopt_remote``).  Its steps afterwards do what that rank of ``world`` GPUs does: 1/world of the bytes, its pairs,
+    and on rank 0 the combine over ALL ranks' vectors."""
     other_kw = dict(kw, overlap=False, exchange_always=False)
-    root = SplitStreams(dev, capture_bytes, make_buffer, make_noise, rank=0, world_size=world, emulate=True, **root_kw)
+    me = SplitStreams(dev, capture_bytes, make_buffer, make_noise, rank=rank, world_size=world, emulate=True, **kw)
     others = [SplitStreams(dev, capture_bytes, make_buffer, make_noise, rank=r, world_size=world, emulate=True, **other_kw)
-              for r in range(1, world)]
-    everyone = [root] + others
-    for st in everyone:                                   # pass 1: what needs no other rank
+              for r in range(world) if r != rank]
+    for st in [me] + others:                              # pass 1: what needs no other rank
         st.scan()
         with st._on_side():
             st.cut_slots()
     torch.cuda.synchronize()
     for st in others:
-        root.all_slots[st.rank * st.pmax:(st.rank + 1) * st.pmax].copy_(st.my_slots)
-    root.all_slots[0:root.pmax].copy_(root.my_slots)
+        me.all_slots[st.rank * st.pmax:(st.rank + 1) * st.pmax].copy_(st.my_slots)
+    me.all_slots[me.rank * me.pmax:(me.rank + 1) * me.pmax].copy_(me.my_slots)
     for st in others:                                     # pass 2: over everybody's slots
-        st.all_slots.copy_(root.all_slots)
+        st.all_slots.copy_(me.all_slots)
         st.solve(st.all_slots)
         vec = st.pack()
         torch.cuda.synchronize()
-        root.adopt_remote(st.rank, st.my_slots, vec)
+        me.adopt_remote(st.rank, st.my_slots, vec)
     torch.cuda.synchronize()
     for st in others:
         st.close()
-    if root._main is not None:                            # the walked ranks pointed the shared context at their streams
-        dev.set_stream(root._main.cuda_stream)
-    return root
+    if me._main is not None:                              # the walked ranks pointed the shared context at their streams
+        dev.set_stream(me._main.cuda_stream)
+    return me
+
+
+def emulated_rank0(dev, capture_bytes: Sequence[int], make_buffer, make_noise, world: int, **kw) -> "SplitStreams":
+    return emulated_rank(dev, capture_bytes, make_buffer, make_noise, world, 0, **kw)
 
 
 class PartStream:
@@ -282,6 +287,15 @@ class SplitStreams:
             self._ev_free.record(self._main)
         else:
             self._side = self._main
+        # Rank 0's gather + combine get a THIRD stream (and a context bound to it): on the second stream they would sit
+        # between step k's K5 and step k + 1's scan, and under K2 -- where every small launch waits tens of microseconds
+        # for a slot -- that serialisation left the next scan starting when K2 was two thirds through
+        # (profiles/r04_split_emulated8_timeline.txt).  The combine reads only the packed vectors of its own step.
+        self.dev_comb, self._comb = self.dev_side, self._side
+        if self.overlap and self.is_root:
+            self.dev_comb = type(dev)(dev.index)
+            self._comb = torch.cuda.Stream(device=d)
+            self.dev_comb.set_stream(self._comb.cuda_stream)
         kw = dict(chunk_bytes=chunk_bytes, chunk_samples=chunk_samples, nperseg=nperseg, fs=fs, slice_samples=slice_samples,
                   noise_samples=noise_samples, window=window, factor=factor, rssi_threshold=rssi_threshold)
         self.streams: List[PartStream] = []
@@ -363,6 +377,9 @@ class SplitStreams:
     def _on_side(self):
         return torch.cuda.stream(self._side) if self.overlap else contextlib.nullcontext()
 
+    def _on_comb(self):
+        return torch.cuda.stream(self._comb) if self.overlap else contextlib.nullcontext()
+
     # ---------------------------------------------------------------- the step
     def stream_scan(self):
         """K1 + K3 + K4 of every part of this rank, one fused pass each (side stream)."""
@@ -440,16 +457,16 @@ class SplitStreams:
 
     def exchange(self, dst: int = 0) -> Optional[StepResults]:
         assert dst == 0
-        # Gather and (rank 0) combine run on the SECOND stream: a chain of small latency-bound kernels (one-workgroup
-        # threshold, amplitude total, packing) that would otherwise sit between two steps' K2 launches with the chip
-        # idle; the main stream goes straight on to the next step.  Everything they read is in the packed vectors
-        # (two sets, used alternately).
+        # Gather and (rank 0) combine run beside the main stream: a chain of small latency-bound kernels that would
+        # otherwise sit between two steps' K2 launches with the chip idle; the main stream goes straight on to the next
+        # step.  On rank 0 the chain has a stream of its own (see __init__), elsewhere it follows K5 on the second one.
+        # Everything it reads is in the packed vectors (two sets, used alternately).
         vec = self.pack()
         k = self._idx
         final = None
         if self.overlap:
-            self._side.wait_event(self._ev_packed)
-        with self._on_side():
+            self._comb.wait_event(self._ev_packed)
+        with self._on_comb():
             if self.emulate:
                 src = vec.view(-1)
                 if self._always:
@@ -464,11 +481,11 @@ class SplitStreams:
             if self.is_root:
                 final = self._combine(rows, k)
                 if self._done[k] is not None:
-                    self._done[k].record(self._side)
+                    self._done[k].record(self._comb)
             if self.overlap:
                 if self._ev_vec_free[k] is None:
                     self._ev_vec_free[k] = torch.cuda.Event()
-                self._ev_vec_free[k].record(self._side)
+                self._ev_vec_free[k].record(self._comb)
         if not self.is_root:
             return None
         return StepResults(final, self._done[k], self.n_ant)
@@ -483,7 +500,7 @@ class SplitStreams:
         """Arena k (every capture's assembled arrays + the result vectors) and the static plan of its combine: the copy
         list part vector -> capture-order array and one descriptor per capture, checked on the host and uploaded once
         (gj_combine_plan_create).  Which rank holds which part, and which rank solved which pair, never changes."""
-        dev, nper, L8 = self.dev_side, self.nperseg, 8 * self.part_len
+        dev, nper, L8 = self.dev_comb, self.nperseg, 8 * self.part_len
         off = 0
 
         def take(nbytes: int) -> int:
@@ -549,7 +566,7 @@ class SplitStreams:
         """Every capture rebuilt from its parts' vectors and finished (threshold, amplitude totals, onset, mean
         spectrum, packing) in three launches on the second stream, no host synchronisation, no allocation."""
         assert rows.is_contiguous() and rows.numel() * 8 == self.world * self.pmax * 8 * self.part_len
-        self.dev_side.split_combine_dev(self._plans[k], rows)
+        self.dev_comb.split_combine_dev(self._plans[k], rows)
         self.last_psd = self._psd_views[k]
         return self._final[k]
 
@@ -566,7 +583,9 @@ class SplitStreams:
     def close(self):
         for k, pl in enumerate(self._plans):
             if pl is not None:
-                self.dev_side.combine_plan_destroy(pl)
+                self.dev_comb.combine_plan_destroy(pl)
                 self._plans[k] = None
+        if self.dev_comb is not self.dev_side and self.dev_comb is not self.dev:
+            self.dev_comb.close()
         if self.overlap and self.dev_side is not self.dev:
             self.dev_side.close()

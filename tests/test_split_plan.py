@@ -64,3 +64,4 @@ def test_buffer_range_and_pairs():
     assert sorted(x for v in deal.values() for x in v) == [(0, 1), (0, 2), (1, 2)] and max(len(v) for v in deal.values()) == 1
     deal = split.deal_pairs(8, [0, 1, 2])
     assert sorted(x for v in deal.values() for x in v) == [(i, j) for i in range(8) for j in range(i + 1, 8)]
+
