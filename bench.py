@@ -382,7 +382,7 @@ def main():
                     "bound": "hbm", "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": scan_ms,
                     "achieved": (nbytes / 1e9) / (scan_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (nbytes / 1e9) / (scan_ms / 1e3) / HBM_PEAK_GBS,
-                    **family_traffic("profiles/r03_pmc_scan/summary.json", nbytes)},
+                    **family_traffic("profiles/r04_pmc_scan/summary.json", nbytes)},
             },
             "results": {"pairs": [list(p) for p in tdoa.pairs], "lags": tdoa.lags,
                         "lag_margins": [round(m, 4) for m in tdoa.margins], "onsets": onsets,
@@ -414,7 +414,7 @@ def main():
                 "transforms_per_s": n_fft / (acq_ms / 1e3),
                 "real_time_factor": (intg * 1e-3) / (acq_ms / 1e3),
                 "k2_transforms_per_s_for_scale": (nbytes / 2 / (NPERSEG // 2)) / (solo_ms / 1e3),
-                **family_traffic("profiles/r03_pmc_acq/summary.json", nbytes),
+                **family_traffic("profiles/r04_pmc_acq/summary.json", nbytes),
                 "parity": "unpinned (gnssdec unbuildable here); oracle = numpy restatement of sdracq.c / sdrcmn.c"}
         if ref_point is not None:
             k2r = ref_point["k2_ms"]

@@ -574,7 +574,10 @@ int gj_combine_plan_create(gj_ctx* ctx, const gj_combine_copy* copies, int n_cop
     if (n_copies < 1 || n_copies > 65535 || n_captures < 1 || n_captures > 1024)
         return fail(ctx, GJ_ERR_INVALID, "%d copies, %d captures", n_copies, n_captures);
     if (nperseg < 16 || nperseg > 4096 || (nperseg & (nperseg - 1))) return fail(ctx, GJ_ERR_UNSUPPORTED, "nperseg %d", nperseg);
-    Guard g(ctx);
+    // no context state is touched: validation on the host, two device allocations and two synchronous copies -- done
+    // WITHOUT the context lock (a synchronous copy is a host-side wait)
+    NoCancel nc;
+    (void)hipSetDevice(ctx->device);
     return combine_plan_create(ctx, copies, n_copies, captures, n_captures, rows_bytes, d_arena, arena_bytes, nperseg, pct, rise_db,
                                d_pairs, d_lags, d_peaks, d_margins, out);
 }
@@ -589,8 +592,9 @@ int gj_combine_plan_destroy(gj_ctx* ctx, gj_combine_plan* plan) {
     if (!plan) return GJ_OK;
     if (!ctx) return GJ_ERR_INVALID;
     (void)wait_stream(ctx, current_stream(ctx));   // queued launches read the plan's device arrays
-    Guard g(ctx);
-    combine_plan_destroy(plan);
+    NoCancel nc;
+    (void)hipSetDevice(ctx->device);
+    combine_plan_destroy(plan);                    // hipFree may wait for the device: not under the context lock
     return GJ_OK;
 }
 

@@ -117,8 +117,15 @@ int main(void) {
         const int rc_id = gj_comm_unique_id(id);
         if (rc_id != GJ_OK) { fprintf(stderr, "gj_comm_unique_id -> %d (librccl missing?)\n", rc_id); return 2; }
         CHECK(gj_comm_init_rank(ctx, id, 0, 1, &comm));
-        int r = -1, nr = -1;
-        CHECK(gj_comm_rank(comm, &r, &nr));
+        int r = -1, nr = -1, cdev = -1;
+        CHECK(gj_comm_rank(comm, &r, &nr));          /* read from the live communicator (ncclCommUserRank / ncclCommCount) */
+        CHECK(gj_comm_device(comm, &cdev));
+        char ident[160];
+        CHECK(gj_device_identity(ctx, ident, sizeof(ident)));
+        if (cdev != 0 || strncmp(ident, "pci=", 4) != 0 || !strstr(ident, " uuid=") || !strstr(ident, " hip=0")) {
+            fprintf(stderr, "identity '%s', communicator device %d\n", ident, cdev);
+            return 1;
+        }
         CHECK(gj_comm_allgather_dev(comm, d_slot, sb, d_slots));
         const int32_t pair[2] = {0, 0};
         CHECK(gj_memcpy_h2d(ctx, d_pairs, pair, sizeof(pair)));
