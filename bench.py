@@ -142,11 +142,9 @@ def main():
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout, args))
 
     guard_stdout()
-    # The step uses two streams (three on rank 0 of --split) beside torch's and the contexts' own.  The HIP runtime deals
-    # streams over GPU_MAX_HW_QUEUES hardware queues (four by default), and two of the step's streams on one queue run
-    # one after the other (seen in the kernel trace: the combine stream on the main stream's queue, K2 queued behind it).
-    # Eight queues keep them apart; the one-capture-per-GPU step is indifferent (1.301 against 1.308 ms).
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # (The step's streams -- two, three on rank 0 of --split -- must not share a hardware queue: the runtime deals streams
+    # over GPU_MAX_HW_QUEUES queues, four by default, and two on one queue run one after the other.  The pipelines test
+    # for that when they make their streams: gpsjam/streams.py.)
     import numpy as np
     import torch
     import gpsjam
@@ -668,7 +666,6 @@ def run_ranks(n, argv, limit_s, stdout=None):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this driver
-    env.setdefault("GPU_MAX_HW_QUEUES", "8")                 # see main(): the step's streams on hardware queues of their own
     env.setdefault("OMP_NUM_THREADS", "1")
     print("[bench] launching " + " ".join(cmd), file=sys.stderr, flush=True)
     # same session and process group as this parent: whatever stops the parent's group stops the ranks too; a
@@ -949,8 +946,10 @@ def deployment(np, torch, gpsjam, dev, StreamSpec, reps=20):
         caps.append(c)
     nch, rows = dev.chunk_count(nb, 65536), dev.welch_rows(nb, CHUNK_SAMPLES, REF_NPERSEG)
     sb = dev.tdoa_slot_bytes(REF_SLICE)
+    from gpsjam.streams import stream_beside
     side_dev = gpsjam.Device(dev.index)
-    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    side = stream_beside([(dev, main)])        # a second stream on a hardware queue of its own (gpsjam/streams.py)
     side_dev.set_stream(side.cuda_stream)
     power = [torch.empty(nch, dtype=torch.float32, device="cuda") for _ in range(3)]
     stats = [torch.empty(3, dtype=torch.float32, device="cuda") for _ in range(3)]
@@ -1042,7 +1041,9 @@ def deployment(np, torch, gpsjam, dev, StreamSpec, reps=20):
                         "baseline": [float(x[0]) for x in gpu["stats"]]},
             "what": "resident_step: back-to-back steps over three captures already in HBM (rate) and one step alone (latency); "
                     "file_to_results: three page-cache-resident files through gj_ingest_file (pieces sized to the capture, kernels "
-                    "on what has landed) + K5 on the resident captures, wall clock with PCIe, best of three"}
+                    "on what has landed), one file after the other as the drop-ins do (three at once, one thread and lane each, was "
+                    "measured: 5.8-7.3 against 5.6-6.0 ms, no gain -- each ingest already runs eight fill threads) + K5 on the "
+                    "resident captures, wall clock with PCIe, best of three"}
     return {"line": line, "gpu": gpu}
 
 

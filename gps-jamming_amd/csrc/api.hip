@@ -192,6 +192,22 @@ int gj_debug_set_wait_hook(gj_ctx* ctx, void (*hook)(void*, int), void* arg) {
     return GJ_OK;
 }
 
+// one wave that spins on the constant-rate (100 MHz) real-time counter: keeps the context's stream -- and the hardware
+// queue behind it -- busy for a known time without occupying the chip
+__global__ void debug_busy_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+int gj_debug_busy_dev(gj_ctx* ctx, float milliseconds) {
+    if (!ctx) return GJ_ERR_INVALID;
+    if (!(milliseconds >= 0.f) || milliseconds > 100.f) return fail(ctx, GJ_ERR_INVALID, "busy time %g ms (0..100)", (double)milliseconds);
+    Guard g(ctx);
+    hipLaunchKernelGGL(debug_busy_kernel, dim3(1), dim3(64), 0, ctx->stream, (unsigned long long)((double)milliseconds * 1e5));
+    GJ_LAUNCH_CHECK(ctx);
+    return GJ_OK;
+}
+
 int gj_debug_counters(gj_ctx* ctx, int* lanes, int* lanes_busy, int* lanes_reclaimed, int* owner_deaths) {
     if (!ctx) return GJ_ERR_INVALID;
     Guard g(ctx);

@@ -206,6 +206,12 @@ class Capture:
     passes (tests)."""
 
     uploads = 0
+    _count_lock = __import__("threading").Lock()
+
+    @classmethod
+    def _count(cls):
+        with cls._count_lock:                                # several host threads may upload at once (one lane each)
+            cls.uploads += 1
 
     @classmethod
     def _adopt(cls, dev: "Device", ptr: int, nbytes: int, path=None) -> "Capture":
@@ -213,7 +219,7 @@ class Capture:
         self = cls.__new__(cls)
         self.dev, self.ptr, self.nbytes, self.path = dev, int(ptr or 0), int(nbytes), path
         self.results, self.ingest_ms, self.results_unpack = {}, None, None
-        Capture.uploads += 1
+        Capture._count()
         return self
 
     def __init__(self, dev: "Device", source, offset: int = 0, max_bytes: int = 0):
@@ -237,7 +243,7 @@ class Capture:
             dev._check(dev._lib.gj_upload(dev._ctx, raw.ctypes.data if raw.size else None, raw.size, C.byref(p)))
             self.nbytes = int(raw.size)
         self.ptr = p.value or 0
-        Capture.uploads += 1
+        Capture._count()
 
     @property
     def nsamples(self) -> int:
@@ -378,6 +384,10 @@ class Device:
             return raw.ptr, raw.nbytes, raw
         arr = as_u8(raw)
         return (arr.ctypes.data if arr.size else None), int(arr.size), arr
+
+    def debug_busy_dev(self, milliseconds: float):
+        """Keep this context's stream (and its hardware queue) busy for a while with one spinning wave (gj_debug_busy_dev)."""
+        self._check(self._lib.gj_debug_busy_dev(self._ctx, float(milliseconds)))
 
     def debug_counters(self):
         """Lanes made / in use / taken back from dead callers, dead-owner recoveries of the mutex."""

@@ -138,6 +138,7 @@ SIGNATURES = {
     "gj_device_identity": (_i, [_vp, C.c_char_p, _sz]),
     "gj_reserve": (_i, [_vp, _sz]),
     "gj_debug_set_wait_hook": (_i, [_vp, _vp, _vp]),
+    "gj_debug_busy_dev": (_i, [_vp, _f]),
     "gj_debug_counters": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "gj_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "gj_free": (_i, [_vp, _vp]),

@@ -391,7 +391,9 @@ class AntennaStream:
             self._own_side = side_device is None
             # side_priority < 0: a high-priority HIP stream -- its (short) kernels are dispatched ahead of K2's waiting
             # workgroups, which shortens the scan -> slot -> exchange -> K5 chain without changing the total work
-            self._side = torch.cuda.Stream(device=capture.device, priority=int(side_priority))
+            # ... on a hardware queue of its own: two streams the runtime has mapped to one queue run one after the other
+            from .streams import stream_beside
+            self._side = stream_beside([(dev, self._main)], device=capture.device, priority=int(side_priority))
             self.dev_side.set_stream(self._side.cuda_stream)
             self._ev_free = torch.cuda.Event()      # main: previous results consumed, buffers may be rewritten
             self._ev_side = torch.cuda.Event()      # side: scan / TDOA results ready

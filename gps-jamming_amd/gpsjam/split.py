@@ -280,8 +280,9 @@ class SplitStreams:
         if self._main is not None:
             dev.set_stream(self._main.cuda_stream)
         if self.overlap:
+            from .streams import stream_beside
             self.dev_side = type(dev)(dev.index)
-            self._side = torch.cuda.Stream(device=d)
+            self._side = stream_beside([(dev, self._main)], device=d)     # on a hardware queue of its own (gpsjam/streams.py)
             self.dev_side.set_stream(self._side.cuda_stream)
             self._ev_free, self._ev_side, self._ev_packed = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
             self._ev_free.record(self._main)
@@ -294,7 +295,10 @@ class SplitStreams:
         self.dev_comb, self._comb = self.dev_side, self._side
         if self.overlap and self.is_root:
             self.dev_comb = type(dev)(dev.index)
-            self._comb = torch.cuda.Stream(device=d)
+            # The runtime deals streams over a few hardware queues and two streams on one queue run one after the other: a
+            # third stream once landed on the MAIN stream's queue and K2 queued behind the combine.  stream_beside tests
+            # candidates until one runs beside both other streams; more queues (GPU_MAX_HW_QUEUES=8) give it room.
+            self._comb = stream_beside([(dev, self._main), (self.dev_side, self._side)], device=d)
             self.dev_comb.set_stream(self._comb.cuda_stream)
         kw = dict(chunk_bytes=chunk_bytes, chunk_samples=chunk_samples, nperseg=nperseg, fs=fs, slice_samples=slice_samples,
                   noise_samples=noise_samples, window=window, factor=factor, rssi_threshold=rssi_threshold)

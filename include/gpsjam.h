@@ -92,6 +92,12 @@ int gj_reserve(gj_ctx* ctx, size_t workspace_bytes);
  * lanes made, lanes in use, lanes taken back from callers whose thread had gone, and how often the
  * mutex was found with a dead owner. */
 int gj_debug_set_wait_hook(gj_ctx* ctx, void (*hook)(void* arg, int site), void* arg);
+/* Keep the context's stream busy for `milliseconds` (0..100) with ONE wave that spins on the 100-MHz real-time counter:
+ * the chip stays free, the stream -- and the hardware queue the runtime mapped it to -- does not.  A host that needs
+ * two streams to run side by side uses it to find out whether they share a hardware queue (the HIP runtime deals
+ * streams over GPU_MAX_HW_QUEUES queues, four by default, and two streams on one queue run one after the other):
+ * gpsjam/streams.py. */
+int gj_debug_busy_dev(gj_ctx* ctx, float milliseconds);
 int gj_debug_counters(gj_ctx* ctx, int* lanes, int* lanes_busy, int* lanes_reclaimed, int* owner_deaths);
 
 /* device memory for callers that do not bring their own allocator (torch) */

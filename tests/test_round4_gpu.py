@@ -142,3 +142,33 @@ def test_communicator_reports_live_figures(dev):
     assert dev._lib.gj_comm_rank(h, C.byref(r), C.byref(n)) == 0 and (r.value, n.value) == (-1, 0)
     comm.dev = dev                                        # close() only frees the handle now
     comm.close()
+
+
+# ----------------------------------------------------------------------------- streams on hardware queues of their own
+def test_stream_beside_finds_a_stream_that_overlaps(dev):
+    """gpsjam.streams: a stream is tested against another by keeping that one busy with a spinning wave
+    (gj_debug_busy_dev) and recording an event on the candidate.  A stream never runs beside itself; stream_beside
+    returns one that runs beside the main stream, and beside two streams at once."""
+    import torch
+    from gpsjam import streams
+    main = torch.cuda.Stream()
+    dev.set_stream(main.cuda_stream)
+    try:
+        assert streams.runs_beside(dev, main, main) is False          # the same queue by definition
+        side = streams.stream_beside([(dev, main)])
+        assert streams.runs_beside(dev, main, side) is True
+        with gpsjam.Device(0) as dev2:
+            dev2.set_stream(side.cuda_stream)
+            third = streams.stream_beside([(dev, main), (dev2, side)])
+            assert streams.runs_beside(dev, main, third) and streams.runs_beside(dev2, side, third)
+        # the busy kernel holds the stream for about the time asked, and nothing else
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(main)
+        dev.debug_busy_dev(3.0)
+        b.record(main)
+        torch.cuda.synchronize()
+        assert 2.5 < a.elapsed_time(b) < 6.0
+        with pytest.raises(gpsjam.GpsJamError):
+            dev.debug_busy_dev(1000.0)
+    finally:
+        dev.set_stream(None, external=False)
