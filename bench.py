@@ -927,12 +927,13 @@ def welch_ref_traffic(nbytes):
     return out
 
 
-def deployment(np, torch, gpsjam, dev, StreamSpec, reps=20):
+def deployment(np, torch, gpsjam, dev, StreamSpec, reps=20, graph=True):
     """The reference's deployment at the reference's sizes (worker.py:184-196,586-600): THREE antenna
     captures of 10 s (40 960 000 bytes each).  Two figures:
       resident_step_ms   captures in HBM; per capture the fused scan (K1 power map + K3 + K4) + noise-floor threshold + K2 at
-                         nperseg 1024 + TDOA slot, then K5 over the three slots at N = 50 000 (FFT length 131 072), 3 pairs --
-                         K2 on one stream, everything else on a second one, host waits once per step;
+                         nperseg 1024 + TDOA slot, then K5 over the three slots at N = 50 000 (FFT length 131 072), 3 pairs, one
+                         result vector per antenna -- gpsjam.local.LocalAntennas: K2 on the main stream, each capture's chain on a
+                         side stream of its own, nothing synchronises the host inside a step;
       file_to_results_ms three capture FILES -> everything on the host: gj_ingest_file per file (the kernels run on the pieces
                          as they land), then K5 on the resident captures -- what a user of the drop-ins waits for.
     Returns the line entry and the GPU results (for the parity check against the oracle on the same bytes)."""
@@ -946,34 +947,13 @@ def deployment(np, torch, gpsjam, dev, StreamSpec, reps=20):
         caps.append(c)
     nch, rows = dev.chunk_count(nb, 65536), dev.welch_rows(nb, CHUNK_SAMPLES, REF_NPERSEG)
     sb = dev.tdoa_slot_bytes(REF_SLICE)
-    from gpsjam.streams import stream_beside
-    side_dev = gpsjam.Device(dev.index)
-    main = torch.cuda.current_stream()
-    side = stream_beside([(dev, main)])        # a second stream on a hardware queue of its own (gpsjam/streams.py)
-    side_dev.set_stream(side.cuda_stream)
-    power = [torch.empty(nch, dtype=torch.float32, device="cuda") for _ in range(3)]
-    stats = [torch.empty(3, dtype=torch.float32, device="cuda") for _ in range(3)]
-    amp = [torch.zeros(4, dtype=torch.int64, device="cuda") for _ in range(3)]
-    onset = [torch.zeros(4, dtype=torch.int64, device="cuda") for _ in range(3)]
-    psd = [torch.empty((rows, REF_NPERSEG), dtype=torch.float32, device="cuda") for _ in range(3)]
-    slots = torch.zeros((3, sb), dtype=torch.uint8, device="cuda")
-    lags = torch.zeros(3, dtype=torch.int32, device="cuda")
-    peaks, margins = torch.zeros(3, dtype=torch.float32, device="cuda"), torch.zeros(3, dtype=torch.float32, device="cuda")
-    dev.reserve(dev.welch_workspace(nb, CHUNK_SAMPLES, REF_NPERSEG))
-    side_dev.reserve(max(side_dev.xcorr_workspace(3, REF_SLICE, 3), nb // 48 + (1 << 20)))
-    ev_go, ev_side = torch.cuda.Event(), torch.cuda.Event()
-
-    def step():
-        ev_go.record(main)
-        side.wait_event(ev_go)
-        for a in range(3):
-            side_dev.stream_scan_dev(caps[a], nb, 65536, power[a], 0.0, amp[a], 200000, 1000, 50.0, onset[a])
-            side_dev.power_threshold_dev(power[a], nch, stats[a])
-            side_dev.tdoa_slot_dev(caps[a], nb, onset[a], REF_SLICE, slots[a])
-            dev.welch_dev(caps[a], nb, CHUNK_SAMPLES, REF_NPERSEG, 2.048e6, psd[a])
-        side_dev.xcorr_slots_dev(slots, sb, 3, REF_SLICE, pairs, lags, peaks, margins)
-        ev_side.record(side)
-        main.wait_event(ev_side)
+    from gpsjam.local import LocalAntennas
+    # every antenna of the deployment on this GPU: K2 on the main stream, each capture's scan -> threshold -> slot chain on
+    # a side stream of its own, K5 over the three slots, one result vector per antenna (gpsjam/local.py)
+    st = LocalAntennas(dev, caps, nperseg=REF_NPERSEG, chunk_samples=CHUNK_SAMPLES, slice_samples=REF_SLICE, rssi_threshold=0.0,
+                       graph=graph)
+    step = st.step
+    power, stats, amp, onset, psd, lags = st.power, st.stats, st.amp, st.onset, st.psd, st.lags
 
     for _ in range(5):
         step()
@@ -1029,7 +1009,7 @@ def deployment(np, torch, gpsjam, dev, StreamSpec, reps=20):
                 os.remove(pth)
             except OSError:
                 pass
-    side_dev.close()
+    st.close()
     total = 3 * ns
     line = {"captures": 3, "capture_bytes": nb, "nperseg": REF_NPERSEG, "xcorr_slice": REF_SLICE, "pairs": [list(p) for p in pairs],
             "resident_step_ms": resident_ms, "resident_step_latency_ms": min(one),

@@ -388,39 +388,63 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
 }
 
 // one bin per thread: used when the caller's output arrays are not 16-byte aligned
+// Sum of a chunk's partial spectra, in ONE fixed order whatever the launch shape and whoever computes it (a part of a
+// split capture sums the same rows the same way): four partial sums over the rows i = r, r + 4, r + 8, ... (ascending),
+// r = 0..3, combined as (s0 + s1) + (s2 + s3).  Round 4: until then every thread added its column's rows one after
+// the other -- 23 rows for the 1-GiB capture (19 us), but 300 for a 10-s capture, whose few chunks are cut into many
+// runs to fill the chip: 80-108 us of dependent loads per launch, three times the K2 launch it finishes
+// (profiles/r04_deployment_timeline.txt).  Now a workgroup is 64 columns x 4 row lanes (one wave per row lane: coalesced
+// rows), eight loads in flight per thread.
 __global__ __launch_bounds__(256) void welch_finalize_scalar_kernel(const float* __restrict__ partial, int n,
                                                                     unsigned per_chunk, unsigned nchunks, float scale_full,
                                                                     float scale_last, int shift, float* __restrict__ psd,
                                                                     float* __restrict__ psd_db) {
+    __shared__ float sh[4][64];
     const unsigned c = blockIdx.y;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const float* p = partial + (size_t)c * per_chunk * n + k;
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + cx;
     float s = 0.f;
-    for (unsigned i = 0; i < per_chunk; ++i) s += p[(size_t)i * n];
-    const float val = s * ((c + 1 == nchunks) ? scale_last : scale_full);
+    if (k < n) {
+        const float* p = partial + (size_t)c * per_chunk * n + k;
+#pragma unroll 8
+        for (unsigned i = ry; i < per_chunk; i += 4) s += p[(size_t)i * n];
+    }
+    sh[ry][cx] = s;
+    __syncthreads();
+    if (ry != 0 || k >= n) return;
+    const float t = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
+    const float val = t * ((c + 1 == nchunks) ? scale_last : scale_full);
     const int o = shift ? ((k + n / 2) & (n - 1)) : k;
     psd[(size_t)c * n + o] = val;
     if (psd_db) psd_db[(size_t)c * n + o] = 10.0f * log10f(val + 1e-15f);
 }
 
-// four consecutive bins per thread: 16-byte loads of the partial rows, 16-byte stores
+// four consecutive bins per thread: 16-byte loads of the partial rows, 16-byte stores; the same order of summation
 __global__ __launch_bounds__(256) void welch_finalize_kernel(const float* __restrict__ partial, int n, unsigned per_chunk,
                                                              unsigned nchunks, float scale_full, float scale_last,
                                                              int shift, float* __restrict__ psd,
                                                              float* __restrict__ psd_db) {
+    __shared__ float4 sh[4][64];
     const unsigned c = blockIdx.y;
-    const int k = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
-    if (k >= n) return;
-    const float4* p = reinterpret_cast<const float4*>(partial + (size_t)c * per_chunk * n + k);
-    const size_t stride = (size_t)n / 4;
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int k = 4 * (blockIdx.x * 64 + cx);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (unsigned i = 0; i < per_chunk; ++i) {   // fixed order: bit-identical from run to run
-        const float4 q = p[(size_t)i * stride];
-        s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+    if (k < n) {
+        const float4* p = reinterpret_cast<const float4*>(partial + (size_t)c * per_chunk * n + k);
+        const size_t stride = (size_t)n / 4;
+#pragma unroll 8
+        for (unsigned i = ry; i < per_chunk; i += 4) {
+            const float4 q = p[(size_t)i * stride];
+            s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+        }
     }
+    sh[ry][cx] = s;
+    __syncthreads();
+    if (ry != 0 || k >= n) return;
+    const float4 a0 = sh[0][cx], a1 = sh[1][cx], a2 = sh[2][cx], a3 = sh[3][cx];
     const float sc = (c + 1 == nchunks) ? scale_last : scale_full;
-    const float4 val = make_float4(s.x * sc, s.y * sc, s.z * sc, s.w * sc);
+    const float4 val = make_float4(((a0.x + a1.x) + (a2.x + a3.x)) * sc, ((a0.y + a1.y) + (a2.y + a3.y)) * sc,
+                                   ((a0.z + a1.z) + (a2.z + a3.z)) * sc, ((a0.w + a1.w) + (a2.w + a3.w)) * sc);
     const int o = shift ? ((k + n / 2) & (n - 1)) : k;   // n/2 is a multiple of 4: the group stays contiguous
     *reinterpret_cast<float4*>(psd + (size_t)c * n + o) = val;
     if (psd_db)
@@ -550,11 +574,11 @@ int welch_end(gj_ctx* ctx, const WelchJob& job, int flags, float* d_psd, float* 
     float* partial = job.partial;
     const bool aligned = ((reinterpret_cast<uintptr_t>(d_psd) | reinterpret_cast<uintptr_t>(d_psd_db)) & 15) == 0;
     if (aligned)
-        hipLaunchKernelGGL(welch_finalize_kernel, dim3((nperseg / 4 + 255) / 256, pl.g.nchunks), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(welch_finalize_kernel, dim3((nperseg / 4 + 63) / 64, pl.g.nchunks), dim3(256), 0, ctx->stream,
                            partial, nperseg, pl.g.splits * (unsigned)pl.batch, pl.g.nchunks, (float)pl.scale_full,
                            (float)pl.scale_last, (flags & GJ_WELCH_SHIFT) ? 1 : 0, d_psd, d_psd_db);
     else
-        hipLaunchKernelGGL(welch_finalize_scalar_kernel, dim3((nperseg + 255) / 256, pl.g.nchunks), dim3(256), 0,
+        hipLaunchKernelGGL(welch_finalize_scalar_kernel, dim3((nperseg + 63) / 64, pl.g.nchunks), dim3(256), 0,
                            ctx->stream, partial, nperseg, pl.g.splits * (unsigned)pl.batch, pl.g.nchunks,
                            (float)pl.scale_full, (float)pl.scale_last, (flags & GJ_WELCH_SHIFT) ? 1 : 0, d_psd, d_psd_db);
     GJ_LAUNCH_CHECK(ctx);
