@@ -400,37 +400,20 @@ __global__ __launch_bounds__(kBlockThreads, N == 2048 ? 2 : 3) void acq_inv_all_
     // every index outside the +-2-chip zone around the peak counts towards the mean: nsamp - (4 nsampchip + 1) of them,
     // wrapped or not (launch_acq_search checks 4 nsampchip < nsamp)
     const int cnt = P.nsamp - 4 * nsampchip - 1;
-    // Optional (GJ_ACQ_AHEAD > 0): part of a step's data spectrum and the running maximum of its (PRN, step) fetched ONE
-    // STEP AHEAD, right behind the previous step's accumulation, so that the loads travel while the row's maximum is
-    // reduced and exchanged.  Measured, see below; the shipped form reads everything at the step's start.
-#ifndef GJ_ACQ_AHEAD
-#define GJ_ACQ_AHEAD 0    // loads of the data spectrum held one step ahead, of 16 (A/B knob, tools/ab_build.sh).  0 ships: the kernel sits
-                          // at 168 VGPRs = three workgroups per CU, and every pair held ahead spills (2: 8 B ... 16: 140 B of scratch);
-                          // 4-6 ahead gained 7-9 % with the old five-operation product and LOSE 15 % with the present one
-                          // (profiles/r04_ab_acq.txt)
-#endif
-    constexpr int AH = GJ_ACQ_AHEAD;
-    cf xa[AH > 0 ? AH : 1];
-    unsigned long long seen = 0ull;
-    auto fetch = [&](int step) {
-        const cf* x = xspec + ((size_t)step * P.n_freq + (live ? f : 0)) * N;
-#pragma unroll
-        for (int s = 0; s < AH; ++s) xa[s] = x[jl0 + TF * s];
-        // read past the L1 by the transform's first thread; possibly stale by the time it is used -- gmax only grows
-        if (AH > 0 && jl == 0 && live) seen = __hip_atomic_load(&gmax[(size_t)p * P.intg + step], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    fetch(0);
     for (int step = 0; step < P.intg; ++step) {
         c2 v[16];
-        if (AH == 0 && jl == 0 && live) seen = __hip_atomic_load(&gmax[(size_t)p * P.intg + step], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long seen_now = seen;
-        const cf* xnow = xspec + ((size_t)step * P.n_freq + (live ? f : 0)) * N;
+        // the running maximum of this (PRN, step) as it stands now, read past the L1 by the transform's first thread; used
+        // after the transform, so its latency hides behind the spectra's loads.  Possibly stale by then -- gmax only grows
+        unsigned long long seen_now = 0ull;
+        if (jl == 0 && live) seen_now = __hip_atomic_load(&gmax[(size_t)p * P.intg + step], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const cf* x = xspec + ((size_t)step * P.n_freq + (live ? f : 0)) * N;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const cf a = s < AH ? xa[s] : xnow[jl0 + TF * s], q = c[jl0 + TF * s];
+            const cf a = x[jl0 + TF * s], q = c[jl0 + TF * s];
             // conj(X) * (-C / m) as stored = cpxconv's product, as in acq_inv_kernel.  Plain arithmetic on purpose: the
-            // packed form (v_pk_mul + v_pk_fma per point, alone or two points interleaved) measured 18-19 % SLOWER here
-            // (profiles/r04_ab_acq.txt) -- the loads arrive one by one and the scalar form consumes them as they come
+            // packed form (v_pk_mul + v_pk_fma per point, alone or two points interleaved) measured 18-19 % SLOWER here,
+            // and so did every attempt to hold part of the next step's spectrum in registers or the running power in LDS
+            // (profiles/r04_ab_acq.txt): the kernel sits at 168 VGPRs with three workgroups per CU and nothing to spare
             v[s] = make_c2(a.x * q.x - a.y * q.y, a.x * q.y + a.y * q.x);
         }
         acq_transform<N>(v, lds, tid, b * lds_span(N), jl, tw);
@@ -440,7 +423,6 @@ __global__ __launch_bounds__(kBlockThreads, N == 2048 ? 2 : 3) void acq_inv_all_
             acc[s] += (double)(v[s].x * v[s].x + v[s].y * v[s].y);   // 1/m^2 rides on the code spectrum (acq_code_body)
             mine.v = __builtin_fmax(mine.v, acc[s]);
         }
-        if (step + 1 < P.intg) fetch(step + 1);
 #ifdef GJ_ACQ_ABLATE_CHECK   // timing only (tools/ab_build.sh): no peak bookkeeping at all
         if (step + 1 == P.intg && live && jl == 0) rows[((size_t)p * P.intg + step) * P.n_freq + f].maxv = mine.v;
         continue;

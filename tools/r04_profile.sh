@@ -17,6 +17,9 @@ timeout -k 10 300 python3 bench.py --split --emulate-world 8 --force-exchange --
 timeout -k 10 300 python3 bench.py --split --emulate-world 4 --force-exchange --steps 20 --warmup 5 --precondition 10 > $OUT/split_emulated4.json 2> $OUT/split_emulated4.err; echo "split emu4 rc=$?"
 timeout -k 10 300 python3 bench.py --gpus 2 --split --backend gloo --share-gpu --steps 10 --warmup 2 --precondition 10 > $OUT/split_n2_share.json 2> $OUT/split_n2.err; echo "split n2 rc=$?"
 timeout -k 10 300 python3 bench.py --gpus 2 --backend gloo --share-gpu --steps 10 --warmup 2 --precondition 10 --no-cpu-baseline > $OUT/weak_n2_share.json 2> $OUT/weak_n2.err; echo "weak n2 rc=$?"
+for r in 1 2 7; do timeout -k 10 300 python3 bench.py --split --emulate-world 8 --emulate-rank $r --force-exchange --steps 20 --warmup 5 --precondition 10 > $OUT/split_emulated8_rank$r.json 2> $OUT/split_emulated8_rank$r.err; echo "split emu8 rank $r rc=$?"; done
+timeout -k 10 200 python3 tools/deployment_probe.py > $OUT/deployment_graph.txt 2>/dev/null; timeout -k 10 200 python3 tools/deployment_probe.py --eager > $OUT/deployment_eager.txt 2>/dev/null; echo "deployment rc=$?"
+bash tools/pmc_welch.sh $TAG/pmc_welch4096 4096 > $OUT/pmc_welch4096.log 2>&1; echo "pmc welch4096 rc=$?"
 bash tools/pmc_welch.sh $TAG/pmc_welch1024 1024 > $OUT/pmc_welch1024.log 2>&1; echo "pmc welch1024 rc=$?"
 bash tools/pmc_secondary.sh $TAG/pmc_sec "acq fscan" > $OUT/pmc_sec.log 2>&1; echo "pmc sec rc=$?"
 cd /tmp && export TMPDIR=/tmp
