@@ -822,7 +822,7 @@ def pmc_summary(nbytes):
     so the figures are the recorded ones, offered only for the capture size they were measured on, and
     flagged when the kernel sources have changed since."""
     out = {"traffic": None, "valu_insts": None, "source": "no PMC summary found", "matches_build": None}
-    for rel in ("profiles/r03_pmc_welch/summary.json", "profiles/r02_pmc_welch/summary.json"):
+    for rel in ("profiles/r04_pmc_welch/summary.json", "profiles/r03_pmc_welch/summary.json", "profiles/r02_pmc_welch/summary.json"):
         try:
             with open(os.path.join(REPO, rel)) as f:
                 js = json.load(f)
