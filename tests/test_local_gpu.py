@@ -79,3 +79,42 @@ def test_local_antennas_from_files(dev, tmp_path):
     finally:
         torch.cuda.set_stream(torch.cuda.default_stream())
         dev.set_stream(None, external=False)
+
+
+def test_local_antennas_edge_shapes(dev):
+    """One antenna (no pairs), five antennas (more captures than side streams: chains share streams), and a capture too
+    short for K4's noise span next to ordinary ones (its onset is -1, its slot invalid, its pairs GJ_LAG_INVALID as in
+    the other arrangements; skrypty/triangulateTDOA.py:67-77 aborts there)."""
+    import torch
+    from gpsjam import local, sharded
+    from gpsjam.synth import StreamSpec, generate
+    n = 600_000
+    mk = lambda a, d, m=n: generate(StreamSpec(seed=71, antenna=a, delay=d, jam_start=300_000, jam_end=1 << 40, jam_sigma=55.0), m)   # noqa: E731
+    kw = dict(chunk_samples=131072, nperseg=1024, slice_samples=50000)
+    work = torch.cuda.Stream()
+    torch.cuda.set_stream(work)
+    dev.set_stream(work.cuda_stream)
+    try:
+        with local.LocalAntennas(dev, [torch.from_numpy(mk(0, 0)).cuda()], **kw) as one:
+            res, td = one.step().unpack()
+            res2, _ = one.step().unpack()
+            assert len(res) == 1 and td.pairs == [] and res[0].onset > 0 and res2[0].onset == res[0].onset
+        delays = (0, 3, -2, 5, 1)
+        with local.LocalAntennas(dev, [torch.from_numpy(mk(a, d)).cuda() for a, d in enumerate(delays)], **kw) as five:
+            assert len(five._sides) == 3 and len(five.pairs) == 10
+            for _ in range(3):
+                res, td = five.step().unpack()
+            for (i, j), lag in zip(td.pairs, td.lags):
+                assert lag + res[j].onset - res[i].onset == delays[j] - delays[i], (i, j, lag)
+        short = mk(1, 0, 150_000)                               # shorter than noise_samples + window: no onset
+        with local.LocalAntennas(dev, [torch.from_numpy(mk(0, 0)).cuda(), torch.from_numpy(short).cuda(),
+                                       torch.from_numpy(mk(2, 4)).cuda()], **kw) as mixed:
+            for _ in range(3):
+                res, td = mixed.step().unpack()
+            assert res[1].onset == -1 and res[0].onset > 0 and res[2].onset > 0
+            assert td.lag(0, 1) == sharded.LAG_INVALID and td.lag(1, 2) == sharded.LAG_INVALID
+            assert td.lag(0, 2) + res[2].onset - res[0].onset == 4
+            assert res[1].power_map.size == 5 and np.isfinite(res[1].baseline)
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        dev.set_stream(None, external=False)
