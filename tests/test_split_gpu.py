@@ -381,3 +381,37 @@ def test_combine_plan_is_validated_on_the_host(dev):
         with pytest.raises(gpsjam.GpsJamError):
             dev.combine_plan(copies, caps_, rows_bytes, arena, nper, None, None, None, None)
     arena.free()
+
+
+@pytest.mark.parametrize("seed,world", [(1, 2), (2, 3), (3, 5), (4, 8), (5, 6), (6, 7)])
+def test_emulated_world_random_ragged_captures(dev, seed, world):
+    """Random numbers of antennas (1-4), random ragged lengths (odd byte counts included), a burst somewhere or nowhere:
+    the combine over all emulated ranks' part vectors is byte for byte the single-GPU run."""
+    import torch
+    from gpsjam import split
+    from gpsjam.synth import StreamSpec, generate
+    rng = np.random.default_rng(1000 + seed)
+    n_ant = int(rng.integers(1, 5))
+    caps = []
+    for a in range(n_ant):
+        n = int(rng.integers(300_000, 1_400_000))
+        burst = int(rng.integers(220_000, n)) if rng.random() < 0.8 else (1 << 40)
+        raw = generate(StreamSpec(seed=200 + seed, antenna=a, delay=int(rng.integers(-6, 7)), jam_start=burst, jam_end=1 << 41,
+                                  jam_sigma=float(rng.uniform(45, 70))), n)
+        caps.append(raw[:raw.size - int(rng.integers(0, 3))])                 # sometimes an odd trailing byte
+    kw = dict(chunk_samples=65536, nperseg=int(rng.choice([256, 1024, 4096])), slice_samples=int(rng.choice([4096, 50000])),
+              rssi_threshold=float(rng.choice([0.0, 0.05])))
+    work = torch.cuda.Stream()
+    torch.cuda.set_stream(work)
+    dev.set_stream(work.cuda_stream)
+    try:
+        want = _single_gpu(dev, caps, kw)
+        st = split.emulated_rank0(dev, [_nbytes(c) for c in caps], lambda p, b0, b1: _device_range(dev, caps[p.antenna], b0, b1),
+                                  lambda a, n: _device_range(dev, caps[a], 0, n), world, **kw)
+        for step in range(3):
+            res, td = st.step().unpack()
+            _assert_identical(f"seed {seed} world {world} step {step}", _collect(res, td, [p.cpu().numpy().copy() for p in st.last_psd]), want)
+        st.close()
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        dev.set_stream(None, external=False)
