@@ -362,9 +362,10 @@ class Device:
         ``last_kernel_ms`` says so."""
         if not isinstance(raw, Capture) or not raw.results:
             return None
-        if raw.results_unpack is not None and raw.dev is self and raw.results_unpack != self.get_unpack():
-            raw.results.clear()
-            return None
+        if raw.results_unpack is not None and raw.results_unpack != self.get_unpack():
+            if raw.dev is self:                              # this context's convention has changed: they are stale for good
+                raw.results.clear()
+            return None                                      # (another context with another convention: just not served)
         hit = raw.results.get(key)
         if hit is not None:
             self.last_kernel_ms = 0.0

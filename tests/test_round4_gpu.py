@@ -172,3 +172,42 @@ def test_stream_beside_finds_a_stream_that_overlaps(dev):
             dev.debug_busy_dev(1000.0)
     finally:
         dev.set_stream(None, external=False)
+
+
+# ----------------------------------------------------------------------------- the ingest follows a stream switch
+def test_ingest_follows_a_stream_switch_made_mid_call(dev):
+    """Another thread may call gj_set_stream while gj_ingest_* is between two of its lock sections (AntennaStream and
+    SplitStreams do at construction).  Emulated exactly at the worst place: the wait hook at the head of the staged copy --
+    after the ingest has read the context's stream and queued its first work on it, before a single piece has landed --
+    points the context at ANOTHER stream.  The kernels the ingest launches from then on run on the new stream; they
+    must still wait for the pieces (and for what was queued on the old stream): same results as an undisturbed ingest."""
+    import torch
+    n = 24 << 20                                            # samples: 48 MiB, a dozen pieces
+    raw = generate(StreamSpec(seed=93, jam_start=9_000_000, jam_end=1 << 40, jam_sigma=55.0), n)
+    with dev.ingest(raw, rssi_threshold=0.0, welch=(2048000, 1024)) as cap:
+        want = (dev.chunk_power(cap).copy(), dev.welch(cap, nperseg=1024, want_db=False)[0].copy(), dev.amp_stats(cap, 0.0),
+                dev.onset(cap))
+    other = torch.cuda.Stream()
+    switched = []
+
+    @C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+    def hook(_arg, site):
+        if site == 3 and not switched:
+            switched.append(True)
+            dev.set_stream(other.cuda_stream)               # "another thread": gj_set_stream between two lock sections
+
+    dev._check(dev._lib.gj_debug_set_wait_hook(dev._ctx, C.cast(hook, C.c_void_p), None))
+    try:
+        for _ in range(3):                                  # a race that is lost shows up as garbage in early chunks
+            switched.clear()
+            dev.set_stream(None, external=False)
+            with dev.ingest(raw, rssi_threshold=0.0, welch=(2048000, 1024)) as cap:
+                assert switched, "the hook never fired: the ingest did not take the staged path"
+                np.testing.assert_array_equal(dev.chunk_power(cap), want[0])
+                assert dev.welch(cap, nperseg=1024, want_db=False)[0].tobytes() == want[1].tobytes()
+                got_amp, got_on = dev.amp_stats(cap, 0.0), dev.onset(cap)
+                assert (got_amp.sum, got_amp.count, got_amp.first_index) == (want[2].sum, want[2].count, want[2].first_index)
+                assert bytes(got_on) == bytes(want[3])
+    finally:
+        dev._check(dev._lib.gj_debug_set_wait_hook(dev._ctx, None, None))
+        dev.set_stream(None, external=False)
