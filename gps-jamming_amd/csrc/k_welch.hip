@@ -118,6 +118,22 @@ struct WelchBins {   // (thread, slot) that ends up holding bin k
 // while slower threads of the workgroup still gather from the other, so ONE barrier per
 // exchange (between scatter and gather) is enough.
 // `after_scatter0()` runs right behind the first scatter (see welch_passes_x4096)
+// The exchange barrier.  For N <= 1024 a transform's N / 16 threads lie inside ONE wave, whose LDS instructions execute
+// in issue order: the writes of a scatter are seen by the gather behind them without any workgroup barrier.  What is
+// needed is only that the COMPILER keeps the two in order (per lane they touch different addresses): a wavefront-scope
+// fence.  The four (or more) transforms a workgroup works on then run independently instead of waiting for each other
+// four times per segment (round 4: welch_kernel<1024> is the reference's own FFT size, skrypty/widmo_plot.py:10).
+template <int N>
+__device__ __forceinline__ void welch_exchange_sync() {
+    if constexpr (N / 16 <= 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 template <int N, int PASS, typename Mid>
 __device__ __forceinline__ void welch_passes(c2 (&v)[16], cf* lds0, cf* lds1, unsigned it, int base, int jl,
                                              const c2 (&tw)[3][15], const InnerTw& ktw, Mid&& after_scatter0) {
@@ -129,9 +145,9 @@ __device__ __forceinline__ void welch_passes(c2 (&v)[16], cf* lds0, cf* lds1, un
         cf* lds = (WelchCfg<N>::dbuf && second) ? lds1 : lds0;
         lds_scatter<N, PASS>(v, lds, base, jl);
         if constexpr (PASS == 0) after_scatter0();
-        __syncthreads();
+        welch_exchange_sync<N>();
         lds_gather<N>(v, lds, base, jl);
-        if (!WelchCfg<N>::dbuf) __syncthreads();
+        if (!WelchCfg<N>::dbuf) welch_exchange_sync<N>();
         welch_passes<N, PASS + 1>(v, lds0, lds1, it, base, jl, tw, ktw, after_scatter0);
     }
 }
