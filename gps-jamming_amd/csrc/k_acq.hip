@@ -400,16 +400,28 @@ __global__ __launch_bounds__(kBlockThreads, N == 2048 ? 2 : 3) void acq_inv_all_
     // every index outside the +-2-chip zone around the peak counts towards the mean: nsamp - (4 nsampchip + 1) of them,
     // wrapped or not (launch_acq_search checks 4 nsampchip < nsamp)
     const int cnt = P.nsamp - 4 * nsampchip - 1;
+    // (`seen` lives across the steps on purpose: declared inside the loop the same code compiles to a kernel that is 11 %
+    // slower -- 0.196 against 0.176 ms per search, profiles/r04_ab_acq.txt; the register allocation decides, not the idea)
+    unsigned long long seen = 0ull;
     for (int step = 0; step < P.intg; ++step) {
         c2 v[16];
         // the running maximum of this (PRN, step) as it stands now, read past the L1 by the transform's first thread; used
         // after the transform, so its latency hides behind the spectra's loads.  Possibly stale by then -- gmax only grows
-        unsigned long long seen_now = 0ull;
-        if (jl == 0 && live) seen_now = __hip_atomic_load(&gmax[(size_t)p * P.intg + step], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (jl == 0 && live) seen = __hip_atomic_load(&gmax[(size_t)p * P.intg + step], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long seen_now = seen;
         const cf* x = xspec + ((size_t)step * P.n_freq + (live ? f : 0)) * N;
+        // ALL 32 loads of the step first, the products behind them: left to itself the scheduler sometimes issues the loads
+        // two at a time with a full wait in between (seen in the ISA of an otherwise identical source: 0.196 against
+        // 0.176 ms per search).  The scheduling barrier pins the order; the products then consume the loads as they land.
+        cf xa[16], qa[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) xa[s] = x[jl0 + TF * s];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) qa[s] = c[jl0 + TF * s];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const cf a = x[jl0 + TF * s], q = c[jl0 + TF * s];
+            const cf a = xa[s], q = qa[s];
             // conj(X) * (-C / m) as stored = cpxconv's product, as in acq_inv_kernel.  Plain arithmetic on purpose: the
             // packed form (v_pk_mul + v_pk_fma per point, alone or two points interleaved) measured 18-19 % SLOWER here,
             // and so did every attempt to hold part of the next step's spectrum in registers or the running power in LDS
