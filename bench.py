@@ -399,7 +399,7 @@ def main():
                 "bound": "hbm", "algorithmic_bytes_per_launch": k5_bytes, "avg_launch_ms": k5_ms,
                 "achieved": (k5_bytes / 1e9) / (k5_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (k5_bytes / 1e9) / (k5_ms / 1e3) / HBM_PEAK_GBS,
-                **family_traffic("profiles/r03_pmc_xcorr/summary.json", nbytes),
+                **family_traffic("profiles/r04_pmc_xcorr/summary.json", nbytes),
                 "note": "PMC: about half of the four-step floor reaches HBM -- the spectra are written through "
                         "(50 MB) and about a third of the reads miss L2 / Infinity Cache (56 MB)"}
         if acq_ms is not None:

@@ -55,19 +55,35 @@ __device__ __forceinline__ c2 twiddle_big(unsigned long long m, unsigned long lo
     return make_c2(c, s);
 }
 
+// One transform.  The twiddles of pass P + 1 are loaded right behind the scatter of pass P -- the points are in LDS, their
+// registers are free, and the fifteen loads are in flight across the exchange's barriers.  Round 4: until then every pass
+// loaded its twiddles right in front of its butterflies and the compiler issued them one at a time, each with a full
+// wait (90 serialised L2 round trips per workgroup in xc_rows_pair_kernel: visible as L[0]L[0]L[0]... in the ISA).
+// With many workgroups in flight other waves covered that; the reference's own slice size (50 000 samples, FFT length
+// 131 072: 96 row workgroups) did not.  Same arithmetic, same bits.
 template <int N, int PASS>
-__device__ __forceinline__ void xc_passes(c2 (&v)[16], cf* lds, int base, int jl, const cf* twtab) {
+__device__ __forceinline__ void xc_passes_tw(c2 (&v)[16], cf* lds, int base, int jl, const cf* twtab, const c2 (&tw)[15]) {
     constexpr int NP = fft_npass(N);
-    c2 tw[15];
-    if constexpr (PASS > 0) load_twiddles<N, PASS>(tw, twtab, jl);
     fft_pass<N, PASS>(v, tw, inner_twiddles());
     if constexpr (PASS + 1 < NP) {
         lds_scatter<N, PASS>(v, lds, base, jl);
+        c2 nxt[15];
+        load_twiddles<N, PASS + 1>(nxt, twtab, jl);
+        __builtin_amdgcn_sched_barrier(0);   // all fifteen issued here, not drip-fed behind the gather
         __syncthreads();
         lds_gather<N>(v, lds, base, jl);
         __syncthreads();
-        xc_passes<N, PASS + 1>(v, lds, base, jl, twtab);
+        xc_passes_tw<N, PASS + 1>(v, lds, base, jl, twtab, nxt);
     }
+}
+
+template <int N, int PASS>
+__device__ __forceinline__ void xc_passes(c2 (&v)[16], cf* lds, int base, int jl, const cf* twtab) {
+    static_assert(PASS == 0, "transforms start at pass 0 (which has no twiddles)");
+    c2 none[15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) none[k] = make_c2(1.f, 0.f);
+    xc_passes_tw<N, 0>(v, lds, base, jl, twtab, none);
 }
 
 // start word of antenna a: an element of the caller's start array, or the flag word of a TDOA slot
