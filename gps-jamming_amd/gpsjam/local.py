@@ -162,9 +162,13 @@ class LocalAntennas:
         return StepResults(self._final[k], self._done[k], self.n_ant)
 
     def close(self):
+        self._graphs = None                              # the captured graphs name this object's buffers
         for sdev, _ in self._sides:
             sdev.close()
         self._sides = []
+        for b in getattr(self, "_file_buffers", []):     # from_files: the captures were uploaded for this object
+            b.free()
+        self._file_buffers = []
 
     def __enter__(self):
         return self
