@@ -145,7 +145,8 @@ int gj_create(int device_id, gj_ctx** out) {
     ctx->stream = ctx->own_stream;
     if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) return bail(GJ_ERR_HIP);
     // constant tables: W_4096^m, periodic Hann windows
-    const size_t bytes = kTwiddleTable * sizeof(cf) + kWindowFloats * sizeof(float) + 256;
+    const size_t tables = align_up(kTwiddleTable * sizeof(cf) + kWindowFloats * sizeof(float) + 256, 256);
+    const size_t bytes = tables + kSyncWords * sizeof(unsigned);   // the arrival counters start out (and stay) zero
     void* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) return bail(GJ_ERR_NOMEM);
     ctx->d_twiddle = static_cast<cf*>(p);
@@ -159,6 +160,7 @@ int gj_create(int device_id, gj_ctx** out) {
     for (int nn = 16; nn <= 4096; nn *= 2)
         for (int k = 0; k < nn; ++k) win[nn - 16 + k] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * (double)k / (double)nn));
     if (hipMemcpy(p, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return bail(GJ_ERR_HIP);
+    ctx->d_sync = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(p) + tables);
     *out = ctx;
     return GJ_OK;
 }
@@ -192,24 +194,33 @@ int gj_debug_set_wait_hook(gj_ctx* ctx, void (*hook)(void*, int), void* arg) {
     return GJ_OK;
 }
 
+int gj_debug_inject(gj_ctx* ctx, int what, int count) {
+    if (!ctx) return GJ_ERR_INVALID;
+    if (what != GJ_INJECT_OWNER_ALIVE || count < 0) return fail(ctx, GJ_ERR_INVALID, "unknown injection %d (count %d)", what, count);
+    Guard g(ctx);
+    ctx->inject_owner_alive = count;
+    return GJ_OK;
+}
+
 // one wave that spins on the constant-rate (100 MHz) real-time counter: keeps the context's stream -- and the hardware
 // queue behind it -- busy for a known time without occupying the chip
-__global__ void debug_busy_kernel(unsigned long long ticks) {
+__global__ void probe_busy_kernel(unsigned long long ticks) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
-int gj_debug_busy_dev(gj_ctx* ctx, float milliseconds) {
+int gj_probe_busy_dev(gj_ctx* ctx, float milliseconds) {
     if (!ctx) return GJ_ERR_INVALID;
     if (!(milliseconds >= 0.f) || milliseconds > 100.f) return fail(ctx, GJ_ERR_INVALID, "busy time %g ms (0..100)", (double)milliseconds);
     Guard g(ctx);
-    hipLaunchKernelGGL(debug_busy_kernel, dim3(1), dim3(64), 0, ctx->stream, (unsigned long long)((double)milliseconds * 1e5));
+    hipLaunchKernelGGL(probe_busy_kernel, dim3(1), dim3(64), 0, ctx->stream, (unsigned long long)((double)milliseconds * 1e5));
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
 }
 
 int gj_debug_counters(gj_ctx* ctx, int* lanes, int* lanes_busy, int* lanes_reclaimed, int* owner_deaths) {
     if (!ctx) return GJ_ERR_INVALID;
+    (void)lane_sweep(ctx);        // lanes of callers that have ended come back here as well as at a check-out
     Guard g(ctx);
     wait_hook(ctx, kUnderLock);   // the one hook site that runs WITH the lock held (dead-owner recovery test)
     int busy = 0;

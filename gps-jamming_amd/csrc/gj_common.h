@@ -21,10 +21,19 @@ struct gj_comm;
 // lock, then stages, waits and copies with NO lock held; two host threads therefore never share a buffer, and a
 // caller that is killed inside a wait (the GUI stops an analysis with QThread.terminate(),
 // GpsJammerApp/app/ui_mainwindow.py:818-826) leaves nothing locked: its lane is taken back once its thread is gone.
+//
+// "Gone" is decided by the kernel, not sampled: `owner` is a robust mutex the calling thread holds from check-out to
+// check-in.  When a thread ends, the kernel walks its robust list and marks every mutex it still held "owner died"
+// BEFORE it clears the thread's tid word (the thing pthread_join waits for), so from the moment a dead caller can be
+// joined a trylock on its lane answers EOWNERDEAD -- no window in which a dying thread still looks alive, and no tid
+// that a later thread could inherit (round 4's tgkill probe had both defects: GPUTEST_r04 went red on the first).
+// Every check-out (and gj_debug_counters) sweeps ALL busy lanes this way, whether or not a free lane exists.
 struct gj_lane {
     static constexpr int kPinBufs = 32;   // pinned bounce buffers (2 per fill thread)
     bool busy = false;
-    int owner_tid = 0;                    // kernel thread id of the caller that holds the lane
+    int owner_tid = 0;                    // kernel thread id of the caller that holds the lane (diagnostics only)
+    pthread_mutex_t owner;                // robust; held by the calling thread for the life of the check-out
+    bool owner_ready = false;
     unsigned char* stage = nullptr;       // grow-only device staging: [input][results]
     size_t stage_bytes = 0;
     void* pin[kPinBufs] = {};
@@ -60,12 +69,17 @@ struct gj_ctx {
     bool mu_ready = false;
     int owner_deaths = 0;
     gj::cf* d_twiddle = nullptr;   // W_4096^m
+    // Arrival counters of the kernels whose workgroups hand results to the LAST one of them to finish (scan tail: word 0;
+    // K5: one word per pair from word kSyncXcorr on).  Zero at creation; every kernel that uses one leaves it at zero
+    // (its last arriver resets it), so no launch needs a memset in front of it.  Lives behind the constant tables.
+    unsigned* d_sync = nullptr;
     unsigned char* ws = nullptr;   // grow-only workspace for partial results
     size_t ws_bytes = 0;
     std::vector<gj_retired> retired;
     std::vector<gj_lane*> lanes;
     std::vector<gj_comm*> comms;   // communicators created on this context (gj_destroy takes them down)
     int lanes_reclaimed = 0;
+    int inject_owner_alive = 0;    // gj_debug_inject: the next probes of a busy lane skip the owner check ("alive")
     // unpack convention (gj_set_unpack): sample = (u8 - offset) * scale; off2 = 2 * offset is an integer
     int off2 = 255;
     double scale = 1.0 / 127.5;
@@ -75,6 +89,10 @@ struct gj_ctx {
 };
 
 namespace gj {
+
+constexpr int kSyncWords = 1024;    // 4 KiB
+constexpr int kSyncTail = 0;        // scan_tail_kernel
+constexpr int kSyncXcorr = 64;      // xc_cols_kernel<.., 1>: + pair index
 
 // what the kernels need of the unpack convention: v = 2 u - off2 (exact integer), |sample| = |v| * half_scale
 struct Unpack {
@@ -233,6 +251,60 @@ __device__ __forceinline__ void wave_sum_pair_u16(float a, float b, float& sum_a
                    r2 = (unsigned)__builtin_amdgcn_readlane((int)p, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)p, 48);
     sum_a = (float)((r0 & 0xffffu) + (r1 & 0xffffu) + (r2 & 0xffffu) + (r3 & 0xffffu));
     sum_b = (float)((r0 >> 16) + (r1 >> 16) + (r2 >> 16) + (r3 >> 16));
+}
+
+// ---- results handed from many workgroups to the last one of them to finish (MI355X_MICROARCH.md, "inter-workgroup
+// visibility": per-XCD L2s are not coherent, a CU's L1 is never refreshed by other CUs' stores) ----------------------------
+// Producer, ONE lane, after ITS OWN plain stores of the handed-off record: drain them, write the XCD's L2 back (agent-scope
+// release), then add to the counter.  Returns the add's old value: `expected - 1` tells the caller it arrived last.
+__device__ __forceinline__ unsigned arrive_release(unsigned* counter) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Consumer, the lane whose add came last: invalidate this CU's L1 (agent-scope acquire) and wait for it; the workgroup's other
+// waves may read the records after the barrier that follows.  Also puts the counter back to zero for the next launch.
+__device__ __forceinline__ void last_arriver_acquire(unsigned* counter) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- TDOA slot: the onset-aligned slice of one capture + a validity header, as one message ----
+// [int64 flag: 0 = valid, -1 = invalid][int64 start sample in the sender's capture][2 n bytes of I/Q]
+// `sample0` / `total`: iq[0] is sample `sample0` of a capture of `total` samples (0 / nsamples for a whole capture).
+// The slice is valid when it lies inside the CAPTURE (the reference's rule, skrypty/triangulateTDOA.py:67-77); a part whose
+// buffer does not hold a valid slice says so with flag -2 (a sizing error of the caller, never silently wrong data).
+// Thread `g0` of `gstride` cooperating threads; `head` writes the header.
+__device__ __forceinline__ void tdoa_slot_body(const uint8_t* __restrict__ iq, size_t nsamples, long long s, size_t n,
+                                               uint8_t* __restrict__ slot, long long sample0, size_t total, size_t g0,
+                                               size_t gstride, bool head) {
+    const bool in_capture = s >= 0 && (unsigned long long)s + n <= total;
+    const bool held = s >= sample0 && (unsigned long long)(s - sample0) + n <= nsamples;
+    const bool ok = in_capture && held;
+    if (head) {
+        long long* h = reinterpret_cast<long long*>(slot);
+        h[0] = ok ? 0 : (in_capture ? -2 : -1);
+        h[1] = s;
+    }
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(iq) + (ok ? s - sample0 : 0);
+    uint4* dst = reinterpret_cast<uint4*>(slot + GJ_SLOT_HEADER);
+    // the slot is padded to a multiple of 256 bytes: the padding is written too (zeros), so that a slot is a fully
+    // defined message
+    const size_t ngroups = ((GJ_SLOT_HEADER + 2 * n + 255) / 256 * 256 - GJ_SLOT_HEADER) / 16;
+    for (size_t g = g0; g < ngroups; g += gstride) {
+        unsigned w[4] = {0, 0, 0, 0};
+        if (ok) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const size_t i = g * 8 + k;
+                const unsigned v = (i < n) ? src[i] : 0u;
+                w[k >> 1] |= v << (16 * (k & 1));
+            }
+        }
+        dst[g] = uint4{w[0], w[1], w[2], w[3]};
+    }
 }
 
 // The capture's onset from its parts' (each already in capture coordinates): the part with the smallest start >= 0

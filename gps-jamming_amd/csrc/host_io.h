@@ -12,6 +12,7 @@ hipStream_t current_stream(gj_ctx* ctx);
 gj_lane* lane_checkout(gj_ctx* ctx);          // nullptr + last error when a lane cannot be made
 void lane_checkin(gj_ctx* ctx, gj_lane* lane);
 void lane_free(gj_lane* lane);                // gj_destroy only
+int lane_sweep(gj_ctx* ctx);                  // lanes of ended callers taken back (drained, stripped, free again)
 
 void comm_detach_all(gj_ctx* ctx);            // comm.hip
 

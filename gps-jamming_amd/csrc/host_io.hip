@@ -5,7 +5,7 @@
 //     -> wait for the call's own event (no lock) -> copy the results out of the lane's pinned area -> check in.
 // Nothing waits, reads a file or copies a capture while holding ctx->mu, so a caller killed at any of those points
 // (QThread.terminate(), GpsJammerApp/app/ui_mainwindow.py:818-826) blocks nobody; the lane it held is taken back
-// when its thread is seen to be gone.
+// at the next check-out after its thread has ended (gj_lane::owner, a robust mutex: gj_common.h).
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -29,82 +29,105 @@ namespace gj {
 constexpr int kMaxLanes = 8;
 
 static int this_tid() { return (int)syscall(SYS_gettid); }
-static bool thread_alive(int tid) {
-    if (tid <= 0) return false;
-    return syscall(SYS_tgkill, (int)getpid(), tid, 0) == 0 || errno != ESRCH;
+
+// Everything a lane holds except the lane itself and its owner mutex.  hipFree / hipHostFree wait for the device.
+static void lane_strip(gj_lane* L) {
+    if (L->stage) (void)hipFree(L->stage);
+    L->stage = nullptr;
+    L->stage_bytes = 0;
+    for (int k = 0; k < gj_lane::kPinBufs; ++k) {
+        if (L->pin[k]) (void)hipHostFree(L->pin[k]);
+        if (L->pin_ev[k]) (void)hipEventDestroy(L->pin_ev[k]);
+        L->pin[k] = nullptr;
+        L->pin_cap[k] = 0;
+        L->pin_ev[k] = nullptr;
+    }
+    if (L->rpin) (void)hipHostFree(L->rpin);
+    L->rpin = nullptr;
+    L->rpin_bytes = 0;
+    for (hipEvent_t* e : {&L->ev_start, &L->ev_stop, &L->ev_done}) {
+        if (*e) (void)hipEventDestroy(*e);
+        *e = nullptr;
+    }
+    for (size_t k = 0; k < L->n_piece_ev; ++k)
+        if (L->piece_ev[k]) (void)hipEventDestroy(L->piece_ev[k]);
+    delete[] L->piece_ev;
+    L->piece_ev = nullptr;
+    L->n_piece_ev = 0;
+    if (L->copy_stream) (void)hipStreamDestroy(L->copy_stream);
+    L->copy_stream = nullptr;
+    if (L->ws) (void)hipFree(L->ws);
+    L->ws = nullptr;
+    L->ws_bytes = 0;
 }
 
 void lane_free(gj_lane* L) {
     if (!L) return;
-    if (L->stage) (void)hipFree(L->stage);
-    for (int k = 0; k < gj_lane::kPinBufs; ++k) {
-        if (L->pin[k]) (void)hipHostFree(L->pin[k]);
-        if (L->pin_ev[k]) (void)hipEventDestroy(L->pin_ev[k]);
-    }
-    if (L->rpin) (void)hipHostFree(L->rpin);
-    for (hipEvent_t e : {L->ev_start, L->ev_stop, L->ev_done})
-        if (e) (void)hipEventDestroy(e);
-    for (size_t k = 0; k < L->n_piece_ev; ++k)
-        if (L->piece_ev[k]) (void)hipEventDestroy(L->piece_ev[k]);
-    delete[] L->piece_ev;
-    if (L->copy_stream) (void)hipStreamDestroy(L->copy_stream);
-    if (L->ws) (void)hipFree(L->ws);
+    lane_strip(L);
+    if (L->owner_ready) (void)pthread_mutex_destroy(&L->owner);
     delete L;
 }
 
-gj_lane* lane_checkout(gj_ctx* ctx) {
-    reap_retired(ctx);
-    const int me = this_tid();
-    for (;;) {
-        gj_lane* taken = nullptr;
-        hipStream_t drain = nullptr;
-        bool reclaimed = false;
-        {
-            Guard g(ctx);
-            for (gj_lane* L : ctx->lanes)
-                if (!L->busy) {
-                    taken = L;
-                    break;
-                }
-            if (!taken)
-                for (gj_lane* L : ctx->lanes)
-                    if (!thread_alive(L->owner_tid)) {   // its caller was killed inside a call
-                        taken = L;
-                        reclaimed = true;
-                        drain = ctx->stream;
-                        ++ctx->lanes_reclaimed;
-                        break;
-                    }
-            if (!taken && (int)ctx->lanes.size() < kMaxLanes) {
-                taken = new (std::nothrow) gj_lane();
-                if (!taken) {
-                    fail(ctx, GJ_ERR_NOMEM, "lane");
-                    return nullptr;
-                }
-                ctx->lanes.push_back(taken);
-            }
-            if (taken) {
-                taken->busy = true;
-                taken->owner_tid = me;
-            }
-        }
-        if (taken) {
-            if (reclaimed) {
-                // what the dead caller queued may still be reading or writing the lane's buffers: kernels on the
-                // context's stream, and -- if it died inside gj_ingest_* / a staged upload -- H2D copies on the lane's own
-                // copy stream or out of its bounce buffers.  Reclaims are rare: drain them all, holding no
-                // lock.  (Fill threads of a caller that was killed outright may still be writing a bounce buffer for a
-                // few milliseconds; INTEGRATION.md says that a hard kill DURING a staged copy is not covered.)
-                (void)wait_stream(ctx, drain);
-                if (taken->copy_stream) (void)wait_stream(ctx, taken->copy_stream);
-                for (int k = 0; k < gj_lane::kPinBufs; ++k)
-                    if (taken->pin_ev[k]) (void)wait_event(ctx, taken->pin_ev[k]);
-            }
-            return taken;
-        }
-        wait_hook(ctx, kWaitLane);   // every lane is held by a live caller: wait for one, holding nothing
-        usleep(200);
+static bool lane_owner_init(gj_lane* L) {
+    pthread_mutexattr_t at;
+    if (pthread_mutexattr_init(&at) != 0) return false;
+    (void)pthread_mutexattr_setrobust(&at, PTHREAD_MUTEX_ROBUST);
+    L->owner_ready = pthread_mutex_init(&L->owner, &at) == 0;
+    pthread_mutexattr_destroy(&at);
+    return L->owner_ready;
+}
+
+// Try to become the lane's owner.  kOwnerLive: a live thread holds it.  kOwnerFree: it was free, now ours.
+// kOwnerDead: its owner ended without checking in (the kernel said so), now ours.
+enum OwnerProbe { kOwnerLive, kOwnerFree, kOwnerDead };
+static OwnerProbe lane_owner_take(gj_lane* L) {
+    const int r = pthread_mutex_trylock(&L->owner);
+    if (r == 0) return kOwnerFree;
+    if (r == EOWNERDEAD) {
+        (void)pthread_mutex_consistent(&L->owner);
+        return kOwnerDead;
     }
+    if (r == ENOTRECOVERABLE) {   // left inconsistent by an earlier recovery that itself died: start over
+        (void)pthread_mutex_destroy(&L->owner);
+        L->owner_ready = false;
+        if (lane_owner_init(L) && pthread_mutex_trylock(&L->owner) == 0) return kOwnerDead;
+    }
+    return kOwnerLive;
+}
+
+// Under the context lock: every busy lane whose owner has ended becomes the calling thread's (still marked busy) and
+// is appended to `orphans`.
+static void lane_sweep_locked(gj_ctx* ctx, int me, std::vector<gj_lane*>& orphans) {
+    for (gj_lane* L : ctx->lanes) {
+        if (!L->busy) continue;
+        if (ctx->inject_owner_alive > 0) {   // gj_debug_inject: this probe answers "alive"
+            --ctx->inject_owner_alive;
+            continue;
+        }
+        if (lane_owner_take(L) == kOwnerLive) continue;
+        // kOwnerDead, or "busy" with nobody holding it (its owner ended between taking the mutex and raising the flag)
+        L->owner_tid = me;
+        ++ctx->lanes_reclaimed;
+        orphans.push_back(L);
+    }
+}
+
+// With NO lock held, by the thread that now owns the orphan: what the dead caller queued may still be reading or
+// writing the lane's buffers -- kernels on the context's stream(s), and, if it died inside gj_ingest_* / a staged
+// upload, H2D copies on the lane's own copy stream or out of its bounce buffers.  Drain them, then give
+// back everything the dead caller had grown the lane to (its staging arena and up to 32 pinned bounce buffers: hundreds
+// of MiB that nobody asked the next caller to inherit).  Reclaims are rare; the next call re-creates what it needs.
+// (Fill threads of a caller that was killed outright may still be writing a bounce buffer for a few milliseconds;
+// INTEGRATION.md says that a hard kill DURING a staged copy is not covered.)
+static void lane_recover(gj_ctx* ctx, gj_lane* L, hipStream_t s0, hipStream_t s1) {
+    (void)hipSetDevice(ctx->device);
+    (void)wait_stream(ctx, s0);
+    if (s1 != s0) (void)wait_stream(ctx, s1);
+    if (L->copy_stream) (void)wait_stream(ctx, L->copy_stream);
+    for (int k = 0; k < gj_lane::kPinBufs; ++k)
+        if (L->pin_ev[k]) (void)wait_event(ctx, L->pin_ev[k]);
+    (void)hipGetLastError();
+    lane_strip(L);
 }
 
 void lane_checkin(gj_ctx* ctx, gj_lane* L) {
@@ -112,6 +135,71 @@ void lane_checkin(gj_ctx* ctx, gj_lane* L) {
     Guard g(ctx);
     L->busy = false;
     L->owner_tid = 0;
+    (void)pthread_mutex_unlock(&L->owner);   // by the thread that checked the lane out
+}
+
+// Take back the lanes of callers that have ended; returns how many.  Called by every check-out and by
+// gj_debug_counters, so a dead caller's lane comes back at the next call whether or not a free lane exists.
+int lane_sweep(gj_ctx* ctx) {
+    std::vector<gj_lane*> orphans;
+    hipStream_t s0 = nullptr, s1 = nullptr;
+    {
+        Guard g(ctx);
+        lane_sweep_locked(ctx, this_tid(), orphans);
+        s0 = ctx->stream;
+        s1 = ctx->own_stream;
+    }
+    for (gj_lane* L : orphans) {
+        lane_recover(ctx, L, s0, s1);
+        lane_checkin(ctx, L);
+    }
+    return (int)orphans.size();
+}
+
+gj_lane* lane_checkout(gj_ctx* ctx) {
+    reap_retired(ctx);
+    const int me = this_tid();
+    for (;;) {
+        gj_lane* taken = nullptr;
+        std::vector<gj_lane*> orphans;
+        hipStream_t s0 = nullptr, s1 = nullptr;
+        {
+            Guard g(ctx);
+            lane_sweep_locked(ctx, me, orphans);
+            s0 = ctx->stream;
+            s1 = ctx->own_stream;
+            if (!orphans.empty()) {
+                taken = orphans.front();   // already ours and marked busy
+            } else {
+                for (gj_lane* L : ctx->lanes)
+                    if (!L->busy && lane_owner_take(L) != kOwnerLive) {
+                        taken = L;
+                        break;
+                    }
+                if (!taken && (int)ctx->lanes.size() < kMaxLanes) {
+                    gj_lane* L = new (std::nothrow) gj_lane();
+                    if (!L || !lane_owner_init(L) || pthread_mutex_trylock(&L->owner) != 0) {
+                        lane_free(L);
+                        fail(ctx, GJ_ERR_NOMEM, "lane");
+                        return nullptr;
+                    }
+                    ctx->lanes.push_back(L);
+                    taken = L;
+                }
+                if (taken) {
+                    taken->busy = true;
+                    taken->owner_tid = me;
+                }
+            }
+        }
+        for (gj_lane* L : orphans) {
+            lane_recover(ctx, L, s0, s1);
+            if (L != taken) lane_checkin(ctx, L);
+        }
+        if (taken) return taken;
+        wait_hook(ctx, kWaitLane);   // every lane is held by a live caller: wait for one, holding nothing
+        usleep(200);
+    }
 }
 
 namespace {

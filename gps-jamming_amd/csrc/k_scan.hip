@@ -1167,6 +1167,384 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The scan's tail in ONE launch (VERDICT r04 "next" 3).  Behind stream_scan_kernel the chain used to be five dependent
+// launches of one to a few workgroups each -- amplitude totals, screening, exact onset scan, onset record, noise-floor
+// threshold -- and a sixth for the TDOA slot; beside K2 each of them waited 5-50 us for its turn, and at the sizes the
+// reference runs (10-s captures) that chain, not K2, was the step.  Here they are ROLES of one grid:
+//   workgroup 0                 noise-floor threshold of the power map   (power_threshold_body, as it is)
+//   workgroup 1                 amplitude totals + chunk-power edge cases (amp_finalize / amp_part_finalize bodies)
+//   workgroups 2 .. 2 + nct-1   K4 over kTailBlocks 512-sample blocks each: screening of its blocks against the guard
+//                               band, and -- instead of handing a candidate to a second kernel -- the exact scan of
+//                               every stretch of ITS range that fails the proof, in order, up to its first crossing.
+//                               Ranges are disjoint and every position is either proven quiet or looked at exactly, so
+//                               the first crossing of the capture is the smallest of the workgroups' own: no
+//                               workgroup waits for another.  Each writes one record; the LAST to arrive (agent-scope
+//                               release / acquire around an arrival counter: gj_common.h) reduces the records in
+//                               workgroup order, writes the gj_onset record and cuts the TDOA slot at that onset.
+// Results: chunk powers, threshold, amplitude statistics, onset index, guard index, noise, margin_hit and the slot are
+// the same bits as the separate launches gave.  margin_before -- a bound, not a measurement (gpsjam.h) -- is now a
+// function of the capture alone: the records are combined in workgroup order up to the one that holds the crossing,
+// where the separate kernels folded in whatever workgroups AHEAD of the crossing had published by then.
+// No memset in front: the noise sum is no longer accumulated by atomics in the scan (it is the sum of the scan's own
+// 512-sample block sums over the span + the span's ragged end), every word of the scratch is written before it is read,
+// and the arrival counter is left at zero by the last arriver.
+// ---------------------------------------------------------------------------------------
+constexpr int kTailBlocks = 2048;                       // 512-sample blocks screened per onset workgroup (1 Mi samples)
+constexpr int kTailHalo = (kOnsetMaxWin + 510) / 512 + 1;
+constexpr int kTailPre = kTailBlocks + kTailHalo + (kTailBlocks + kTailHalo) / 32 + 8;
+constexpr int kTailTileBlocks = kOnsetOut / 512;        // the exact scan looks at 2048 positions = 4 blocks at a time
+
+struct TailRec {
+    unsigned long long first;   // first position of the workgroup's range whose moving average crosses, ~0: none
+    unsigned long long guard;   // first position inside (or above) the rounding band, ~0: none
+    unsigned below;             // largest window sum in front of `first` (exact where looked at, the screening bound elsewhere)
+    unsigned pad;
+};
+
+struct TailArgs {
+    const uint8_t* iq;               // the buffer K4 runs over (a part: halo + own range)
+    unsigned long long nsamples;     // of that buffer
+    long long sample0;               // capture index of iq[0] (0 for a whole capture)
+    unsigned long long total_samples;   // of the whole capture (slot validity)
+    int has_thr, is_part, valid, has_slot;
+    // threshold role
+    float* power;
+    unsigned long long nchunks;
+    float pct, ratio;
+    float* stats;
+    uint8_t* mask;
+    // amplitude role (the OWN range of a part)
+    const uint8_t* own_iq;
+    unsigned long long own_samples, own_tiles, own_bytes, chunk_bytes;
+    const AmpTile* tiles;
+    gj_amp_stats* amp;
+    gj_amp_part* amp_part;
+    long long own_sample0;
+    int flags;
+    // onset role
+    int window, noise_samples, noise_in_scratch;
+    float factor;
+    const unsigned* cblk;
+    OnsetScratch* sc;
+    TailRec* rec;
+    unsigned* arrive;
+    unsigned nct;
+    gj_onset* onset;
+    // slot
+    uint8_t* slot;
+    unsigned long long slice_samples;
+    Unpack up;
+};
+
+struct TailShared {
+    unsigned long long r64[2][kScanThreads / 64];
+    unsigned r32[kScanThreads / 64];
+    unsigned long long b64[2];
+    unsigned b32;
+    int last;
+    long long start;
+};
+
+__device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v, TailShared& sh, int slot) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    if ((threadIdx.x & 63) == 0) sh.r64[slot][threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned long long r = sh.r64[slot][0];
+#pragma unroll
+    for (int k = 1; k < kScanThreads / 64; ++k) r = sh.r64[slot][k] < r ? sh.r64[slot][k] : r;
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ unsigned block_max_u32(unsigned v, TailShared& sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    if ((threadIdx.x & 63) == 0) sh.r32[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned r = sh.r32[0];
+#pragma unroll
+    for (int k = 1; k < kScanThreads / 64; ++k) r = sh.r32[k] > r ? sh.r32[k] : r;
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, TailShared& sh) {
+    v = wave_sum_u64(v);
+    if ((threadIdx.x & 63) == 0) sh.r64[0][threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned long long r = 0;
+#pragma unroll
+    for (int k = 0; k < kScanThreads / 64; ++k) r += sh.r64[0][k];
+    __syncthreads();
+    return r;
+}
+
+// Inclusive prefix sums, in place, of the `need` words pre[onset_pad(1)] .. pre[onset_pad(need)] (pre[0] = 0): the
+// three-step scan of onset_scan_kernel / onset_coarse_kernel (thread spans, span totals, fold).
+__device__ __forceinline__ void block_prefix_u32(unsigned* pre, unsigned* thread_tot, int need) {
+    const int tid = threadIdx.x;
+    const int per = (need + kScanThreads - 1) / kScanThreads;
+    const int lo = tid * per;
+    const int hi = (lo + per < need) ? lo + per : need;
+    unsigned run = 0;
+    for (int k = lo; k < hi; ++k) {
+        run += pre[onset_pad(k + 1)];
+        pre[onset_pad(k + 1)] = run;
+    }
+    thread_tot[tid] = run;
+    __syncthreads();
+    if (tid < 64) {
+        unsigned t0 = thread_tot[4 * tid], t1 = thread_tot[4 * tid + 1], t2 = thread_tot[4 * tid + 2], t3 = thread_tot[4 * tid + 3];
+        unsigned tot = t0 + t1 + t2 + t3, inc = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_up(inc, off, 64);
+            if (tid >= off) inc += o;
+        }
+        const unsigned ex = inc - tot;
+        thread_tot[4 * tid] = ex;
+        thread_tot[4 * tid + 1] = ex + t0;
+        thread_tot[4 * tid + 2] = ex + t0 + t1;
+        thread_tot[4 * tid + 3] = ex + t0 + t1 + t2;
+    }
+    __syncthreads();
+    const unsigned add = thread_tot[tid];
+    for (int k = lo; k < hi; ++k) pre[onset_pad(k + 1)] += add;
+    __syncthreads();
+}
+
+// K4 of one onset workgroup `w`; writes rec[w].  Whole workgroup.
+__device__ void tail_onset_range(const TailArgs& A, unsigned w, unsigned* pre_c, unsigned* thread_tot, unsigned* pre_x,
+                                 TailShared& sh) {
+    const int tid = threadIdx.x;
+    const int window = A.window;
+    const size_t nsamples = (size_t)A.nsamples;
+    const size_t nout = nsamples - (size_t)window + 1;
+    // the threshold (triangulateTDOA.py:41-42,46), from the exact noise sum
+    unsigned long long noise_S;
+    if (A.noise_in_scratch) {
+        noise_S = A.sc->noise_S;                       // a part that does not hold the span: summed by the scan launch
+    } else {
+        const size_t nb = (size_t)A.noise_samples / 512;
+        unsigned long long part = 0;
+        for (size_t j = tid; j < nb; j += kScanThreads) part += A.cblk[j];
+        for (size_t n = nb * 512 + tid; n < (size_t)A.noise_samples; n += kScanThreads) part += m_of(A.iq[2 * n], A.iq[2 * n + 1], A.up.off2);
+        noise_S = block_sum_u64(part, sh);
+    }
+    float noise = (float)((double)noise_S / (4.0 * (double)A.noise_samples));
+    if (noise == 0.f) noise = 1e-9f;
+    const float thr_f = noise * A.factor;
+    if (w == 0 && tid == 0) { A.sc->noise = noise; A.sc->thr = thr_f; }
+    const double thr = (double)thr_f, thr_lo = thr * (1.0 - kOnsetGuard);
+    const double scale = 0.25 / (double)window;
+    // screening: block sums of this range + the blocks a window that starts in it can reach
+    const size_t j0 = (size_t)w * kTailBlocks;
+    const int cb = (window + 510) / 512 + 1;
+    const size_t nblk_total = (nsamples + 511) / 512;
+    size_t jend = j0 + kTailBlocks;
+    if (512 * jend > nout) jend = (nout + 511) / 512;
+    const int nloc = jend > j0 ? (int)(jend - j0) : 0;
+    const int need = nloc ? nloc + cb - 1 : 0;
+    for (int k = tid; k < need; k += kScanThreads) {
+        const size_t j = j0 + k;
+        pre_c[onset_pad(k + 1)] = j < nblk_total ? A.cblk[j] : 0u;
+    }
+    if (tid == 0) pre_c[0] = 0;
+    __syncthreads();
+    if (need) block_prefix_u32(pre_c, thread_tot, need);
+    unsigned long long first = ~0ull, guard = ~0ull;
+    unsigned below = 0;
+    const uint16_t* iq16_all = reinterpret_cast<const uint16_t*>(A.iq);
+    int kstart = 0;
+    while (kstart < nloc) {                              // workgroup-uniform
+        // the first block from kstart on that fails the proof
+        unsigned long long mine = ~0ull;
+        for (int k = kstart + tid; k < nloc; k += kScanThreads) {
+            const unsigned U = pre_c[onset_pad(k + cb)] - pre_c[onset_pad(k)];
+            if ((double)U * scale > thr_lo) { mine = (unsigned long long)k; break; }
+        }
+        const unsigned long long k1u = block_min_u64(mine, sh, 0);
+        const int k1 = k1u == ~0ull ? nloc : (int)k1u;
+        // the blocks in front of it are quiet: they enter the margin with their bound
+        unsigned quiet = 0;
+        for (int k = kstart + tid; k < k1; k += kScanThreads) {
+            const unsigned U = pre_c[onset_pad(k + cb)] - pre_c[onset_pad(k)];
+            quiet = U > quiet ? U : quiet;
+        }
+        quiet = block_max_u32(quiet, sh);
+        below = quiet > below ? quiet : below;
+        if (k1 >= nloc) break;
+        // exact: the kOnsetOut positions from that block on (clipped to this range): prefix sums of 4|z|^2 in LDS,
+        // window sums by difference
+        const size_t o0 = (j0 + (size_t)k1) * 512;
+        size_t o1 = o0 + kOnsetOut;
+        if (o1 > jend * 512) o1 = jend * 512;
+        if (o1 > nout) o1 = nout;
+        const int npos = (int)(o1 - o0);
+        const int needx = npos + window - 1;
+        const uint16_t* iq16 = iq16_all + o0;
+        for (int k = tid; k < needx; k += kScanThreads) {
+            const unsigned v = iq16[k];
+            pre_x[onset_pad(k + 1)] = m_of(v & 255u, v >> 8, A.up.off2);
+        }
+        if (tid == 0) pre_x[0] = 0;
+        __syncthreads();
+        block_prefix_u32(pre_x, thread_tot, needx);
+        unsigned Sv[kOnsetOut / kScanThreads];
+        unsigned long long best = ~0ull, best_lo = ~0ull;
+#pragma unroll
+        for (int i = 0; i < kOnsetOut / kScanThreads; ++i) {
+            const int k = tid + i * kScanThreads;
+            Sv[i] = 0;
+            if (k < npos) {
+                const unsigned S = pre_x[onset_pad(k + window)] - pre_x[onset_pad(k)];
+                Sv[i] = S;
+                const double ma = (double)S * scale;
+                if (ma > thr_lo && best_lo == ~0ull) best_lo = o0 + k;
+                if (ma > thr && best == ~0ull) best = o0 + k;
+            }
+        }
+        const unsigned long long hit = block_min_u64(best, sh, 0);
+        const unsigned long long hit_lo = block_min_u64(best_lo, sh, 1);
+        unsigned b = 0;
+#pragma unroll
+        for (int i = 0; i < kOnsetOut / kScanThreads; ++i) {
+            const int k = tid + i * kScanThreads;
+            if (k < npos && o0 + k < hit) b = Sv[i] > b ? Sv[i] : b;
+        }
+        b = block_max_u32(b, sh);
+        below = b > below ? b : below;
+        if (hit_lo != ~0ull && guard == ~0ull) guard = hit_lo;
+        if (hit != ~0ull) { first = hit; break; }
+        kstart = k1 + (npos + 511) / 512;
+    }
+    if (tid == 0) {
+        TailRec r;
+        r.first = first; r.guard = guard; r.below = below; r.pad = 0;
+        A.rec[w] = r;
+    }
+}
+
+// The last onset workgroup to arrive: records -> gj_onset (the arithmetic of onset_finalize_kernel), then the slot.
+__device__ void tail_onset_finish(const TailArgs& A, TailShared& sh) {
+    const int tid = threadIdx.x;
+    const int window = A.window;
+    long long start_index = -1;
+    if (A.valid) {
+        unsigned long long wmin = ~0ull;
+        for (unsigned w = tid; w < A.nct; w += kScanThreads)
+            if (A.rec[w].first != ~0ull) { wmin = w; break; }
+        const unsigned long long wstar = block_min_u64(wmin, sh, 0);
+        const bool found = wstar != ~0ull;
+        const unsigned wlast = found ? (unsigned)wstar : A.nct - 1;
+        unsigned below = 0;
+        unsigned long long guard = ~0ull;
+        for (unsigned w = tid; w <= wlast; w += kScanThreads) {
+            const TailRec r = A.rec[w];
+            below = r.below > below ? r.below : below;
+            guard = r.guard < guard ? r.guard : guard;
+        }
+        below = block_max_u32(below, sh);
+        guard = block_min_u64(guard, sh, 1);
+        const unsigned long long i0 = found ? A.rec[wstar].first : 0ull;
+        unsigned long long S = 0;
+        if (found)
+            for (int k = tid; k < window; k += kScanThreads) S += m_of(A.iq[2 * (i0 + k)], A.iq[2 * (i0 + k) + 1], A.up.off2);
+        S = block_sum_u64(S, sh);
+        if (tid == 0) {
+            const double thr = (double)A.sc->thr, scale = 0.25 / (double)window;
+            gj_onset o;
+            o.start_index = found ? A.sample0 + (long long)i0 + window / 2 : -1;
+            o.noise_power = A.sc->noise;
+            o.threshold = A.sc->thr;
+            o.margin_hit = found ? (float)(((double)S * scale - thr) / thr) : 0.f;
+            o.margin_before = (float)((thr - (double)below * scale) / thr);
+            unsigned long long ig = guard;
+            if (found && i0 < ig) ig = i0;
+            o.guard_index = ig != ~0ull ? A.sample0 + (long long)ig + window / 2 : -1;
+            *A.onset = o;
+            sh.start = o.start_index;
+        }
+    } else if (tid == 0) {
+        gj_onset o;
+        o.start_index = -1; o.noise_power = 0.f; o.threshold = 0.f; o.margin_hit = 0.f; o.margin_before = 0.f; o.guard_index = -1;
+        *A.onset = o;
+        sh.start = -1;
+    }
+    __syncthreads();
+    if (A.has_slot)
+        tdoa_slot_body(A.iq, (size_t)A.nsamples, sh.start, (size_t)A.slice_samples, A.slot, A.sample0, (size_t)A.total_samples,
+                       (size_t)tid, (size_t)kScanThreads, tid == 0);
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_tail_kernel(TailArgs A) {
+    __shared__ ThrShared sh_thr;
+    __shared__ double sh_amp[16];
+    __shared__ long long first_s;
+    __shared__ TailShared sh;
+    __shared__ unsigned pre_c[kTailPre];
+    __shared__ unsigned thread_tot[kScanThreads];
+    extern __shared__ unsigned pre_x[];                // kOnsetOut + window - 1 words + padding
+    const int tid = threadIdx.x;
+    unsigned b = blockIdx.x;
+    if (A.has_thr) {
+        if (b == 0) {
+            power_threshold_body(A.power, (size_t)A.nchunks, A.pct, A.ratio, A.stats, A.mask, sh_thr);
+            return;
+        }
+        --b;
+    }
+    if (b == 0) {
+        // amplitude totals + the chunk-power edge cases: the bodies of amp_finalize_kernel / amp_part_finalize_kernel
+        power_edge_cases(A.power, (size_t)A.nchunks, (size_t)A.own_bytes, (size_t)A.chunk_bytes, A.flags);
+        const long long first = amp_block_first(A.tiles, (size_t)A.own_tiles, &first_s);
+        if (first == 0x7fffffffffffffffll) {
+            if (tid == 0) {
+                if (A.is_part) { A.amp_part->first_index = -1; A.amp_part->count = 0; A.amp_part->sum = 0.0; A.amp_part->tail = 0.0; }
+                else { A.amp->first_index = -1; A.amp->count = 0; A.amp->sum = 0.0; A.amp->mean = 0.f; A.amp->reserved = 0.f; }
+            }
+            return;
+        }
+        const double tail = amp_block_tail(A.own_iq, (size_t)A.own_samples, A.tiles, first, A.up, sh_amp);
+        const double behind = amp_block_total(A.tiles, (size_t)A.own_tiles, (size_t)first / kAmpTileSamples, sh_amp);
+        if (tid == 0) {
+            const unsigned long long cnt = A.own_samples - (size_t)first;
+            if (A.is_part) {
+                A.amp_part->first_index = A.own_sample0 + first;
+                A.amp_part->count = cnt;
+                A.amp_part->sum = behind + tail;
+                A.amp_part->tail = tail;
+            } else {
+                const double total = behind + tail;
+                A.amp->first_index = first;
+                A.amp->count = cnt;
+                A.amp->sum = total;
+                A.amp->mean = (float)(total / (double)cnt);
+                A.amp->reserved = 0.f;
+            }
+        }
+        return;
+    }
+    --b;
+    // onset workgroups
+    if (A.valid) tail_onset_range(A, b, pre_c, thread_tot, pre_x, sh);
+    if (tid == 0) {
+        const unsigned ticket = arrive_release(A.arrive);
+        const int last = ticket == A.nct - 1;
+        if (last) last_arriver_acquire(A.arrive);
+        sh.last = last;
+    }
+    __syncthreads();
+    if (!sh.last) return;
+    tail_onset_finish(A, sh);
+}
+
 // One implementation for a whole capture (part == nullptr) and for one part of a capture split over GPUs.
 // A part's buffer is [halo][own range]: the halo (whole 64-KiB tiles of the capture in front of the own range, at
 // least window - 1 samples; none for the capture's first part) lets K4 evaluate every window that ENDS inside the

@@ -389,42 +389,12 @@ int launch_xcorr(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, 
     return GJ_OK;
 }
 
-// ---- TDOA slot: the onset-aligned slice of one capture + a validity header, as one message ----
-// [int64 flag: 0 = valid, -1 = invalid][int64 start sample in the sender's capture][2 n bytes of I/Q]
-__device__ __forceinline__ size_t align_up_dev(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-// `sample0` / `total`: iq[0] is sample `sample0` of a capture of `total` samples (0 / nsamples for a whole capture).
-// The slice is valid when it lies inside the CAPTURE (the reference's rule); a part whose buffer does not hold a
-// valid slice says so with flag -2 (a sizing error of the caller, never silently wrong data).
+// ---- TDOA slot (layout and rules: tdoa_slot_body, gj_common.h) ----
 __global__ __launch_bounds__(256) void tdoa_slot_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
                                                         const long long* __restrict__ start, size_t n,
                                                         uint8_t* __restrict__ slot, long long sample0, size_t total) {
-    const long long s = *start;
-    const bool in_capture = s >= 0 && (unsigned long long)s + n <= total;
-    const bool held = s >= sample0 && (unsigned long long)(s - sample0) + n <= nsamples;
-    const bool ok = in_capture && held;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        long long* h = reinterpret_cast<long long*>(slot);
-        h[0] = ok ? 0 : (in_capture ? -2 : -1);
-        h[1] = s;
-    }
-    const uint16_t* src = reinterpret_cast<const uint16_t*>(iq) + (ok ? s - sample0 : 0);
-    uint4* dst = reinterpret_cast<uint4*>(slot + GJ_SLOT_HEADER);
-    // the slot is padded to a multiple of 256 bytes: the padding is written too (zeros), so that a
-    // slot is a fully defined message
-    const size_t ngroups = (align_up_dev(GJ_SLOT_HEADER + 2 * n, 256) - GJ_SLOT_HEADER) / 16;
-    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < ngroups; g += (size_t)gridDim.x * blockDim.x) {
-        unsigned w[4] = {0, 0, 0, 0};
-        if (ok) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const size_t i = g * 8 + k;
-                const unsigned v = (i < n) ? src[i] : 0u;
-                w[k >> 1] |= v << (16 * (k & 1));
-            }
-        }
-        dst[g] = uint4{w[0], w[1], w[2], w[3]};
-    }
+    tdoa_slot_body(iq, nsamples, *start, n, slot, sample0, total, blockIdx.x * (size_t)blockDim.x + threadIdx.x,
+                   (size_t)gridDim.x * blockDim.x, blockIdx.x == 0 && threadIdx.x == 0);
 }
 
 int launch_tdoa_slot(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, const int64_t* d_start, size_t n_samples,

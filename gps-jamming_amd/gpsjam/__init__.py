@@ -386,9 +386,14 @@ class Device:
         arr = as_u8(raw)
         return (arr.ctypes.data if arr.size else None), int(arr.size), arr
 
-    def debug_busy_dev(self, milliseconds: float):
-        """Keep this context's stream (and its hardware queue) busy for a while with one spinning wave (gj_debug_busy_dev)."""
-        self._check(self._lib.gj_debug_busy_dev(self._ctx, float(milliseconds)))
+    def probe_busy_dev(self, milliseconds: float):
+        """Keep this context's stream (and its hardware queue) busy for a while with one spinning wave (gj_probe_busy_dev):
+        the stream-overlap probe of gpsjam/streams.py."""
+        self._check(self._lib.gj_probe_busy_dev(self._ctx, float(milliseconds)))
+
+    def debug_inject(self, what: int, count: int = 1):
+        """Fault injection for tests (gj_debug_inject; GJ_INJECT_OWNER_ALIVE = 1)."""
+        self._check(self._lib.gj_debug_inject(self._ctx, int(what), int(count)))
 
     def debug_counters(self):
         """Lanes made / in use / taken back from dead callers, dead-owner recoveries of the mutex."""

@@ -117,7 +117,7 @@ GJ_MAX_ANTENNAS = 16
 GJ_LAG_INVALID = -(1 << 31)
 GJ_SLOT_HEADER = 16
 GJ_COMM_ID_BYTES = 128
-GJ_VERSION = 130
+GJ_VERSION = 140
 
 _vp, _sz, _i, _f, _d = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double
 _pf, _psz = C.POINTER(C.c_float), C.POINTER(C.c_size_t)
@@ -138,7 +138,8 @@ SIGNATURES = {
     "gj_device_identity": (_i, [_vp, C.c_char_p, _sz]),
     "gj_reserve": (_i, [_vp, _sz]),
     "gj_debug_set_wait_hook": (_i, [_vp, _vp, _vp]),
-    "gj_debug_busy_dev": (_i, [_vp, _f]),
+    "gj_probe_busy_dev": (_i, [_vp, _f]),
+    "gj_debug_inject": (_i, [_vp, _i, _i]),
     "gj_debug_counters": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "gj_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "gj_free": (_i, [_vp, _vp]),

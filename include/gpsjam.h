@@ -17,7 +17,9 @@
  *    killed inside a call (QThread.terminate(), GpsJammerApp/app/ui_mainwindow.py:818-826) does
  *    not block the next one.  Every "*_u8" / upload call works in buffers of its own (a "lane":
  *    device staging, pinned bounce buffers, events), so concurrent calls on one context never
- *    share a result area; kernels of all calls are ordered on the context's one stream;
+ *    share a result area; kernels of all calls are ordered on the context's one stream.  The lane of
+ *    a killed caller is taken back -- drained and emptied -- at the next lane check-out or
+ *    gj_debug_counters call after its thread has ended (see "Diagnostics" below for exactly what);
  *  - "*_dev" functions take DEVICE pointers, enqueue on the context's stream and return
  *    without synchronising (results land in device memory; no host synchronisation, no
  *    allocation when the workspace has been reserved) -- this is what bench.py times;
@@ -39,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GJ_VERSION 130 /* 0.1.3: device identity, communicator figures read from the live communicator, three-launch part combine; the result header has 40 fields (GJ_RESULT_HEADER) */
+#define GJ_VERSION 140 /* 0.1.4: lane ownership by robust mutex (gj_debug_inject), gj_probe_busy_dev (was gj_debug_busy_dev), fused scan tail */
 
 typedef struct gj_ctx gj_ctx;
 
@@ -89,16 +91,37 @@ int gj_reserve(gj_ctx* ctx, size_t workspace_bytes);
  * a thread there to show that an abandoned caller blocks nobody.  Site 5 is the exception: it is
  * inside gj_debug_counters WITH the lock held, so that a test can end a thread as the mutex's owner
  * and watch the next caller recover it.  NULL removes the hook.  The counters:
- * lanes made, lanes in use, lanes taken back from callers whose thread had gone, and how often the
- * mutex was found with a dead owner. */
+ * lanes made, lanes in use, lanes taken back from callers whose thread had ended, and how often the
+ * context mutex was found with a dead owner.
+ *
+ * What happens to a caller that is killed inside a call, and when: the calling thread holds its lane's
+ * owner token -- a robust mutex -- from check-out to check-in.  The kernel marks that token "owner
+ * died" while the thread exits, before the thread can be joined, so there is no interval in which a dead
+ * caller looks alive and no thread id a later thread could inherit.  EVERY later lane check-out (any
+ * "*_u8" / upload / ingest call, from any thread) and every gj_debug_counters call first sweeps all
+ * lanes in use; a lane whose owner has ended is taken over by the sweeping thread, which -- holding
+ * no lock -- waits for whatever the dead caller had queued (the context's streams, the lane's copy
+ * stream and bounce-buffer events), frees everything the lane had grown to (device staging, pinned
+ * buffers, events, copy stream, ingest workspace) and returns it to the pool.  Not covered: the
+ * resident capture a killed gj_upload / gj_ingest had allocated but not yet handed out (that device
+ * memory stays allocated until gj_destroy of the process' GPU context), and a kill in the middle of a
+ * staged copy whose helper threads are still running. */
 int gj_debug_set_wait_hook(gj_ctx* ctx, void (*hook)(void* arg, int site), void* arg);
-/* Keep the context's stream busy for `milliseconds` (0..100) with ONE wave that spins on the 100-MHz real-time counter:
- * the chip stays free, the stream -- and the hardware queue the runtime mapped it to -- does not.  A host that needs
- * two streams to run side by side uses it to find out whether they share a hardware queue (the HIP runtime deals
- * streams over GPU_MAX_HW_QUEUES queues, four by default, and two streams on one queue run one after the other):
- * gpsjam/streams.py. */
-int gj_debug_busy_dev(gj_ctx* ctx, float milliseconds);
 int gj_debug_counters(gj_ctx* ctx, int* lanes, int* lanes_busy, int* lanes_reclaimed, int* owner_deaths);
+/* Fault injection for tests.  GJ_INJECT_OWNER_ALIVE: the next `count` owner probes of a lane in use are
+ * skipped, i.e. answer "its caller is alive" whatever the truth -- the wrong answer that round 4's
+ * sampled probe gave inside the thread-exit window.  A test uses it to show that a lane missed once is
+ * still taken back at the next check-out or counters call. */
+#define GJ_INJECT_OWNER_ALIVE 1
+int gj_debug_inject(gj_ctx* ctx, int what, int count);
+
+/* Stream-overlap probe.  Keeps the context's stream busy for `milliseconds` (0..100; more is refused) with ONE wave
+ * that spins on the 100-MHz real-time counter: the chip stays free, the stream -- and the hardware queue the runtime
+ * mapped it to -- does not.  A host that needs two streams to run side by side uses it to find out whether they share
+ * a hardware queue (the HIP runtime deals streams over GPU_MAX_HW_QUEUES queues, four by default, and two streams on
+ * one queue run one after the other): gpsjam/streams.py, which the pipelines of gpsjam/sharded.py, split.py and
+ * local.py call at construction.  Enqueues only; never synchronises. */
+int gj_probe_busy_dev(gj_ctx* ctx, float milliseconds);
 
 /* device memory for callers that do not bring their own allocator (torch) */
 int gj_malloc(gj_ctx* ctx, size_t bytes, void** dptr);

@@ -3,6 +3,9 @@
  * exit system call -- no unwinding, no destructors, exactly what a hard kill leaves behind -- at the library's own
  * wait sites (gj_debug_set_wait_hook), and the main thread then keeps using the same context:
  *   A dies inside a 256-MiB gj_upload (staged copy)          -> its lane is taken back, the next call is correct
+ *   A' the same, and the owner probe is made to answer "alive" once (gj_debug_inject: the wrong answer a sampled
+ *      probe gave in GPUTEST_r04)                            -> a second lane is made; the missed lane still comes back at
+ *      the NEXT check-out (and, in a second run of the step, at the next gj_debug_counters call)
  *   B dies inside gj_chunk_power_u8, waiting for its event   -> same
  *   C dies as the OWNER of the context mutex                 -> the next locker recovers the mutex
  *   D is pthread_cancel'ed (QThread.terminate() on POSIX) while inside gj_upload -> the call completes, the
@@ -109,8 +112,45 @@ int main(void) {
         gj_debug_counters(ctx, &lanes, &busy, &reclaimed, &deaths);
         printf("%s: lanes %d busy %d reclaimed %d owner_deaths %d\n", names[k], lanes, busy, reclaimed, deaths);
         if (busy != 0) return 5;
+        /* the dead caller's lane is re-used, not replaced: ownership is the kernel's verdict (a robust mutex), so the
+         * first check-out after the join already sees it -- whatever the timing of the thread's exit */
+        if (k == 0 && (lanes != 1 || reclaimed != 1)) return 9;
     }
     if (reclaimed < 2 || deaths < 1) return 6;
+    /* A': the probe misses the dead owner once.  Round 4's state (lanes 2, busy 1, reclaimed unchanged) is reproduced on
+     * purpose, then the lane must come back: first at the next check-out, second time at the next counters call. */
+    for (int variant = 0; variant < 2; ++variant) {
+        void* ret = NULL;
+        int lanes0, busy0, reclaimed0;
+        gj_debug_counters(ctx, &lanes0, &busy0, &reclaimed0, &deaths);
+        pthread_create(&t, NULL, die_in_upload, NULL);
+        pthread_join(t, &ret);
+        if (ret == (void*)1) return 3;
+        /* variant 0: two wrong answers (the check-out's sweep and the counters' sweep) so that the missed state can be read */
+        if (gj_debug_inject(ctx, GJ_INJECT_OWNER_ALIVE, variant == 0 ? 2 : 1) != GJ_OK) return 10;
+        if (check_power("with the dead owner reported alive")) return 4;   /* served from another lane */
+        if (variant == 0) {
+            gj_debug_counters(ctx, &lanes, &busy, &reclaimed, &deaths);
+            printf("dead owner reported alive: lanes %d busy %d reclaimed %d (the state GPUTEST_r04 ended in)\n", lanes, busy, reclaimed);
+            if (busy != 1 || reclaimed != reclaimed0 || lanes < 2) return 11;
+            if (check_power("at the next check-out")) return 4;             /* its sweep takes the lane back */
+        }
+        gj_debug_counters(ctx, &lanes, &busy, &reclaimed, &deaths);        /* variant 1: THIS call's sweep takes it back */
+        printf("missed once, then %s: lanes %d busy %d reclaimed %d\n", variant == 0 ? "the next check-out" : "the next counters call",
+               lanes, busy, reclaimed);
+        if (busy != 0 || reclaimed != reclaimed0 + 1) return 12;
+    }
+    /* more dead callers than there are lanes (8): every one of them comes back, nothing spins */
+    for (int k = 0; k < 12; ++k) {
+        void* ret = NULL;
+        pthread_create(&t, NULL, die_in_event_wait, NULL);
+        pthread_join(t, &ret);
+        if (ret == (void*)1) return 3;
+    }
+    if (check_power("after twelve more dead callers")) return 4;
+    gj_debug_counters(ctx, &lanes, &busy, &reclaimed, &deaths);
+    printf("after twelve more dead callers: lanes %d busy %d reclaimed %d\n", lanes, busy, reclaimed);
+    if (busy != 0 || lanes > 8) return 13;
     /* D: cancelled while inside gj_upload */
     {
         void* ret = NULL;

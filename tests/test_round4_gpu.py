@@ -147,7 +147,7 @@ def test_communicator_reports_live_figures(dev):
 # ----------------------------------------------------------------------------- streams on hardware queues of their own
 def test_stream_beside_finds_a_stream_that_overlaps(dev):
     """gpsjam.streams: a stream is tested against another by keeping that one busy with a spinning wave
-    (gj_debug_busy_dev) and recording an event on the candidate.  A stream never runs beside itself; stream_beside
+    (gj_probe_busy_dev) and recording an event on the candidate.  A stream never runs beside itself; stream_beside
     returns one that runs beside the main stream, and beside two streams at once."""
     import torch
     from gpsjam import streams
@@ -164,12 +164,12 @@ def test_stream_beside_finds_a_stream_that_overlaps(dev):
         # the busy kernel holds the stream for about the time asked, and nothing else
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(main)
-        dev.debug_busy_dev(3.0)
+        dev.probe_busy_dev(3.0)
         b.record(main)
         torch.cuda.synchronize()
         assert 2.5 < a.elapsed_time(b) < 6.0
         with pytest.raises(gpsjam.GpsJamError):
-            dev.debug_busy_dev(1000.0)
+            dev.probe_busy_dev(1000.0)
     finally:
         dev.set_stream(None, external=False)
 
