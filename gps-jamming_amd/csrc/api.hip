@@ -443,6 +443,32 @@ int gj_stream_scan_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t c
                               noise_samples, window, factor, d_onset);
 }
 
+static int scan_extra_of(gj_ctx* ctx, const gj_scan_extra* e, ScanExtra& x) {
+    if (!e) return GJ_OK;
+    x.pct = e->pct;
+    x.rise_db = e->rise_db;
+    x.d_stats = e->d_stats;
+    x.d_mask = e->d_mask;
+    x.d_slot = e->d_slot;
+    x.slice_samples = e->slice_samples;
+    if (e->d_slot && e->slice_samples < 1) return fail(ctx, GJ_ERR_INVALID, "n_samples must be >= 1");
+    if (e->d_slot && (reinterpret_cast<uintptr_t>(e->d_slot) & 15)) return fail(ctx, GJ_ERR_INVALID, "slot must be 16-byte aligned");
+    return GJ_OK;
+}
+
+int gj_capture_scan_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
+                        float* d_power, float rssi_threshold, gj_amp_stats* d_amp, int noise_samples, int window,
+                        float factor, gj_onset* d_onset, const gj_scan_extra* extra) {
+    GJ_ENTER(ctx);
+    if (!d_power || !d_amp || !d_onset || (nbytes && !d_iq)) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    if (chunk_bytes == 0) return fail(ctx, GJ_ERR_INVALID, "chunk_bytes must be > 0");
+    ScanExtra x;
+    const int rc = scan_extra_of(ctx, extra, x);
+    if (rc) return rc;
+    return launch_stream_scan(ctx, d_iq, nbytes, chunk_bytes, eps, flags, d_power, rssi_threshold, d_amp,
+                              noise_samples, window, factor, d_onset, &x);
+}
+
 int gj_xcorr_lags_dev(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, int n_ant, const int64_t* d_starts,
                       size_t n_samples, const int32_t* pairs, int n_pairs, int32_t* d_lags, float* d_peaks,
                       float* d_margins) {
@@ -519,6 +545,20 @@ int gj_part_scan_dev(gj_ctx* ctx, const gj_part_view* part, size_t chunk_bytes, 
     if (!part || !part->d_buf || !d_power || !d_tiles || !d_amp || !d_onset) return fail(ctx, GJ_ERR_INVALID, "null buffer");
     return launch_part_scan(ctx, *part, chunk_bytes, eps, flags, d_power, rssi_threshold, d_tiles, d_amp, noise_samples,
                             window, factor, d_onset);
+}
+
+int gj_part_capture_scan_dev(gj_ctx* ctx, const gj_part_view* part, size_t chunk_bytes, float eps, int flags, float* d_power,
+                             float rssi_threshold, void* d_tiles, gj_amp_part* d_amp, int noise_samples, int window, float factor,
+                             gj_onset* d_onset, const gj_scan_extra* extra) {
+    GJ_ENTER(ctx);
+    if (!part || !part->d_buf || !d_power || !d_tiles || !d_amp || !d_onset) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    if (part->buf_first_byte & 1) return fail(ctx, GJ_ERR_INVALID, "the buffer must start on a sample");
+    ScanExtra x;
+    const int rc = scan_extra_of(ctx, extra, x);
+    if (rc) return rc;
+    x.slot_buf_bytes = part->buf_bytes;   // a slice may run into the tail behind the own range
+    return launch_part_scan(ctx, *part, chunk_bytes, eps, flags, d_power, rssi_threshold, d_tiles, d_amp, noise_samples,
+                            window, factor, d_onset, &x);
 }
 
 static int part_own(gj_ctx* ctx, const gj_part_view* part, const uint8_t** own) {

@@ -353,14 +353,24 @@ int scan_begin(gj_ctx*, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, 
                ScanJob&);
 int scan_start(gj_ctx*, ScanJob&);                              // clears the accumulators (after job.ws is set)
 int scan_range(gj_ctx*, const ScanJob&, size_t tile0, size_t tile1);
-int scan_end(gj_ctx*, const ScanJob&);
+// what the scan's tail launch can do on top of K1 + K3 + K4 (all optional): the noise-floor threshold of the power map
+// (gj_power_threshold_dev) and the TDOA slot cut at the onset (gj_tdoa_slot_dev with d_start = &onset.start_index)
+struct ScanExtra {
+    float pct = 5.f, rise_db = 6.f;
+    float* d_stats = nullptr;      // [3]; nullptr: no threshold
+    uint8_t* d_mask = nullptr;     // [n_chunks] or nullptr
+    uint8_t* d_slot = nullptr;     // nullptr: no slot
+    size_t slice_samples = 0;
+    size_t slot_buf_bytes = 0;     // bytes of the buffer a slice may be cut from (a part: its whole buffer, tail included); 0: the scanned bytes
+};
+int scan_end(gj_ctx*, const ScanJob&, const ScanExtra* extra = nullptr);
 bool scan_fusable(const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes);
 int launch_chunk_power(gj_ctx*, const uint8_t*, size_t, size_t, float, int, float*);
 int launch_power_threshold(gj_ctx*, const float*, size_t, float, float, float*, uint8_t*);
 int launch_amp_stats(gj_ctx*, const uint8_t*, size_t, float, gj_amp_stats*);
 int launch_onset(gj_ctx*, const uint8_t*, size_t, int, int, float, gj_onset*);
 int launch_stream_scan(gj_ctx*, const uint8_t*, size_t, size_t, float, int, float*, float, gj_amp_stats*, int, int,
-                       float, gj_onset*);
+                       float, gj_onset*, const ScanExtra* extra = nullptr);
 int launch_histogram(gj_ctx*, const uint8_t*, size_t, size_t, int, int, unsigned long long*);
 int launch_welch(gj_ctx*, const uint8_t*, size_t, size_t, int, double, int, float*, float*, size_t plan_bytes = 0);
 size_t welch_workspace(gj_ctx*, size_t, size_t, int, size_t plan_bytes = 0);
@@ -368,7 +378,8 @@ int launch_xcorr(gj_ctx*, const uint8_t* const*, const size_t*, int, const int64
                  const int32_t*, int, int32_t*, float*, float*);
 int launch_tdoa_slot(gj_ctx*, const uint8_t*, size_t, const int64_t*, size_t, uint8_t*, long long sample0 = 0, size_t total_samples = 0);
 int launch_slots_pick(gj_ctx*, const uint8_t*, size_t, const int*, const int*, int, uint8_t*);
-int launch_part_scan(gj_ctx*, const gj_part_view&, size_t, float, int, float*, float, void*, gj_amp_part*, int, int, float, gj_onset*);
+int launch_part_scan(gj_ctx*, const gj_part_view&, size_t, float, int, float*, float, void*, gj_amp_part*, int, int, float, gj_onset*,
+                     const ScanExtra* extra = nullptr);
 size_t amp_tile_count(size_t nbytes);
 int launch_amp_combine(gj_ctx*, const void*, size_t, const gj_amp_part*, int, size_t, gj_amp_stats*);
 int launch_onset_combine(gj_ctx*, const gj_onset*, int, gj_onset*);

@@ -1015,12 +1015,23 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
                                                                    float* __restrict__ power,
                                                                    unsigned long long* __restrict__ acc, float thr,
                                                                    AmpTile* __restrict__ tiles,
-                                                                   unsigned* __restrict__ cblk, size_t noise_bytes,
-                                                                   OnsetScratch* __restrict__ sc, Unpack up,
-                                                                   unsigned skip_tiles = 0, unsigned tile_base = 0) {
+                                                                   unsigned* __restrict__ cblk, Unpack up,
+                                                                   unsigned skip_tiles, unsigned tile_base,
+                                                                   unsigned noise_block, const uint8_t* __restrict__ noise_src,
+                                                                   int noise_samples, OnsetScratch* __restrict__ sc) {
     // skip_tiles (a part of a split capture): the first tiles of the buffer are the HALO in front of the part's own
     // range -- they feed K4's block sums only; chunk powers and amplitude tiles start at the own range (`nbytes` =
     // its length, `power` / `tiles` / `acc` its arrays).
+    // noise_block (a part that does not hold the capture's first noise_samples samples): one extra workgroup sums K4's
+    // noise span from the copy the part brought along (`noise_src`) -- exact integers -- for the tail kernel.  A buffer
+    // that starts with the span needs nothing here: the tail adds up this kernel's own 512-sample block sums.
+    if (blockIdx.x == noise_block) {
+        unsigned long long s2 = 0, s1 = 0;
+        block_byte_moments(noise_src, 0, (size_t)2 * noise_samples, s2, s1);
+        if (threadIdx.x == 0)
+            sc->noise_S = (unsigned long long)(4ll * (long long)s2 - 4ll * up.off2 * (long long)s1 + (long long)up.off2 * up.off2 * (2ll * noise_samples));
+        return;
+    }
     __shared__ unsigned long long red_m[2][kScanThreads / 64];
     __shared__ double red_s[kScanThreads / 64];
     __shared__ long long red_f[kScanThreads / 64];
@@ -1033,18 +1044,14 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
     const uint4* v = reinterpret_cast<const uint4*>(iq + b0);
     // Everything comes from the per-sample m = (2I-255)^2 + (2Q-255)^2 (exact integers, three instructions per
     // sample): amplitudes are sqrt(m) / 255, chunk power is sum(m) / (4 n), the K4 sums are sums of m.
-    unsigned S = 0, nS = 0;                                        // per lane: <= 16 vectors x 8 x 130050 < 2^32
+    unsigned S = 0;                                                // per lane: <= 16 vectors x 8 x 130050 < 2^32
     double sum = 0.0;                                              // sum of sqrt(m); scaled by 1/255 once per tile
     long long first = 0x7fffffffffffffffll;
-    const bool in_noise = b0 < noise_bytes;                        // tile touches the K4 noise span
     unsigned k2 = 0x00020002u, km255 = pk_minus_off2(up.off2);
     asm volatile("" : "+v"(k2), "+v"(km255));                      // keep both in VGPRs (one constant-bus slot per op)
     // `live` is false only for the lanes past the end of a partial last tile (see below): they take
     // part in the wave-wide reductions with zero contributions
-    // noise_c: std::true_type in the few tiles that touch K4's noise span (the first 400 KB of a capture), false_type
-    // everywhere else -- the other 16 377 tiles of a GiB do not pay for the span test
-    auto body = [&](const uint4& q, unsigned i, const bool live, auto noise_c) {   // i: vector index inside the tile (< 4096)
-        constexpr bool NOISE = decltype(noise_c)::value;
+    auto body = [&](const uint4& q, unsigned i, const bool live) {   // i: vector index inside the tile (< 4096)
         const unsigned ws[4] = {q.x, q.y, q.z, q.w};
         int m[8];
 #pragma unroll
@@ -1064,30 +1071,19 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
         }
         const unsigned m8 = live ? (unsigned)(((m[0] + m[1]) + (m[2] + m[3])) + ((m[4] + m[5]) + (m[6] + m[7]))) : 0u;
         S += m8;
-        if constexpr (NOISE) {
-            if (b0 + ((size_t)i << 4) < noise_bytes) nS += m8;      // noise_bytes % 16 == 0
-        }
         // block sum of 4|z|^2 over the wave = one 512-sample block
         const int c512 = wave_sum_lane63((int)m8);
         if ((tid & 63) == 63) cblk[(b0 >> 10) + (i >> 6)] = (unsigned)c512;
         sum += (double)(live ? part : 0.f);
     };
-    if (nvec == kScanTile / 16 && !in_noise) {
+    if (nvec == kScanTile / 16) {
         // full tile: 16 vectors per lane, four 16-byte loads in flight before the arithmetic starts
         for (unsigned i = tid; i < (unsigned)(kScanTile / 16); i += 4 * kScanThreads) {
             const uint4 q0 = v[i], q1 = v[i + kScanThreads], q2 = v[i + 2 * kScanThreads], q3 = v[i + 3 * kScanThreads];
-            body(q0, i, true, std::false_type{});
-            body(q1, i + kScanThreads, true, std::false_type{});
-            body(q2, i + 2 * kScanThreads, true, std::false_type{});
-            body(q3, i + 3 * kScanThreads, true, std::false_type{});
-        }
-    } else if (nvec == kScanTile / 16) {
-        for (unsigned i = tid; i < (unsigned)(kScanTile / 16); i += 4 * kScanThreads) {
-            const uint4 q0 = v[i], q1 = v[i + kScanThreads], q2 = v[i + 2 * kScanThreads], q3 = v[i + 3 * kScanThreads];
-            body(q0, i, true, std::true_type{});
-            body(q1, i + kScanThreads, true, std::true_type{});
-            body(q2, i + 2 * kScanThreads, true, std::true_type{});
-            body(q3, i + 3 * kScanThreads, true, std::true_type{});
+            body(q0, i, true);
+            body(q1, i + kScanThreads, true);
+            body(q2, i + 2 * kScanThreads, true);
+            body(q3, i + 3 * kScanThreads, true);
         }
     } else {
         // partial last tile: the trip count is WAVE-uniform (the 512-sample block sums are reduced
@@ -1098,8 +1094,7 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
             const unsigned i = ib + lane;
             const bool live = i < (unsigned)nvec;
             const uint4 q = live ? v[i] : uint4{0u, 0u, 0u, 0u};
-            if (in_noise) body(q, i, live, std::true_type{});
-            else body(q, i, live, std::false_type{});
+            body(q, i, live);
         }
     }
     // ragged end of the stream (< 8 samples): one lane, scalar
@@ -1128,10 +1123,6 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
             c = group_sum_dpp<64>(c);
             if (tid == 0) cblk[jb] = (unsigned)c;
         }
-    }
-    if (in_noise) {
-        const unsigned long long wn = wave_sum_u64(nS);
-        if ((tid & 63) == 0) atomicAdd(&sc->noise_S, wn);
     }
     if constexpr (!TRACK_FIRST) {
         if (tid == 0 && b1 > b0) first = (long long)(b0 >> 1);   // threshold below the smallest amplitude
@@ -1193,7 +1184,6 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
 constexpr int kTailBlocks = 2048;                       // 512-sample blocks screened per onset workgroup (1 Mi samples)
 constexpr int kTailHalo = (kOnsetMaxWin + 510) / 512 + 1;
 constexpr int kTailPre = kTailBlocks + kTailHalo + (kTailBlocks + kTailHalo) / 32 + 8;
-constexpr int kTailTileBlocks = kOnsetOut / 512;        // the exact scan looks at 2048 positions = 4 blocks at a time
 
 struct TailRec {
     unsigned long long first;   // first position of the workgroup's range whose moving average crosses, ~0: none
@@ -1207,6 +1197,7 @@ struct TailArgs {
     unsigned long long nsamples;     // of that buffer
     long long sample0;               // capture index of iq[0] (0 for a whole capture)
     unsigned long long total_samples;   // of the whole capture (slot validity)
+    unsigned long long slot_nsamples;   // samples of the buffer a slice may be cut from (>= nsamples: a part's tail)
     int has_thr, is_part, valid, has_slot;
     // threshold role
     float* power;
@@ -1435,7 +1426,6 @@ __device__ void tail_onset_range(const TailArgs& A, unsigned w, unsigned* pre_c,
 __device__ void tail_onset_finish(const TailArgs& A, TailShared& sh) {
     const int tid = threadIdx.x;
     const int window = A.window;
-    long long start_index = -1;
     if (A.valid) {
         unsigned long long wmin = ~0ull;
         for (unsigned w = tid; w < A.nct; w += kScanThreads)
@@ -1479,7 +1469,7 @@ __device__ void tail_onset_finish(const TailArgs& A, TailShared& sh) {
     }
     __syncthreads();
     if (A.has_slot)
-        tdoa_slot_body(A.iq, (size_t)A.nsamples, sh.start, (size_t)A.slice_samples, A.slot, A.sample0, (size_t)A.total_samples,
+        tdoa_slot_body(A.iq, (size_t)A.slot_nsamples, sh.start, (size_t)A.slice_samples, A.slot, A.sample0, (size_t)A.total_samples,
                        (size_t)tid, (size_t)kScanThreads, tid == 0);
 }
 
@@ -1565,12 +1555,13 @@ struct ScanState {
     size_t nbytes, chunk_bytes, own_bytes, nsamples, own_samples, ntiles, skip, own_tiles, nchunks, tpc, noise_bytes;
     float eps, rssi_threshold, factor;
     int flags, noise_samples, window, valid;
-    bool noise_fused, noise_here, track, is_part;
+    bool noise_here, track, is_part;
     float* d_power;
     gj_amp_stats* d_amp;
     gj_onset* d_onset;
     ScanPart part;
-    size_t off_tiles, off_acc, off_blk;
+    size_t off_tiles, off_acc, off_blk, off_rec;
+    unsigned nct;   // onset workgroups of the tail
 };
 static_assert(sizeof(ScanState) <= sizeof(ScanJob::state), "ScanJob::state too small");
 
@@ -1608,10 +1599,10 @@ static int scan_begin_impl(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size
     // triangulateTDOA.py:39 speaks of the whole capture; a part must itself hold at least one window
     const size_t total_samples = part ? part->total_samples : st.nsamples;
     st.valid = total_samples >= (size_t)noise_samples + (size_t)window && st.nsamples >= (size_t)window;
-    // the K4 noise span rides along in the same pass when the buffer starts with it and it ends on a 16-byte boundary
+    // K4's noise sum: a buffer that starts with the span gets it from the scan's own block sums (tail kernel); a part
+    // that does not hold the span brings a copy (d_noise), summed by one extra workgroup of the scan launch
     st.noise_bytes = (size_t)2 * noise_samples;
     st.noise_here = !part || (part->buf_sample0 == 0 && st.noise_bytes <= nbytes);
-    st.noise_fused = st.valid && st.noise_here && (st.noise_bytes % 16 == 0);
     if (st.valid && !st.noise_here && !part->d_noise)
         return fail(ctx, GJ_ERR_INVALID, "this part does not hold the capture's noise span (%zu bytes): d_noise is required", st.noise_bytes);
     // When the offset is a half-integer (off2 odd) no component of 2u - off2 is zero, so every amplitude is at
@@ -1621,10 +1612,17 @@ static int scan_begin_impl(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size
     const Unpack upk = unpack_of(ctx);
     const bool all_hit = (ctx->off2 & 1) && (sqrtf(2.0f) * upk.half_scale > rssi_threshold);
     st.track = !all_hit;
-    memcpy(job.state, &st, sizeof(st));
     job.ntiles = st.ntiles;
     job.nchunks = st.nchunks;
-    job.ws_bytes = align_up(st.off_blk + (nblk + 16) * sizeof(unsigned), 256);
+    st.off_rec = align_up(st.off_blk + (nblk + 16) * sizeof(unsigned), 256);
+    {
+        const size_t nout = st.valid ? st.nsamples - (size_t)window + 1 : 0;
+        const size_t nct = st.valid ? ((nout + 511) / 512 + kTailBlocks - 1) / kTailBlocks : 1;
+        if (nct > 0x7ffffff0ull) return fail(ctx, GJ_ERR_UNSUPPORTED, "capture too long");
+        st.nct = (unsigned)nct;
+    }
+    memcpy(job.state, &st, sizeof(st));
+    job.ws_bytes = align_up(st.off_rec + (size_t)st.nct * sizeof(TailRec), 256);
     job.ws = nullptr;
     return GJ_OK;
 }
@@ -1640,7 +1638,8 @@ int scan_begin(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_byt
 int scan_start(gj_ctx* ctx, ScanJob& job) {
     ScanState st;
     memcpy(&st, job.state, sizeof(st));
-    GJ_HIP(ctx, hipMemsetAsync(job.ws, 0, sizeof(OnsetScratch), ctx->stream));
+    // chunks of several tiles accumulate by atomics; nothing else needs clearing (the tail kernel reads only what this
+    // job's launches have written, and its arrival counter is kept at zero by its own last workgroup)
     if (st.tpc > 1) GJ_HIP(ctx, hipMemsetAsync(job.ws + st.off_acc, 0, st.nchunks * 16, ctx->stream));
     return GJ_OK;
 }
@@ -1656,67 +1655,91 @@ int scan_range(gj_ctx* ctx, const ScanJob& job, size_t tile0, size_t tile1) {
     unsigned* cblk = reinterpret_cast<unsigned*>(job.ws + st.off_blk);
     const Unpack upk = unpack_of(ctx);
     const unsigned n = (unsigned)(tile1 - tile0);
+    // a part without the capture's noise span: one more workgroup, with the first range of tiles
+    const bool noise_wg = st.valid && !st.noise_here && tile0 == 0;
+    const unsigned noise_block = noise_wg ? n : 0xffffffffu;
+    const dim3 grid(n + (noise_wg ? 1u : 0u));
     if (st.track)
-        hipLaunchKernelGGL(stream_scan_kernel<true>, dim3(n), dim3(kScanThreads), 0, ctx->stream, st.d_iq, st.nsamples,
+        hipLaunchKernelGGL(stream_scan_kernel<true>, grid, dim3(kScanThreads), 0, ctx->stream, st.d_iq, st.nsamples,
                            st.own_bytes, st.chunk_bytes, (unsigned)st.tpc, st.eps, st.flags, st.d_power, acc, st.rssi_threshold,
-                           tiles, cblk, st.noise_fused ? st.noise_bytes : (size_t)0, sc, upk, (unsigned)st.skip, (unsigned)tile0);
+                           tiles, cblk, upk, (unsigned)st.skip, (unsigned)tile0, noise_block, st.part.d_noise, st.noise_samples, sc);
     else
-        hipLaunchKernelGGL(stream_scan_kernel<false>, dim3(n), dim3(kScanThreads), 0, ctx->stream, st.d_iq, st.nsamples,
+        hipLaunchKernelGGL(stream_scan_kernel<false>, grid, dim3(kScanThreads), 0, ctx->stream, st.d_iq, st.nsamples,
                            st.own_bytes, st.chunk_bytes, (unsigned)st.tpc, st.eps, st.flags, st.d_power, acc, st.rssi_threshold,
-                           tiles, cblk, st.noise_fused ? st.noise_bytes : (size_t)0, sc, upk, (unsigned)st.skip, (unsigned)tile0);
+                           tiles, cblk, upk, (unsigned)st.skip, (unsigned)tile0, noise_block, st.part.d_noise, st.noise_samples, sc);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
 }
 
-int scan_end(gj_ctx* ctx, const ScanJob& job) {
+int scan_end(gj_ctx* ctx, const ScanJob& job, const ScanExtra* extra) {
     ScanState st;
     memcpy(&st, job.state, sizeof(st));
     OnsetScratch* sc = reinterpret_cast<OnsetScratch*>(job.ws);
     AmpTile* tiles = st.is_part ? st.part.d_tiles : reinterpret_cast<AmpTile*>(job.ws + st.off_tiles);
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(job.ws + st.off_acc);
-    unsigned* cblk = reinterpret_cast<unsigned*>(job.ws + st.off_blk);
-    const Unpack upk = unpack_of(ctx);
-    const uint8_t* d_iq = st.d_iq;
     const size_t halo = st.is_part ? st.part.halo_bytes : 0;
     if (st.tpc > 1) {
         hipLaunchKernelGGL(chunk_power_finalize_kernel, dim3((unsigned)((st.nchunks + 255) / 256)), dim3(256), 0,
                            ctx->stream, acc, st.nchunks, st.own_bytes, st.chunk_bytes, st.eps, st.flags, st.d_power, ctx->off2, true);
         GJ_LAUNCH_CHECK(ctx);
     }
-    // amplitude totals + the chunk-power edge cases (last chunk odd / without a complete pair)
-    if (st.is_part)
-        hipLaunchKernelGGL(amp_part_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, d_iq + halo, st.own_samples, tiles,
-                           st.own_tiles, st.part.buf_sample0 + (long long)(halo / 2), st.part.d_amp, upk, st.d_power, st.nchunks,
-                           st.own_bytes, st.chunk_bytes, st.flags);
-    else
-        hipLaunchKernelGGL(amp_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, d_iq, st.nsamples, tiles, st.ntiles, st.d_amp,
-                           upk, st.d_power, st.nchunks, st.nbytes, st.chunk_bytes, st.flags);
-    GJ_LAUNCH_CHECK(ctx);
-    if (st.valid) {
-        if (!st.noise_fused) {
-            hipLaunchKernelGGL(onset_noise_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream,
-                               st.noise_here ? d_iq : st.part.d_noise, st.noise_samples, sc, ctx->off2);
-            GJ_LAUNCH_CHECK(ctx);
-        }
-        const size_t nout = st.nsamples - st.window + 1;
-        const size_t nct = ((nout + 511) / 512 + kCoarseBlocks - 1) / kCoarseBlocks;
-        hipLaunchKernelGGL(onset_coarse_kernel<512>, dim3((unsigned)nct), dim3(kScanThreads), 0, ctx->stream, d_iq,
-                           (const unsigned*)cblk, st.nsamples, st.window, st.noise_samples, st.factor, sc, ctx->off2);
-        GJ_LAUNCH_CHECK(ctx);
-        const size_t nt = (nout + kOnsetOut - 1) / kOnsetOut;
-        hipLaunchKernelGGL(onset_scan_kernel, dim3((unsigned)(nt < 256 ? nt : 256)), dim3(kScanThreads), 0, ctx->stream,
-                           d_iq, st.nsamples, st.window, sc, ctx->off2);
-        GJ_LAUNCH_CHECK(ctx);
+    TailArgs A;
+    memset(&A, 0, sizeof(A));
+    A.iq = st.d_iq;
+    A.nsamples = st.nsamples;
+    A.sample0 = st.is_part ? st.part.buf_sample0 : 0ll;
+    A.total_samples = st.is_part ? st.part.total_samples : st.nsamples;
+    A.is_part = st.is_part;
+    A.valid = st.valid;
+    A.power = st.d_power;
+    A.nchunks = st.nchunks;
+    if (extra && extra->d_stats && st.nchunks) {
+        A.has_thr = 1;
+        A.pct = extra->pct;
+        A.ratio = (float)pow(10.0, (double)extra->rise_db / 10.0);
+        A.stats = extra->d_stats;
+        A.mask = extra->d_mask;
     }
-    hipLaunchKernelGGL(onset_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, d_iq, sc, st.window, st.valid, st.d_onset,
-                       ctx->off2, st.is_part ? st.part.buf_sample0 : 0ll);
+    A.own_iq = st.d_iq + halo;
+    A.own_samples = st.own_samples;
+    A.own_tiles = st.own_tiles;
+    A.own_bytes = st.own_bytes;
+    A.chunk_bytes = st.chunk_bytes;
+    A.tiles = tiles;
+    A.amp = st.d_amp;
+    A.amp_part = st.part.d_amp;
+    A.own_sample0 = A.sample0 + (long long)(halo / 2);
+    A.flags = st.flags;
+    A.window = st.window;
+    A.noise_samples = st.noise_samples;
+    A.noise_in_scratch = st.valid && !st.noise_here;
+    A.factor = st.factor;
+    A.cblk = reinterpret_cast<const unsigned*>(job.ws + st.off_blk);
+    A.sc = sc;
+    A.rec = reinterpret_cast<TailRec*>(job.ws + st.off_rec);
+    A.arrive = ctx->d_sync + kSyncTail;
+    A.nct = st.nct;
+    A.onset = st.d_onset;
+    if (extra && extra->d_slot) {
+        if (extra->slice_samples < 1) return fail(ctx, GJ_ERR_INVALID, "n_samples must be >= 1");
+        if ((reinterpret_cast<uintptr_t>(extra->d_slot) & 15) != 0) return fail(ctx, GJ_ERR_INVALID, "slot must be 16-byte aligned");
+        A.has_slot = 1;
+        A.slot = extra->d_slot;
+        A.slice_samples = extra->slice_samples;
+        A.slot_nsamples = extra->slot_buf_bytes ? extra->slot_buf_bytes / 2 : st.nsamples;
+    }
+    A.up = unpack_of(ctx);
+    const int needx = kOnsetOut + st.window - 1;
+    const size_t dyn = (size_t)(needx + needx / 32 + 8) * sizeof(unsigned);
+    const unsigned grid = (A.has_thr ? 1u : 0u) + 1u + st.nct;
+    hipLaunchKernelGGL(scan_tail_kernel, dim3(grid), dim3(kScanThreads), dyn, ctx->stream, A);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
 }
 
 static int stream_scan_impl(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
                             float* d_power, float rssi_threshold, gj_amp_stats* d_amp, int noise_samples, int window,
-                            float factor, gj_onset* d_onset, const ScanPart* part) {
+                            float factor, gj_onset* d_onset, const ScanPart* part, const ScanExtra* extra = nullptr) {
     ScanJob job;
     int rc = scan_begin_impl(ctx, d_iq, nbytes, chunk_bytes, eps, flags, d_power, rssi_threshold, d_amp, noise_samples, window,
                              factor, d_onset, part, job);
@@ -1726,27 +1749,31 @@ static int stream_scan_impl(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, siz
     job.ws = ctx->ws;
     rc = scan_start(ctx, job);
     if (!rc) rc = scan_range(ctx, job, 0, job.ntiles);
-    if (!rc) rc = scan_end(ctx, job);
+    if (!rc) rc = scan_end(ctx, job, extra);
     return rc;
 }
 
 int launch_stream_scan(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
                        float* d_power, float rssi_threshold, gj_amp_stats* d_amp, int noise_samples, int window,
-                       float factor, gj_onset* d_onset) {
-    if (!scan_fusable(d_iq, nbytes, chunk_bytes)) {   // odd chunk sizes / unaligned captures: the three separate passes
+                       float factor, gj_onset* d_onset, const ScanExtra* extra) {
+    if (!scan_fusable(d_iq, nbytes, chunk_bytes)) {   // odd chunk sizes / unaligned captures: the separate passes
         int rc = launch_chunk_power(ctx, d_iq, nbytes, chunk_bytes, eps, flags, d_power);
         if (!rc) rc = launch_amp_stats(ctx, d_iq, nbytes, rssi_threshold, d_amp);
         if (!rc) rc = launch_onset(ctx, d_iq, nbytes, noise_samples, window, factor, d_onset);
+        if (!rc && extra && extra->d_stats && gj_chunk_count(nbytes, chunk_bytes))
+            rc = launch_power_threshold(ctx, d_power, gj_chunk_count(nbytes, chunk_bytes), extra->pct, extra->rise_db, extra->d_stats, extra->d_mask);
+        if (!rc && extra && extra->d_slot)
+            rc = launch_tdoa_slot(ctx, d_iq, nbytes, &d_onset->start_index, extra->slice_samples, extra->d_slot);
         return rc;
     }
     return stream_scan_impl(ctx, d_iq, nbytes, chunk_bytes, eps, flags, d_power, rssi_threshold, d_amp, noise_samples,
-                            window, factor, d_onset, nullptr);
+                            window, factor, d_onset, nullptr, extra);
 }
 
 // One part of a capture split over GPUs (include/gpsjam.h, gj_part_scan_dev).
 int launch_part_scan(gj_ctx* ctx, const gj_part_view& v, size_t chunk_bytes, float eps, int flags, float* d_power,
                      float rssi_threshold, void* d_tiles, gj_amp_part* d_amp, int noise_samples, int window, float factor,
-                     gj_onset* d_onset) {
+                     gj_onset* d_onset, const ScanExtra* extra) {
     if (v.own_first_byte < v.buf_first_byte || v.own_first_byte + v.own_bytes > v.buf_first_byte + v.buf_bytes ||
         v.own_first_byte + v.own_bytes > v.total_bytes)
         return fail(ctx, GJ_ERR_INVALID, "the own range does not lie inside the buffer / the capture");
@@ -1768,7 +1795,7 @@ int launch_part_scan(gj_ctx* ctx, const gj_part_view& v, size_t chunk_bytes, flo
     p.d_amp = d_amp;
     // the scan covers [halo][own]; what lies behind the own range in the buffer (the slice tail) is not scanned
     return stream_scan_impl(ctx, v.d_buf, halo + v.own_bytes, chunk_bytes, eps, flags, d_power, rssi_threshold, nullptr,
-                            noise_samples, window, factor, d_onset, &p);
+                            noise_samples, window, factor, d_onset, &p, extra);
 }
 
 size_t amp_tile_count(size_t nbytes) { return (nbytes / 2 * 2 + kScanTile - 1) / kScanTile; }

@@ -86,36 +86,38 @@ __device__ __forceinline__ void xc_passes(c2 (&v)[16], cf* lds, int base, int jl
     xc_passes_tw<N, 0>(v, lds, base, jl, twtab, none);
 }
 
-// start word of antenna a: an element of the caller's start array, or the flag word of a TDOA slot
-__global__ void xc_prepare_kernel(XcParams P, long long* __restrict__ eff, int* __restrict__ valid) {
-    const int a = threadIdx.x;
-    if (a >= P.n_ant) return;
+// start word of antenna a: an element of the caller's start array, or the flag word of a TDOA slot.  Read by every
+// workgroup that needs it (a wave-uniform 8-byte load) -- until round 5 a one-wave kernel of its own in front of the
+// transforms, i.e. one more dependent launch on a chain of six.
+__device__ __forceinline__ bool xc_start(const XcParams& P, int a, long long& eff) {
     const long long s = *P.start_ptr[a];
     const bool ok = s >= 0 && (unsigned long long)s + P.n <= P.nsamples[a];
-    valid[a] = ok;
-    eff[a] = ok ? s : 0;
+    eff = ok ? s : 0;
+    return ok;
 }
 
 // ---- column pass: transforms of length L1 over rows, a tile of 4096/L1 adjacent columns ----
 // MODE 0: forward, input = uint8 slice (zero-padded), output Y[a][k1][n2] * W_L^(k1 n2)
 // MODE 1: inverse tail, input = D[p][k1][n2], output = per-workgroup arg-max candidate
 template <int L1, int MODE>
-__global__ __launch_bounds__(kBlockThreads) void xc_cols_kernel(XcParams P, const long long* __restrict__ eff,
-                                                                const int* __restrict__ valid,
-                                                                const cf* __restrict__ twtab, cf* __restrict__ buf,
-                                                                XcCand* __restrict__ cand) {
+__global__ __launch_bounds__(kBlockThreads) void xc_cols_kernel(XcParams P, const cf* __restrict__ twtab, cf* __restrict__ buf,
+                                                                XcCand* __restrict__ cand, unsigned* __restrict__ arrive,
+                                                                int* __restrict__ lags, float* __restrict__ peaks,
+                                                                float* __restrict__ margins) {
     constexpr int TF = L1 / 16, B = kBlockPoints / L1;
     constexpr int RS = lds_span(L1) + 1;   // LDS region stride: b-fastest lanes land on different banks
     __shared__ cf lds[B * RS + 16];
     __shared__ XcCand red[kBlockThreads / 64];
+    __shared__ int last_s;
     const int tid = threadIdx.x;
     const int b = tid % B, jl = tid / B;
     const int t = blockIdx.y;   // antenna (MODE 0) or pair (MODE 1)
     const int n2 = blockIdx.x * B + b;
     c2 v[16];
     if constexpr (MODE == 0) {
-        const bool ok = valid[t] != 0;
-        const uint16_t* src = reinterpret_cast<const uint16_t*>(P.iq[t]) + (ok ? eff[t] : 0);
+        long long eff;
+        const bool ok = xc_start(P, t, eff);
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(P.iq[t]) + eff;
         // L <= 2^24: every index fits 32 bits.  Branch-free: out-of-slice points read the slice's
         // first sample and are zeroed by a select (per-element branches made hipcc shuffle the
         // whole register array through AGPRs: 4800 instructions, 236 VGPRs)
@@ -177,10 +179,44 @@ __global__ __launch_bounds__(kBlockThreads) void xc_cols_kernel(XcParams P, cons
         }
         if ((tid & 63) == 0) red[tid >> 6] = c;
         __syncthreads();
+        // The pair's candidates meet in its LAST workgroup to finish (arrival counter of the pair, agent-scope release /
+        // acquire: gj_common.h), which picks the winner in candidate order -- the reduction a one-workgroup-per-pair
+        // kernel used to do in a launch of its own.  xc_merge is a total order with the runner-up carried along, so the
+        // result does not depend on who arrives last.
         if (tid == 0) {
             XcCand r = red[0];
             for (int k = 1; k < kBlockThreads / 64; ++k) r = xc_merge(r, red[k]);
             cand[(size_t)t * gridDim.x + blockIdx.x] = r;
+            const unsigned ticket = arrive_release(arrive + t);
+            const int last = ticket == gridDim.x - 1;
+            if (last) last_arriver_acquire(arrive + t);
+            last_s = last;
+        }
+        __syncthreads();
+        if (!last_s) return;
+        XcCand r{-1.f, 0x7fffffff, -1.f, 0};
+        for (unsigned k = tid; k < gridDim.x; k += kBlockThreads) r = xc_merge(r, cand[(size_t)t * gridDim.x + k]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            XcCand o;
+            o.val = __shfl_xor(r.val, off, 64);
+            o.m = __shfl_xor(r.m, off, 64);
+            o.val2 = __shfl_xor(r.val2, off, 64);
+            o.pad = 0;
+            r = xc_merge(r, o);
+        }
+        if ((tid & 63) == 0) red[tid >> 6] = r;
+        __syncthreads();
+        if (tid == 0) {
+            r = red[0];
+            for (int k = 1; k < kBlockThreads / 64; ++k) r = xc_merge(r, red[k]);
+            long long e;
+            const bool ok = xc_start(P, P.pair_i[t], e) && xc_start(P, P.pair_j[t], e);
+            lags[t] = ok ? r.m - (int)(P.n - 1) : GJ_LAG_INVALID;
+            // inputs were 2(u-127.5): |c| = sqrt(val) / L / 4
+            peaks[t] = ok ? sqrtf(r.val) * (0.25f / (float)P.L) : 0.f;
+            // relative gap between the peak and the largest |c| at any other lag
+            if (margins) margins[t] = (ok && r.val > 0.f) ? 1.0f - sqrtf(fmaxf(r.val2, 0.f) / r.val) : 0.f;
         }
     }
 }
@@ -265,29 +301,6 @@ __global__ __launch_bounds__(kBlockThreads) void xc_rows_pair_kernel(XcParams P,
     }
 }
 
-__global__ __launch_bounds__(256) void xc_finalize_kernel(XcParams P, const XcCand* __restrict__ cand, unsigned ncand,
-                                                          const int* __restrict__ valid, int* __restrict__ lags,
-                                                          float* __restrict__ peaks, float* __restrict__ margins) {
-    __shared__ XcCand red[256];
-    const int p = blockIdx.x;
-    XcCand r{-1.f, 0x7fffffff, -1.f, 0};
-    for (unsigned k = threadIdx.x; k < ncand; k += blockDim.x) r = xc_merge(r, cand[(size_t)p * ncand + k]);
-    red[threadIdx.x] = r;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) red[threadIdx.x] = xc_merge(red[threadIdx.x], red[threadIdx.x + off]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const bool ok = valid[P.pair_i[p]] && valid[P.pair_j[p]];
-        lags[p] = ok ? red[0].m - (int)(P.n - 1) : GJ_LAG_INVALID;
-        // inputs were 2(u-127.5): |c| = sqrt(val) / L / 4
-        peaks[p] = ok ? sqrtf(red[0].val) * (0.25f / (float)P.L) : 0.f;
-        // relative gap between the peak and the largest |c| at any other lag
-        if (margins) margins[p] = (ok && red[0].val > 0.f) ? 1.0f - sqrtf(fmaxf(red[0].val2, 0.f) / red[0].val) : 0.f;
-    }
-}
-
 static unsigned long long xc_fft_len(size_t n) {
     unsigned long long L = 65536;
     while (L < 2ull * n - 1) L <<= 1;
@@ -302,29 +315,30 @@ size_t xcorr_workspace(gj_ctx*, int n_ant, size_t n_samples, int n_pairs) {
 }
 
 template <int L1>
-static void xc_launch_cols(gj_ctx* ctx, int mode, const XcParams& P, int count, const long long* eff, const int* valid,
-                           cf* buf, XcCand* cand) {
+static void xc_launch_cols(gj_ctx* ctx, int mode, const XcParams& P, int count, cf* buf, XcCand* cand, int* lags, float* peaks,
+                           float* margins) {
     const dim3 grid((unsigned)(P.L / kBlockPoints), (unsigned)count);
+    unsigned* arrive = ctx->d_sync + kSyncXcorr;
     if (mode == 0)
-        hipLaunchKernelGGL((xc_cols_kernel<L1, 0>), grid, dim3(kBlockThreads), 0, ctx->stream, P, eff, valid,
-                           ctx->d_twiddle, buf, cand);
+        hipLaunchKernelGGL((xc_cols_kernel<L1, 0>), grid, dim3(kBlockThreads), 0, ctx->stream, P, ctx->d_twiddle, buf, cand, arrive,
+                           lags, peaks, margins);
     else
-        hipLaunchKernelGGL((xc_cols_kernel<L1, 1>), grid, dim3(kBlockThreads), 0, ctx->stream, P, eff, valid,
-                           ctx->d_twiddle, buf, cand);
+        hipLaunchKernelGGL((xc_cols_kernel<L1, 1>), grid, dim3(kBlockThreads), 0, ctx->stream, P, ctx->d_twiddle, buf, cand, arrive,
+                           lags, peaks, margins);
 }
 
-static void xc_cols(gj_ctx* ctx, int mode, const XcParams& P, int count, const long long* eff, const int* valid, cf* buf,
-                    XcCand* cand) {
+static void xc_cols(gj_ctx* ctx, int mode, const XcParams& P, int count, cf* buf, XcCand* cand, int* lags = nullptr,
+                    float* peaks = nullptr, float* margins = nullptr) {
     switch (P.L1) {
-        case 16: xc_launch_cols<16>(ctx, mode, P, count, eff, valid, buf, cand); break;
-        case 32: xc_launch_cols<32>(ctx, mode, P, count, eff, valid, buf, cand); break;
-        case 64: xc_launch_cols<64>(ctx, mode, P, count, eff, valid, buf, cand); break;
-        case 128: xc_launch_cols<128>(ctx, mode, P, count, eff, valid, buf, cand); break;
-        case 256: xc_launch_cols<256>(ctx, mode, P, count, eff, valid, buf, cand); break;
-        case 512: xc_launch_cols<512>(ctx, mode, P, count, eff, valid, buf, cand); break;
-        case 1024: xc_launch_cols<1024>(ctx, mode, P, count, eff, valid, buf, cand); break;
-        case 2048: xc_launch_cols<2048>(ctx, mode, P, count, eff, valid, buf, cand); break;
-        default: xc_launch_cols<4096>(ctx, mode, P, count, eff, valid, buf, cand); break;
+        case 16: xc_launch_cols<16>(ctx, mode, P, count, buf, cand, lags, peaks, margins); break;
+        case 32: xc_launch_cols<32>(ctx, mode, P, count, buf, cand, lags, peaks, margins); break;
+        case 64: xc_launch_cols<64>(ctx, mode, P, count, buf, cand, lags, peaks, margins); break;
+        case 128: xc_launch_cols<128>(ctx, mode, P, count, buf, cand, lags, peaks, margins); break;
+        case 256: xc_launch_cols<256>(ctx, mode, P, count, buf, cand, lags, peaks, margins); break;
+        case 512: xc_launch_cols<512>(ctx, mode, P, count, buf, cand, lags, peaks, margins); break;
+        case 1024: xc_launch_cols<1024>(ctx, mode, P, count, buf, cand, lags, peaks, margins); break;
+        case 2048: xc_launch_cols<2048>(ctx, mode, P, count, buf, cand, lags, peaks, margins); break;
+        default: xc_launch_cols<4096>(ctx, mode, P, count, buf, cand, lags, peaks, margins); break;
     }
 }
 
@@ -333,6 +347,7 @@ int launch_xcorr(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, 
                  float* d_peaks, float* d_margins) {
     if (n_ant < 1 || n_ant > GJ_MAX_ANTENNAS) return fail(ctx, GJ_ERR_INVALID, "n_ant must be 1..%d", GJ_MAX_ANTENNAS);
     if (n_pairs < 1 || n_pairs > kMaxPairs) return fail(ctx, GJ_ERR_INVALID, "n_pairs must be 1..%d", kMaxPairs);
+    static_assert(kSyncXcorr + kMaxPairs <= kSyncWords, "one arrival counter per pair");
     if (n_samples < 1) return fail(ctx, GJ_ERR_INVALID, "n_samples must be >= 1");
     if (n_samples > (1ull << 23)) return fail(ctx, GJ_ERR_UNSUPPORTED, "slice longer than 2^23 samples");
     XcParams P;
@@ -358,16 +373,13 @@ int launch_xcorr(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, 
     const size_t need = xcorr_workspace(ctx, n_ant, n_samples, n_pairs);
     int rc = ensure_workspace(ctx, need);
     if (rc) return rc;
-    const size_t ncand = (size_t)(P.L / kBlockPoints);
     cf* spec = reinterpret_cast<cf*>(ctx->ws);
     cf* dbuf = spec + (size_t)n_ant * P.L;
     XcCand* cand = reinterpret_cast<XcCand*>(dbuf + (size_t)n_pairs * P.L);
-    long long* eff = reinterpret_cast<long long*>(cand + (size_t)n_pairs * ncand);
-    int* valid = reinterpret_cast<int*>(eff + GJ_MAX_ANTENNAS);
 
-    hipLaunchKernelGGL(xc_prepare_kernel, dim3(1), dim3(64), 0, ctx->stream, P, eff, valid);
-    GJ_LAUNCH_CHECK(ctx);
-    xc_cols(ctx, 0, P, n_ant, eff, valid, spec, nullptr);
+    // three launches: forward columns (unpack + zero-pad fused), rows (both forward row transforms, the product and the
+    // inverse row transform per pair), inverse columns with |.|^2, arg-max and the pair's final pick fused
+    xc_cols(ctx, 0, P, n_ant, spec, nullptr);
     GJ_LAUNCH_CHECK(ctx);
     if (n_pairs <= 2 * n_ant) {
         hipLaunchKernelGGL(xc_rows_pair_kernel, dim3((unsigned)P.L1, (unsigned)n_pairs), dim3(kBlockThreads), 0, ctx->stream,
@@ -381,10 +393,7 @@ int launch_xcorr(gj_ctx* ctx, const uint8_t* const* d_iq, const size_t* nbytes, 
                            ctx->stream, P, ctx->d_twiddle, spec, dbuf);
         GJ_LAUNCH_CHECK(ctx);
     }
-    xc_cols(ctx, 1, P, n_pairs, eff, valid, dbuf, cand);
-    GJ_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(xc_finalize_kernel, dim3((unsigned)n_pairs), dim3(256), 0, ctx->stream, P, cand, (unsigned)ncand,
-                       valid, d_lags, d_peaks, d_margins);
+    xc_cols(ctx, 1, P, n_pairs, dbuf, cand, d_lags, d_peaks, d_margins);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
 }

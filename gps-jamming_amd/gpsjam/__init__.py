@@ -632,6 +632,23 @@ class Device:
                                                  _ptr(d_power), rssi_threshold, _ptr(d_amp), noise_samples,
                                                  window, factor, _ptr(d_onset)))
 
+    @staticmethod
+    def _scan_extra(d_stats, d_mask, pct, rise_db, slice_samples, d_slot):
+        return _ffi.ScanExtra(float(pct), float(rise_db), _ptr(d_stats) or None, _ptr(d_mask) or None,
+                              int(slice_samples) if d_slot is not None else 0, _ptr(d_slot) or None)
+
+    def capture_scan_dev(self, d_iq, nbytes, chunk_bytes, d_power, rssi_threshold, d_amp, noise_samples, window,
+                         factor, d_onset, *, d_stats=None, d_mask=None, pct=5.0, rise_db=6.0, slice_samples=0, d_slot=None,
+                         eps=1e-10, flags=0):
+        """The per-capture side chain in two launches (gj_capture_scan_dev): the fused pass, then one tail launch with
+        the noise-floor threshold (``d_stats`` / ``d_mask``), the amplitude totals, the onset record and the TDOA slot cut
+        at that onset (``d_slot``, ``slice_samples``).  Same results as stream_scan_dev + power_threshold_dev +
+        tdoa_slot_dev."""
+        x = self._scan_extra(d_stats, d_mask, pct, rise_db, slice_samples, d_slot)
+        self._check(self._lib.gj_capture_scan_dev(self._ctx, _ptr(d_iq), nbytes, chunk_bytes, eps, flags,
+                                                  _ptr(d_power), rssi_threshold, _ptr(d_amp), noise_samples,
+                                                  window, factor, _ptr(d_onset), C.byref(x)))
+
     def tdoa_slot_bytes(self, n_samples: int) -> int:
         return self._lib.gj_tdoa_slot_bytes(n_samples)
 
@@ -673,6 +690,14 @@ class Device:
         self._check(self._lib.gj_part_scan_dev(self._ctx, C.byref(view), chunk_bytes, eps, flags, _ptr(d_power),
                                                rssi_threshold, _ptr(d_tiles), _ptr(d_amp), noise_samples, window, factor,
                                                _ptr(d_onset)))
+
+    def part_capture_scan_dev(self, view, chunk_bytes, d_power, rssi_threshold, d_tiles, d_amp, noise_samples, window,
+                              factor, d_onset, *, slice_samples=0, d_slot=None, eps=1e-10, flags=0):
+        """part_scan_dev + part_slot_dev (at the part's own onset) in two launches (gj_part_capture_scan_dev)."""
+        x = self._scan_extra(None, None, 5.0, 6.0, slice_samples, d_slot)
+        self._check(self._lib.gj_part_capture_scan_dev(self._ctx, C.byref(view), chunk_bytes, eps, flags, _ptr(d_power),
+                                                       rssi_threshold, _ptr(d_tiles), _ptr(d_amp), noise_samples, window,
+                                                       factor, _ptr(d_onset), C.byref(x)))
 
     def part_welch_dev(self, view, chunk_samples, nperseg, fs, d_psd, d_psd_db=None, shift=True):
         self._check(self._lib.gj_part_welch_dev(self._ctx, C.byref(view), chunk_samples, nperseg, fs,

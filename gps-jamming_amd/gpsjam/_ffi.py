@@ -64,6 +64,12 @@ class IngestResult(C.Structure):
                 ("onset", Onset), ("upload_ms", C.c_float), ("total_ms", C.c_float)]
 
 
+class ScanExtra(C.Structure):
+    """gj_scan_extra: what the scan's tail launch does on top of K1 + K3 + K4 (threshold of the power map, TDOA slot)."""
+    _fields_ = [("pct", C.c_float), ("rise_db", C.c_float), ("d_stats", C.c_void_p), ("d_mask", C.c_void_p),
+                ("slice_samples", C.c_size_t), ("d_slot", C.c_void_p)]
+
+
 class PartView(C.Structure):
     """gj_part_view: one part of a capture split over GPUs (include/gpsjam.h)."""
     _fields_ = [("d_buf", C.c_void_p), ("buf_bytes", C.c_size_t), ("buf_first_byte", C.c_size_t),
@@ -167,6 +173,7 @@ SIGNATURES = {
     "gj_onset_dev": (_i, [_vp, _vp, _sz, _i, _i, _f, _vp]),
     "gj_onset_u8": (_i, [_vp, _vp, _sz, _i, _i, _f, C.POINTER(Onset), _pf]),
     "gj_stream_scan_dev": (_i, [_vp, _vp, _sz, _sz, _f, _i, _vp, _f, _vp, _i, _i, _f, _vp]),
+    "gj_capture_scan_dev": (_i, [_vp, _vp, _sz, _sz, _f, _i, _vp, _f, _vp, _i, _i, _f, _vp, C.POINTER(ScanExtra)]),
     "gj_xcorr_lags_dev": (_i, [_vp, C.POINTER(_vp), _psz, _i, _vp, _sz, C.POINTER(C.c_int32), _i,
                                _vp, _vp, _vp]),
     "gj_xcorr_lags_u8": (_i, [_vp, C.POINTER(_vp), _i, _sz, C.POINTER(C.c_int32), _i,
@@ -176,6 +183,8 @@ SIGNATURES = {
     "gj_xcorr_slots_dev": (_i, [_vp, _vp, _sz, _i, _sz, C.POINTER(C.c_int32), _i, _vp, _vp, _vp]),
     "gj_amp_tile_count": (_sz, [_sz]),
     "gj_part_scan_dev": (_i, [_vp, C.POINTER(PartView), _sz, _f, _i, _vp, _f, _vp, _vp, _i, _i, _f, _vp]),
+    "gj_part_capture_scan_dev": (_i, [_vp, C.POINTER(PartView), _sz, _f, _i, _vp, _f, _vp, _vp, _i, _i, _f, _vp,
+                                      C.POINTER(ScanExtra)]),
     "gj_part_welch_dev": (_i, [_vp, C.POINTER(PartView), _sz, _i, _d, _i, _vp, _vp]),
     "gj_part_welch_workspace": (_sz, [_vp, C.POINTER(PartView), _sz, _i]),
     "gj_part_slot_dev": (_i, [_vp, C.POINTER(PartView), _vp, _sz, _vp]),

@@ -7,10 +7,11 @@ the third arrangement, and for captures of the reference's size (10 s = 41 MB) t
 capture is a dozen launches that each take microseconds, so what counts is how many dependent launches stand in a row,
 not bytes.  Per step:
   main stream      K2 (Welch PSD) of every capture, one after the other -- a K2 launch fills the chip
-  side stream a    capture a's fused scan (K1 power map, K3 amplitude statistics, K4 onset) -> noise-floor threshold ->
-                   TDOA slot; the captures' chains are independent of each other and run on streams of their own (up to
-                   three, each tested to run beside the others: gpsjam/streams.py), so they overlap instead of queueing
-  side stream 0    after all slots: K5 over every antenna pair
+  side stream a    capture a's fused scan (K1 power map, K3 amplitude statistics, K4 block sums) and its tail (noise-floor
+                   threshold, amplitude totals, onset, TDOA slot): two launches (gj_capture_scan_dev; eight until round 5);
+                   the captures' chains are independent of each other and run on streams of their own (up to three, each
+                   tested to run beside the others: gpsjam/streams.py), so they overlap instead of queueing
+  side stream 0    after all slots: K5 over every antenna pair (three launches)
   main stream      one result vector per antenna (the layout of gj_pack_result_dev; antenna 0 carries the pair table)
 From the second step on the whole step is replayed as ONE captured HIP graph (``graph=True``): ~45 launches of a few
 microseconds each are launch-bound when issued one by one.
@@ -102,11 +103,11 @@ class LocalAntennas:
                 self.dev.welch_dev(cap, self.nbytes[a], self.chunk_samples, self.nperseg, self.fs, self.psd[a])
         for a, cap in enumerate(self.caps):
             sdev, _ = self._sides[a % len(self._sides)]
-            sdev.stream_scan_dev(cap, self.nbytes[a], self.chunk_bytes, self.power[a], self.rssi_threshold, self.amp[a],
-                                 self.noise_samples, self.window, self.factor, self.onset[a])
-            if self.n_chunks[a]:
-                sdev.power_threshold_dev(self.power[a], self.n_chunks[a], self.stats[a])
-            sdev.tdoa_slot_dev(cap, self.nbytes[a], self.onset[a], self.slice_samples, self.slots[a])
+            # two launches per capture: the fused pass, then the tail (threshold, amplitude totals, onset, slot)
+            sdev.capture_scan_dev(cap, self.nbytes[a], self.chunk_bytes, self.power[a], self.rssi_threshold, self.amp[a],
+                                  self.noise_samples, self.window, self.factor, self.onset[a],
+                                  d_stats=self.stats[a] if self.n_chunks[a] else None, slice_samples=self.slice_samples,
+                                  d_slot=self.slots[a])
         sdev0, s0 = self._sides[0]
         for k in range(1, len(self._sides)):         # every slot is in place before the pairs are solved
             self._ev_side[k].record(self._sides[k][1])

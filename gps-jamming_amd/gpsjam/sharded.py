@@ -479,9 +479,13 @@ class AntennaStream:
         if self.overlap:
             self._side.wait_event(self._ev_free)
         d = self.dev_side
-        d.stream_scan_dev(self.cap, self.nbytes, self.chunk_bytes, self.power, self.rssi_threshold,
-                          self.amp, self.noise_samples, self.window, self.factor, self.onset)
-        d.power_threshold_dev(self.power, self.n_chunks, self.stats, self.mask)
+        # two launches: the fused pass, then the tail -- threshold, amplitude totals, onset record and this capture's
+        # TDOA slot (gj_capture_scan_dev; tdoa() finds the slot cut)
+        d.capture_scan_dev(self.cap, self.nbytes, self.chunk_bytes, self.power, self.rssi_threshold,
+                           self.amp, self.noise_samples, self.window, self.factor, self.onset,
+                           d_stats=self.stats if self.n_chunks else None, d_mask=self.mask if self.n_chunks else None,
+                           slice_samples=self.slice_samples, d_slot=self.my_slot)
+        self._slot_cut = True
         if self.overlap:
             self._ev_side.record(self._side)
 
@@ -499,7 +503,9 @@ class AntennaStream:
         its share of the antenna pairs with one multi-pair K5 launch.  All on the second stream, beside K2."""
         with self._on_side():
             dev = self.dev_side
-            dev.tdoa_slot_dev(self.cap, self.nbytes, self.onset, self.slice_samples, self.my_slot)
+            if not getattr(self, "_slot_cut", False):      # tdoa() without a stream_scan() in front of it
+                dev.tdoa_slot_dev(self.cap, self.nbytes, self.onset, self.slice_samples, self.my_slot)
+            self._slot_cut = False
             if self._exchange:
                 if self.comm is not None:
                     self.comm.allgather(self.my_slot, self.slot_bytes, self.slots)

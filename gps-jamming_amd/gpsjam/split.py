@@ -235,14 +235,26 @@ class PartStream:
         self.onset = torch.zeros(4, dtype=torch.int64, device=d)                               # gj_onset
         self.psd = torch.empty((max(self.rows, 1), nperseg), dtype=torch.float32, device=d)
 
-    def scan(self):
-        self.dev_side.part_scan_dev(self.view, self.chunk_bytes, self.power, self.rssi_threshold, self.tiles, self.amp,
-                                    self.noise_samples, self.window, self.factor, self.onset)
+    def scan(self, slot: Optional[torch.Tensor] = None):
+        """K1 + K3 + K4 of the part in two launches; with ``slot`` the TDOA slot at the part's own onset is cut by the
+        same tail launch (gj_part_capture_scan_dev) and the next ``slot(out)`` for that buffer has nothing left to do."""
+        self._slot_cut = None
+        if slot is None:
+            self.dev_side.part_scan_dev(self.view, self.chunk_bytes, self.power, self.rssi_threshold, self.tiles, self.amp,
+                                        self.noise_samples, self.window, self.factor, self.onset)
+        else:
+            self.dev_side.part_capture_scan_dev(self.view, self.chunk_bytes, self.power, self.rssi_threshold, self.tiles,
+                                                self.amp, self.noise_samples, self.window, self.factor, self.onset,
+                                                slice_samples=self.slice_samples, d_slot=slot)
+            self._slot_cut = slot.data_ptr()
 
     def welch(self):
         self.dev.part_welch_dev(self.view, self.chunk_samples, self.nperseg, self.fs, self.psd)
 
     def slot(self, out: torch.Tensor):
+        if getattr(self, "_slot_cut", None) == out.data_ptr():     # cut by this step's scan already
+            self._slot_cut = None
+            return
         self.dev_side.part_slot_dev(self.view, self.onset, self.slice_samples, out)
 
 
@@ -389,8 +401,8 @@ class SplitStreams:
         """K1 + K3 + K4 of every part of this rank, one fused pass each (side stream)."""
         if self.overlap:
             self._side.wait_event(self._ev_free)
-        for s in self.streams:
-            s.scan()
+        for j, s in enumerate(self.streams):
+            s.scan(slot=self.my_slots[j])
         if self.overlap:
             self._ev_side.record(self._side)
 

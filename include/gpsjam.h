@@ -251,6 +251,25 @@ int gj_stream_scan_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes,
                        float rssi_threshold, gj_amp_stats* d_amp,
                        int noise_samples, int window, float factor, gj_onset* d_onset);
 
+/* The whole per-capture side chain in TWO launches: the fused pass above, then one "tail" launch whose workgroups take
+ * roles -- noise-floor threshold of the power map (gj_power_threshold_dev: worker.py:241-248), amplitude totals
+ * (triangulateRSSI.py:65-68), K4's screening + exact scan + record (triangulateTDOA.py:37-49) and the TDOA slot cut at that
+ * onset (gj_tdoa_slot_dev with d_start = &d_onset->start_index) -- where gj_stream_scan_dev + gj_power_threshold_dev +
+ * gj_tdoa_slot_dev were eight dependent launches.  At the reference's capture sizes (10 s = 41 MB) that chain, not the
+ * bytes, was the step time.  Every result is the same bits as from the separate calls, except gj_onset.margin_before,
+ * which is a bound (see gj_onset) and is now a function of the capture alone.  `extra` may be NULL (then this IS
+ * gj_stream_scan_dev); a NULL d_stats / d_slot leaves that role out. */
+typedef struct gj_scan_extra {
+    float pct, rise_db;   /* noise floor: numpy.percentile(power, pct) * 10^(rise_db/10) */
+    float* d_stats;       /* [3] {baseline, threshold, count_above} or NULL */
+    uint8_t* d_mask;      /* [n_chunks] or NULL */
+    size_t slice_samples; /* TDOA slot of slice_samples I/Q pairs ... */
+    uint8_t* d_slot;      /* ... written here (gj_tdoa_slot_bytes, 16-byte aligned) or NULL */
+} gj_scan_extra;
+int gj_capture_scan_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
+                        float* d_power, float rssi_threshold, gj_amp_stats* d_amp, int noise_samples, int window,
+                        float factor, gj_onset* d_onset, const gj_scan_extra* extra);
+
 /* ------------------------------------------------- overlapped ingest ----------------- */
 /* Overlapped ingest: upload a capture AND analyse it, with the kernels running on the pieces (1-16 MiB, by capture size) that have
  * landed in HBM while the rest is still on its way (the reference reads, then computes: worker.py:209-230,
@@ -389,6 +408,10 @@ size_t gj_amp_tile_count(size_t nbytes);
 int gj_part_scan_dev(gj_ctx* ctx, const gj_part_view* part, size_t chunk_bytes, float eps, int flags, float* d_power,
                      float rssi_threshold, void* d_tiles, gj_amp_part* d_amp, int noise_samples, int window,
                      float factor, gj_onset* d_onset);
+/* gj_part_scan_dev + gj_part_slot_dev (at &d_onset->start_index) in the same two launches as gj_capture_scan_dev */
+int gj_part_capture_scan_dev(gj_ctx* ctx, const gj_part_view* part, size_t chunk_bytes, float eps, int flags, float* d_power,
+                             float rssi_threshold, void* d_tiles, gj_amp_part* d_amp, int noise_samples, int window,
+                             float factor, gj_onset* d_onset, const gj_scan_extra* extra);
 /* K2 of the own range: rows [own_first_byte / (2 chunk_samples), ...) of the capture's waterfall */
 int gj_part_welch_dev(gj_ctx* ctx, const gj_part_view* part, size_t chunk_samples, int nperseg, double fs, int flags,
                       float* d_psd, float* d_psd_db);
