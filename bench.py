@@ -927,7 +927,7 @@ def welch_ref_traffic(nbytes):
     return out
 
 
-def deployment(np, torch, gpsjam, dev, StreamSpec, reps=20, graph=True):
+def deployment(np, torch, gpsjam, dev, StreamSpec, reps=20, graph=True, **local_kw):
     """The reference's deployment at the reference's sizes (worker.py:184-196,586-600): THREE antenna
     captures of 10 s (40 960 000 bytes each).  Two figures:
       resident_step_ms   captures in HBM; per capture the fused scan (K1 power map + K3 + K4) + noise-floor threshold + K2 at
@@ -951,7 +951,7 @@ def deployment(np, torch, gpsjam, dev, StreamSpec, reps=20, graph=True):
     # every antenna of the deployment on this GPU: K2 on the main stream, each capture's scan -> threshold -> slot chain on
     # a side stream of its own, K5 over the three slots, one result vector per antenna (gpsjam/local.py)
     st = LocalAntennas(dev, caps, nperseg=REF_NPERSEG, chunk_samples=CHUNK_SAMPLES, slice_samples=REF_SLICE, rssi_threshold=0.0,
-                       graph=graph)
+                       graph=graph, **local_kw)
     step = st.step
     power, stats, amp, onset, psd, lags = st.power, st.stats, st.amp, st.onset, st.psd, st.lags
 

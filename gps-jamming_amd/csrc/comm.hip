@@ -7,6 +7,9 @@
 // of mapping a second one.  Search order: $GPSJAM_RCCL, an already-loaded librccl, librccl.so.1,
 // /opt/rocm/lib/librccl.so.1.
 #include <dlfcn.h>
+#include <unistd.h>
+
+#include <atomic>
 
 #include <rccl/rccl.h>   // types and prototypes only; nothing is linked
 
@@ -14,9 +17,10 @@
 #include "host_io.h"
 
 struct gj_comm {
-    gj_ctx* ctx = nullptr;
+    gj_ctx* ctx = nullptr;            // nullptr: detached (its context is gone, or gj_comm_destroy has begun)
     ncclComm_t comm = nullptr;
     int rank = 0, n_ranks = 1;
+    std::atomic<int> in_flight{0};    // collectives between comm_call_begin and the return of their RCCL call
 };
 
 namespace gj {
@@ -75,15 +79,42 @@ static int rccl_fail(gj_ctx* ctx, const char* what, ncclResult_t rc) {
     return fail(ctx, GJ_ERR_HIP, "%s failed: %s", what, r->GetErrorString ? r->GetErrorString(rc) : "?");
 }
 
+// The RCCL calls are made WITHOUT the context lock (they may wait for a late rank), so the lock no longer keeps a
+// communicator alive under a collective that another thread is still enqueueing.  What does: `in_flight`
+// counts the calls between comm_call_begin and the return of their RCCL call; attaching / detaching a communicator
+// and starting a call are serialised by one process-wide mutex (held for a few loads and stores, never across RCCL);
+// whoever takes a communicator down -- gj_comm_destroy, or gj_destroy of its context -- first detaches it (no new
+// call can start), then waits with no lock held until the calls in flight have returned, then destroys it.
+static std::mutex& comm_mu() {
+    static std::mutex m;
+    return m;
+}
+static void comm_quiesce(gj_ctx* ctx, gj_comm* c) {
+    while (c->in_flight.load(std::memory_order_acquire) > 0) {
+        if (ctx) wait_hook(ctx, kWaitStream);
+        usleep(100);
+    }
+}
+
 // gj_destroy: communicators made on the context go down with it; their handles stay valid for gj_comm_destroy
 // (which then only frees the handle), so the order in which a host drops the two does not matter.
 void comm_detach_all(gj_ctx* ctx) {
-    for (gj_comm* c : ctx->comms) {
-        if (c->comm) (void)rccl()->CommDestroy(c->comm);
-        c->comm = nullptr;
-        c->ctx = nullptr;
+    std::vector<gj_comm*> mine;
+    {
+        std::lock_guard<std::mutex> l(comm_mu());
+        mine.swap(ctx->comms);
+        for (gj_comm* c : mine) c->ctx = nullptr;
     }
-    ctx->comms.clear();
+    for (gj_comm* c : mine) {
+        comm_quiesce(ctx, c);
+        ncclComm_t h = nullptr;
+        {
+            std::lock_guard<std::mutex> l(comm_mu());
+            h = c->comm;
+            c->comm = nullptr;
+        }
+        if (h) (void)rccl()->CommDestroy(h);
+    }
 }
 
 }   // namespace gj
@@ -124,7 +155,7 @@ int gj_comm_init_rank(gj_ctx* ctx, const void* id, int rank, int n_ranks, gj_com
         return rccl_fail(ctx, "ncclCommInitRank", rc);
     }
     {
-        Guard g(ctx);
+        std::lock_guard<std::mutex> l(comm_mu());
         ctx->comms.push_back(c);
     }
     *out = c;
@@ -136,6 +167,7 @@ int gj_comm_rank(gj_comm* c, int* rank, int* n_ranks) {
     // read from the LIVE communicator, not from what gj_comm_init_rank was told: a caller that reports "N ranks"
     // (bench.py's rccl_ranks) reports what RCCL itself holds.  A communicator whose context is gone answers 0 of 0.
     int r = -1, n = 0;
+    std::lock_guard<std::mutex> l(comm_mu());   // two local queries: short, never blocks on a peer
     if (c->comm) {
         Rccl* lib = rccl();
         if (lib->CommUserRank(c->comm, &r) != ncclSuccess || lib->CommCount(c->comm, &n) != ncclSuccess) return GJ_ERR_HIP;
@@ -148,6 +180,7 @@ int gj_comm_rank(gj_comm* c, int* rank, int* n_ranks) {
 int gj_comm_device(gj_comm* c, int* hip_device) {
     if (!c || !hip_device) return GJ_ERR_INVALID;
     *hip_device = -1;
+    std::lock_guard<std::mutex> l(comm_mu());
     if (c->comm && rccl()->CommCuDevice(c->comm, hip_device) != ncclSuccess) return GJ_ERR_HIP;
     return GJ_OK;
 }
@@ -158,21 +191,33 @@ int gj_comm_device(gj_comm* c, int* hip_device) {
 // held across one (a second thread scanning on the same context must not stall behind a late rank).  The order of
 // collectives on one communicator is the caller's business, as it is with RCCL itself.
 struct CommCall {
+    gj_comm* c = nullptr;
     gj_ctx* ctx = nullptr;
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     int rank = 0, n_ranks = 1;
+    CommCall() = default;
+    CommCall(const CommCall&) = delete;
+    CommCall& operator=(const CommCall&) = delete;
+    ~CommCall() {
+        if (c) c->in_flight.fetch_sub(1, std::memory_order_release);   // after the RCCL call has returned
+    }
 };
 
 static int comm_call_begin(gj_comm* c, CommCall& k) {
-    if (!c || !c->ctx || !c->comm) return GJ_ERR_INVALID;   // destroyed, or its context is gone
-    k.ctx = c->ctx;
+    if (!c) return GJ_ERR_INVALID;
+    {
+        std::lock_guard<std::mutex> l(comm_mu());
+        if (!c->ctx || !c->comm) return GJ_ERR_INVALID;   // destroyed, being destroyed, or its context is gone
+        k.ctx = c->ctx;
+        k.comm = c->comm;
+        k.rank = c->rank;
+        k.n_ranks = c->n_ranks;
+        c->in_flight.fetch_add(1, std::memory_order_acquire);   // from here on neither the communicator nor its context goes away
+        k.c = c;
+    }
     Guard g(k.ctx);
-    if (!c->comm) return GJ_ERR_INVALID;
-    k.comm = c->comm;
     k.stream = k.ctx->stream;
-    k.rank = c->rank;
-    k.n_ranks = c->n_ranks;
     return GJ_OK;
 }
 
@@ -213,17 +258,21 @@ int gj_comm_bcast_dev(gj_comm* c, void* d_buf, size_t bytes, int root) {
 
 int gj_comm_destroy(gj_comm* c) {
     if (!c) return GJ_OK;
-    gj_ctx* ctx = c->ctx;
-    if (ctx) {   // still attached: collectives queued on the context's stream must have finished
-        (void)wait_stream(ctx, current_stream(ctx));
-        {
-            Guard g(ctx);
+    gj_ctx* ctx = nullptr;
+    {
+        std::lock_guard<std::mutex> l(comm_mu());
+        ctx = c->ctx;
+        c->ctx = nullptr;                 // detached: no new call starts on it
+        if (ctx)
             for (size_t k = 0; k < ctx->comms.size(); ++k)
                 if (ctx->comms[k] == c) {
                     ctx->comms.erase(ctx->comms.begin() + (long)k);
                     break;
                 }
-        }
+    }
+    if (ctx) {   // was still attached: calls in flight return first, collectives queued on the context's stream finish
+        comm_quiesce(ctx, c);
+        (void)wait_stream(ctx, current_stream(ctx));
         (void)hipSetDevice(ctx->device);
         if (c->comm) (void)rccl()->CommDestroy(c->comm);
     }

@@ -293,7 +293,26 @@ __device__ __forceinline__ void tdoa_slot_body(const uint8_t* __restrict__ iq, s
     // the slot is padded to a multiple of 256 bytes: the padding is written too (zeros), so that a slot is a fully
     // defined message
     const size_t ngroups = ((GJ_SLOT_HEADER + 2 * n + 255) / 256 * 256 - GJ_SLOT_HEADER) / 16;
-    for (size_t g = g0; g < ngroups; g += gstride) {
+    // whole 16-byte groups of the slice: one 16-byte load each.  The source is only 2-byte aligned (a slice starts at
+    // any sample); global memory takes unaligned vector loads, and eight 2-byte loads per group made the copy of a
+    // 2^19-sample slice by ONE workgroup (the scan tail's last arriver) a quarter of a millisecond.
+    const size_t nfull = ok ? (2 * n) / 16 : 0;
+    struct __attribute__((packed, aligned(2))) Group {
+        unsigned x, y, z, w;
+        __device__ __forceinline__ uint4 get() const { return uint4{x, y, z, w}; }
+    };
+    const Group* src16 = reinterpret_cast<const Group*>(src);
+    size_t g = g0;
+    for (; g + 7 * gstride < nfull; g += 8 * gstride) {          // eight loads in flight per thread
+        uint4 q[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = src16[g + k * gstride].get();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[g + k * gstride] = q[k];
+    }
+    for (; g < nfull; g += gstride) dst[g] = src16[g].get();
+    // the slice's ragged end and the padding (an invalid slot: everything)
+    for (; g < ngroups; g += gstride) {
         unsigned w[4] = {0, 0, 0, 0};
         if (ok) {
 #pragma unroll

@@ -1181,6 +1181,8 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
 // 512-sample block sums over the span + the span's ragged end), every word of the scratch is written before it is read,
 // and the arrival counter is left at zero by the last arriver.
 // ---------------------------------------------------------------------------------------
+constexpr size_t kTailSlotBytes = 256u << 10;           // largest slice the tail's last workgroup cuts itself
+constexpr size_t kTailPrioBytes = 256u << 20;           // captures up to this size: the tail runs at raised wave priority
 constexpr int kTailBlocks = 2048;                       // 512-sample blocks screened per onset workgroup (1 Mi samples)
 constexpr int kTailHalo = (kOnsetMaxWin + 510) / 512 + 1;
 constexpr int kTailPre = kTailBlocks + kTailHalo + (kTailBlocks + kTailHalo) / 32 + 8;
@@ -1198,7 +1200,7 @@ struct TailArgs {
     long long sample0;               // capture index of iq[0] (0 for a whole capture)
     unsigned long long total_samples;   // of the whole capture (slot validity)
     unsigned long long slot_nsamples;   // samples of the buffer a slice may be cut from (>= nsamples: a part's tail)
-    int has_thr, is_part, valid, has_slot;
+    int has_thr, is_part, valid, has_slot, hi_prio;
     // threshold role
     float* power;
     unsigned long long nchunks;
@@ -1274,6 +1276,28 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
     for (int k = 0; k < kScanThreads / 64; ++k) r += sh.r64[0][k];
     __syncthreads();
     return r;
+}
+
+// min of a, min of b and max of c over the workgroup in ONE exchange (two barriers instead of six)
+__device__ __forceinline__ void block_min2_max(unsigned long long& a, unsigned long long& b, unsigned& c, TailShared& sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long oa = __shfl_xor(a, off, 64), ob = __shfl_xor(b, off, 64);
+        const unsigned oc = __shfl_xor(c, off, 64);
+        a = oa < a ? oa : a;
+        b = ob < b ? ob : b;
+        c = oc > c ? oc : c;
+    }
+    if ((threadIdx.x & 63) == 0) { sh.r64[0][threadIdx.x >> 6] = a; sh.r64[1][threadIdx.x >> 6] = b; sh.r32[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    a = sh.r64[0][0]; b = sh.r64[1][0]; c = sh.r32[0];
+#pragma unroll
+    for (int k = 1; k < kScanThreads / 64; ++k) {
+        a = sh.r64[0][k] < a ? sh.r64[0][k] : a;
+        b = sh.r64[1][k] < b ? sh.r64[1][k] : b;
+        c = sh.r32[k] > c ? sh.r32[k] : c;
+    }
+    __syncthreads();
 }
 
 // Inclusive prefix sums, in place, of the `need` words pre[onset_pad(1)] .. pre[onset_pad(need)] (pre[0] = 0): the
@@ -1401,15 +1425,26 @@ __device__ void tail_onset_range(const TailArgs& A, unsigned w, unsigned* pre_c,
                 if (ma > thr && best == ~0ull) best = o0 + k;
             }
         }
-        const unsigned long long hit = block_min_u64(best, sh, 0);
-        const unsigned long long hit_lo = block_min_u64(best_lo, sh, 1);
+        // first crossing, first band position and -- in the same exchange -- the largest window sum of the thread's
+        // positions in front of ITS first crossing; the positions between the workgroup's first crossing and the
+        // thread's own are taken out again below (second pass over registers, only when there was a crossing)
+        unsigned long long hit = best, hit_lo = best_lo;
         unsigned b = 0;
 #pragma unroll
         for (int i = 0; i < kOnsetOut / kScanThreads; ++i) {
             const int k = tid + i * kScanThreads;
-            if (k < npos && o0 + k < hit) b = Sv[i] > b ? Sv[i] : b;
+            if (k < npos && o0 + k < best) b = Sv[i] > b ? Sv[i] : b;
         }
-        b = block_max_u32(b, sh);
+        block_min2_max(hit, hit_lo, b, sh);
+        if (hit != ~0ull) {                              // workgroup-uniform: only the positions in front of `hit` count
+            b = 0;
+#pragma unroll
+            for (int i = 0; i < kOnsetOut / kScanThreads; ++i) {
+                const int k = tid + i * kScanThreads;
+                if (k < npos && o0 + k < hit) b = Sv[i] > b ? Sv[i] : b;
+            }
+            b = block_max_u32(b, sh);
+        }
         below = b > below ? b : below;
         if (hit_lo != ~0ull && guard == ~0ull) guard = hit_lo;
         if (hit != ~0ull) { first = hit; break; }
@@ -1483,6 +1518,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_tail_kernel(TailArgs A) {
     extern __shared__ unsigned pre_x[];                // kOnsetOut + window - 1 words + padding
     const int tid = threadIdx.x;
     unsigned b = blockIdx.x;
+    // A few dozen workgroups, each a chain of short dependent phases, on the path to K5 -- beside K2, which keeps every
+    // SIMD's issue slots busy and does not care about latency.  Raised wave priority lets these waves issue when they
+    // are ready (their total instruction count is a rounding error for K2).  Only when the host says the chain is what
+    // the step waits for (captures of the reference's size); behind a GiB-class K2 launch it is hidden either way and
+    // K2's issue slots are the step (round 4 measured +1.2 % there with the priority raised across the board).
+    if (A.hi_prio) __builtin_amdgcn_s_setprio(3);
     if (A.has_thr) {
         if (b == 0) {
             power_threshold_body(A.power, (size_t)A.nchunks, A.pct, A.ratio, A.stats, A.mask, sh_thr);
@@ -1723,17 +1764,24 @@ int scan_end(gj_ctx* ctx, const ScanJob& job, const ScanExtra* extra) {
     if (extra && extra->d_slot) {
         if (extra->slice_samples < 1) return fail(ctx, GJ_ERR_INVALID, "n_samples must be >= 1");
         if ((reinterpret_cast<uintptr_t>(extra->d_slot) & 15) != 0) return fail(ctx, GJ_ERR_INVALID, "slot must be 16-byte aligned");
-        A.has_slot = 1;
         A.slot = extra->d_slot;
         A.slice_samples = extra->slice_samples;
         A.slot_nsamples = extra->slot_buf_bytes ? extra->slot_buf_bytes / 2 : st.nsamples;
+        // the tail's last workgroup cuts the slot alone: fine for the reference's slices (50 000 samples = 100 KB, a few
+        // round trips), not for the benchmark's 2^19-sample ones (1 MiB by one workgroup is latency-bound: ~70 us) --
+        // those get the grid-wide copy kernel behind the tail, one launch more on a chain that a GiB-class K2 hides
+        A.has_slot = 2 * extra->slice_samples <= kTailSlotBytes;
     }
+    A.hi_prio = st.nbytes <= kTailPrioBytes;
     A.up = unpack_of(ctx);
     const int needx = kOnsetOut + st.window - 1;
     const size_t dyn = (size_t)(needx + needx / 32 + 8) * sizeof(unsigned);
     const unsigned grid = (A.has_thr ? 1u : 0u) + 1u + st.nct;
     hipLaunchKernelGGL(scan_tail_kernel, dim3(grid), dim3(kScanThreads), dyn, ctx->stream, A);
     GJ_LAUNCH_CHECK(ctx);
+    if (A.slot && !A.has_slot)
+        return launch_tdoa_slot(ctx, st.d_iq, 2 * (size_t)A.slot_nsamples, &st.d_onset->start_index, (size_t)A.slice_samples, A.slot,
+                                A.sample0, (size_t)A.total_samples);
     return GJ_OK;
 }
 

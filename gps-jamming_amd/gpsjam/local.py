@@ -39,7 +39,7 @@ class LocalAntennas:
     def __init__(self, dev, captures: Sequence[torch.Tensor], *, chunk_bytes: int = 65536, chunk_samples: int = 2048000,
                  nperseg: int = 1024, fs: float = 2.048e6, slice_samples: int = 50000, noise_samples: int = 200000,
                  window: int = 1000, factor: float = 50.0, rssi_threshold: float = 0.0, side_streams: int = 3,
-                 graph: bool = True):
+                 graph: bool = True, scan_first: bool = False):
         assert len(captures) >= 1 and all(c.dtype == torch.uint8 and c.is_contiguous() and c.is_cuda for c in captures)
         self.dev, self.caps = dev, list(captures)
         self.n_ant = len(self.caps)
@@ -47,6 +47,7 @@ class LocalAntennas:
         self.chunk_bytes, self.chunk_samples, self.nperseg, self.fs = chunk_bytes, chunk_samples, nperseg, fs
         self.slice_samples, self.noise_samples, self.window, self.factor = slice_samples, noise_samples, window, factor
         self.rssi_threshold = rssi_threshold
+        self.scan_first = bool(scan_first)
         self._main = torch.cuda.current_stream(d)
         dev.set_stream(self._main.cuda_stream)
         # side streams, each on a hardware queue of its own (tested), each with a context (= workspace) bound to it
@@ -96,11 +97,18 @@ class LocalAntennas:
         self._ev_go.record(main)                     # the previous step's packing has read what the chains overwrite
         for _, s in self._sides:
             s.wait_event(self._ev_go)
-        # the longest chain first: the main stream's K2 launches are on the GPU while the host is still enqueueing the
-        # side chains (a step is ~45 launches; the host needs longer to issue them than the GPU to run them)
-        for a, cap in enumerate(self.caps):
-            if self.rows[a]:
-                self.dev.welch_dev(cap, self.nbytes[a], self.chunk_samples, self.nperseg, self.fs, self.psd[a])
+        def k2():
+            for a, cap in enumerate(self.caps):
+                if self.rows[a]:
+                    self.dev.welch_dev(cap, self.nbytes[a], self.chunk_samples, self.nperseg, self.fs, self.psd[a])
+
+        # Which chain is issued first: K2 (default).  With the side chains down to two launches per capture the other
+        # order was tried -- the fused scan takes 9 us on a 10-s capture when it has the chip, ~40 us beside a K2 launch --
+        # and measured slower, graph 0.300 against 0.262 ms per step, eager 0.273 against 0.270 (two rounds on one box,
+        # tools/deployment_probe.py [--k2-first]): the main stream's three K2 launches are still the longer chain, and
+        # delaying them costs more than the scans gain.  ``scan_first`` keeps the experiment reachable.
+        if not self.scan_first:
+            k2()
         for a, cap in enumerate(self.caps):
             sdev, _ = self._sides[a % len(self._sides)]
             # two launches per capture: the fused pass, then the tail (threshold, amplitude totals, onset, slot)
@@ -108,6 +116,8 @@ class LocalAntennas:
                                   self.noise_samples, self.window, self.factor, self.onset[a],
                                   d_stats=self.stats[a] if self.n_chunks[a] else None, slice_samples=self.slice_samples,
                                   d_slot=self.slots[a])
+        if self.scan_first:
+            k2()
         sdev0, s0 = self._sides[0]
         for k in range(1, len(self._sides)):         # every slot is in place before the pairs are solved
             self._ev_side[k].record(self._sides[k][1])

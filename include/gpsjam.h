@@ -61,7 +61,10 @@ const char* gj_strerror(int status);
 const char* gj_last_error(gj_ctx* ctx); /* of the CALLING THREAD's last failure (kept per thread) */
 int gj_device_count(int* count);
 int gj_create(int device_id, gj_ctx** out);
-int gj_destroy(gj_ctx* ctx); /* idempotent on NULL */
+/* gj_destroy: idempotent on NULL.  Takes down the communicators made on the context (their handles stay valid for
+ * gj_comm_destroy); a collective another thread is still enqueueing on one of them returns first.  No OTHER call on
+ * the context may be in progress or start while it is being destroyed. */
+int gj_destroy(gj_ctx* ctx);
 /* external != 0: run on the caller's HIP stream `hip_stream` (e.g.
  * torch.cuda.current_stream().cuda_stream; NULL then means the legacy default stream);
  * external == 0: back to the context's own non-blocking stream. */
@@ -541,8 +544,11 @@ size_t gj_acq_workspace(gj_ctx* ctx, int nsamp, int n_freq, int n_prn, int intg,
  * synchronise the host; buffers are device memory.  The context lock is NOT held across the RCCL
  * call (a communicator's first collective connects its peers inside the call and may wait for a
  * late rank): other threads keep using the context meanwhile; the order of collectives on one
- * communicator is the caller's, and a communicator must not be destroyed while a call on it is in
- * progress.  librccl is bound at run time (GJ_ERR_UNSUPPORTED when it cannot be loaded). */
+ * communicator is the caller's.  gj_comm_destroy -- and gj_destroy of the communicator's context --
+ * detach the communicator first (a call that starts afterwards answers GJ_ERR_INVALID) and wait for the
+ * calls already in progress on it to return before RCCL's handle is destroyed; the two must not be
+ * called concurrently with each other for the same context.  librccl is bound at run time
+ * (GJ_ERR_UNSUPPORTED when it cannot be loaded). */
 typedef struct gj_comm gj_comm;
 #define GJ_COMM_ID_BYTES 128
 int gj_comm_unique_id(void* id /* [GJ_COMM_ID_BYTES] */);

@@ -21,7 +21,8 @@ def main():
     torch.cuda.set_stream(ws)
     dev.set_stream(ws.cuda_stream)
     graph = "--eager" not in sys.argv
-    r = bench.deployment(np, torch, gpsjam, dev, StreamSpec, graph=graph)["line"]
+    kw = {"scan_first": True} if "--scan-first" in sys.argv else {}
+    r = bench.deployment(np, torch, gpsjam, dev, StreamSpec, graph=graph, **kw)["line"]
     print("graph" if graph else "eager", {k: r[k] for k in ("resident_step_ms", "resident_step_latency_ms", "file_to_results_ms")})
 
 

@@ -3,7 +3,9 @@
 the thing to put after `rocprofv3 ... --` for kernel-trace and PMC passes.
 
     python tools/run_kernel.py welch --reps 5 [--nperseg 4096] [--bytes 1073741824]
-    python tools/run_kernel.py scan  --reps 5      (K1 + threshold + K3 + K4)
+    python tools/run_kernel.py scan  --reps 5      (K1 + threshold + K3 + K4, one kernel family each)
+    python tools/run_kernel.py fscan --reps 5      (gj_stream_scan_dev: fused pass + tail)
+    python tools/run_kernel.py cscan --reps 5 [--slice 524288]   (gj_capture_scan_dev: + threshold and TDOA slot in the tail)
     python tools/run_kernel.py xcorr --reps 5
     python tools/run_kernel.py acq   --reps 5      (one cold acquisition search per repetition)
 Prints the average wall time per repetition measured with HIP events on the launch stream.
@@ -18,10 +20,11 @@ sys.path.insert(0, os.path.join(REPO, "gps-jamming_amd"))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["welch", "scan", "fscan", "thr", "xcorr", "xcorr3", "k1", "k3", "k4", "acq"])
+    ap.add_argument("what", choices=["welch", "scan", "fscan", "cscan", "thr", "xcorr", "xcorr3", "k1", "k3", "k4", "acq"])
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--nperseg", type=int, default=4096)
     ap.add_argument("--bytes", type=int, default=1 << 30)
+    ap.add_argument("--slice", type=int, default=1 << 19)
     args = ap.parse_args()
     import numpy as np
     import gpsjam
@@ -37,6 +40,7 @@ def main():
     d_psd = dev.alloc(4 * max(rows, 1) * args.nperseg)
     d_pow, d_stats, d_mask = dev.alloc(4 * nch), dev.alloc(12), dev.alloc(nch)
     d_amp, d_on = dev.alloc(32), dev.alloc(32)
+    d_slot = dev.alloc(dev.tdoa_slot_bytes(args.slice))
     d_starts, d_lags, d_peaks = dev.alloc(16), dev.alloc(4), dev.alloc(4)
     d_starts.upload(np.array([int(0.4 * ns), int(0.4 * ns) + 3], np.int64))
     d_starts3, d_lags3, d_peaks3 = dev.alloc(24), dev.alloc(12), dev.alloc(12)
@@ -60,6 +64,9 @@ def main():
             dev.onset_dev(cap, nbytes, 200000, 1000, 50.0, d_on)
         elif args.what == "fscan":
             dev.stream_scan_dev(cap, nbytes, 65536, d_pow, 0.0, d_amp, 200000, 1000, 50.0, d_on)
+        elif args.what == "cscan":
+            dev.capture_scan_dev(cap, nbytes, 65536, d_pow, 0.0, d_amp, 200000, 1000, 50.0, d_on, d_stats=d_stats, d_mask=d_mask,
+                                 slice_samples=args.slice, d_slot=d_slot)
         elif args.what == "thr":
             dev.power_threshold_dev(d_pow, nch, d_stats, d_mask)
         elif args.what == "scan":
