@@ -309,7 +309,17 @@ def main():
             psd_ref = torch.empty((dev.welch_rows(nbytes, CHUNK_SAMPLES, REF_NPERSEG), REF_NPERSEG), dtype=torch.float32, device="cuda")
             dev.reserve(max(dev.welch_workspace(nbytes, CHUNK_SAMPLES, REF_NPERSEG), dev.welch_workspace(nbytes, CHUNK_SAMPLES, NPERSEG)))
             k2_ref_ms = timed(lambda: dev.welch_dev(cap, nbytes, CHUNK_SAMPLES, REF_NPERSEG, 2.048e6, psd_ref), work_stream)
-            ref_point = {"k2_ms": k2_ref_ms, "psd": psd_ref, "deployment": deployment(np, torch, gpsjam, dev, StreamSpec)}
+            # K2 at the two sizes, INTERLEAVED (A/B/A/B, same stream, same repetitions, back to back), transform kernel
+            # and finalize launch timed apart (gj_welch_timed_dev): BENCH_r04 had 1024 slower than 4096 because the two
+            # were timed minutes apart with different things in between
+            ab = {NPERSEG: [], REF_NPERSEG: []}
+            for n_ab in (NPERSEG, REF_NPERSEG):
+                dev.welch_timed_dev(cap, nbytes, CHUNK_SAMPLES, n_ab, 2.048e6, stream.psd if n_ab == NPERSEG else psd_ref)
+            for _ in range(6):
+                for n_ab in (NPERSEG, REF_NPERSEG):
+                    ab[n_ab].append(dev.welch_timed_dev(cap, nbytes, CHUNK_SAMPLES, n_ab, 2.048e6,
+                                                        stream.psd if n_ab == NPERSEG else psd_ref))
+            ref_point = {"k2_ms": k2_ref_ms, "psd": psd_ref, "ab": ab, "deployment": deployment(np, torch, gpsjam, dev, StreamSpec)}
         except Exception as e:
             print(f"[bench] reference operating point skipped: {e!r}", file=sys.stderr)
             ref_point = None
@@ -415,14 +425,33 @@ def main():
                 **family_traffic("profiles/r04_pmc_acq/summary.json", nbytes),
                 "parity": "unpinned (gnssdec unbuildable here); oracle = numpy restatement of sdracq.c / sdrcmn.c"}
         if ref_point is not None:
-            k2r = ref_point["k2_ms"]
             par = (cpu or {}).pop("reference_point_parity", None)
+            # the same measurement as its 4096 sibling in the interleaved block below (kernel + finalize, averaged over the
+            # rounds): the two figures of one line come from the same minute of the same box
+            k2r = (sum(k for k, _ in ref_point["ab"][REF_NPERSEG]) + sum(f for _, f in ref_point["ab"][REF_NPERSEG])) / len(ref_point["ab"][REF_NPERSEG])
             line["secondary"][f"K2 welch_kernel<{REF_NPERSEG}> + finalize at the reference's FFT size (widmo_plot.py:10,48), same capture, solo"] = {
                 "bound": "hbm", "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": k2r,
                 "achieved": (nbytes / 1e9) / (k2r / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (nbytes / 1e9) / (k2r / 1e3) / HBM_PEAK_GBS, "msamples_per_s": nbytes / 2 / (k2r / 1e3) / 1e6,
                 **welch_ref_traffic(nbytes),
+                "stopwatch_around_gj_welch_dev_ms": ref_point["k2_ms"],
                 "parity_on_sample": None if par is None else par["psd_1024"]}
+            ab = ref_point["ab"]
+
+            def ab_of(n):
+                ks, fs_ = [k for k, _ in ab[n]], [f for _, f in ab[n]]
+                return {"kernel_ms_avg": sum(ks) / len(ks), "kernel_ms_min": min(ks), "finalize_ms_avg": sum(fs_) / len(fs_),
+                        "kernel_plus_finalize_ms_avg": (sum(ks) + sum(fs_)) / len(ks)}
+            a4096, a1024 = ab_of(NPERSEG), ab_of(REF_NPERSEG)
+            v4096, v1024 = pmc_valu("profiles/r04_pmc_welch/summary.json"), pmc_valu("profiles/r04_pmc_welch1024/summary.json")
+            line["secondary"]["K2 at nperseg 4096 and 1024, interleaved A/B on this box, kernel and finalize apart"] = {
+                "what": "six rounds of (4096, 1024) back to back on one stream with nothing else in flight; HIP events around "
+                        "welch_kernel<N> and around welch_finalize_kernel (gj_welch_timed_dev)",
+                "nperseg_4096": a4096, "nperseg_1024": a1024,
+                "kernel_ratio_1024_over_4096": a1024["kernel_ms_avg"] / a4096["kernel_ms_avg"],
+                "valu_instruction_ratio_1024_over_4096": (v1024 / v4096) if (v4096 and v1024) else None,
+                "note": "the 'solo' figures elsewhere in this line are events around gj_welch_dev as a whole (transform + finalize "
+                        "+ the gap between the two launches), each from its own place in the run; these are the ones to compare"}
             dep = ref_point["deployment"]["line"]
             if par is not None:
                 dep["parity_vs_oracle"] = par["deployment"]
@@ -838,6 +867,15 @@ def pmc_summary(nbytes):
         out["matches_build"] = (js.get("_source_hash") == source_hash()) if js.get("_source_hash") else None
         return out
     return out
+
+
+def pmc_valu(rel):
+    """VALU wave-instructions per K2 launch from a committed PMC summary (None when it is not there)."""
+    try:
+        with open(os.path.join(REPO, rel)) as f:
+            return json.load(f).get("_valu", {}).get("sq_insts_valu_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def family_traffic(rel, nbytes):

@@ -412,6 +412,44 @@ int gj_welch_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_s
     return launch_welch(ctx, d_iq, nbytes, chunk_samples, nperseg, fs, flags, d_psd, d_psd_db);
 }
 
+// gj_welch_dev with HIP events around the transform launch and around the finalize launch (bench.py: K2 at two sizes,
+// interleaved, kernel and finalize apart).  Synchronises on its last event, with no lock held.
+int gj_welch_timed_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_samples, int nperseg, double fs, int flags,
+                       float* d_psd, float* d_psd_db, float* kernel_ms, float* finalize_ms) {
+    if (!ctx) return GJ_ERR_INVALID;
+    if (!kernel_ms || !finalize_ms || (nbytes && (!d_iq || !d_psd))) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    *kernel_ms = *finalize_ms = 0.f;
+    hipEvent_t mid = nullptr;
+    (void)hipSetDevice(ctx->device);
+    GJ_HIP(ctx, hipEventCreate(&mid));
+    int rc = GJ_OK;
+    bool ran = false;
+    {
+        Guard g(ctx);
+        WelchJob job;
+        rc = welch_begin(ctx, nbytes, chunk_samples, nperseg, fs, 0, job);
+        if (!rc && (reinterpret_cast<uintptr_t>(d_iq) & 1) != 0) rc = fail(ctx, GJ_ERR_INVALID, "capture must be 2-byte aligned");
+        if (!rc && job.rows) {
+            rc = ensure_workspace(ctx, job.ws_bytes);
+            job.partial = reinterpret_cast<float*>(ctx->ws);
+            if (!rc && hipEventRecord(ctx->ev_start, ctx->stream) != hipSuccess) rc = fail(ctx, GJ_ERR_HIP, "event");
+            if (!rc) rc = welch_range(ctx, job, d_iq, 0, job.rows);
+            if (!rc && hipEventRecord(mid, ctx->stream) != hipSuccess) rc = fail(ctx, GJ_ERR_HIP, "event");
+            if (!rc) rc = welch_end(ctx, job, flags, d_psd, d_psd_db);
+            if (!rc && hipEventRecord(ctx->ev_stop, ctx->stream) != hipSuccess) rc = fail(ctx, GJ_ERR_HIP, "event");
+            ran = !rc;
+        }
+    }
+    if (ran) rc = wait_event(ctx, ctx->ev_stop);
+    if (ran && !rc) {
+        if (hipEventElapsedTime(kernel_ms, ctx->ev_start, mid) != hipSuccess || hipEventElapsedTime(finalize_ms, mid, ctx->ev_stop) != hipSuccess)
+            rc = fail(ctx, GJ_ERR_HIP, "hipEventElapsedTime failed");
+    }
+    (void)hipEventDestroy(mid);
+    reap_retired(ctx);
+    return rc;
+}
+
 int gj_byte_histogram_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_samples, int nperseg, int stride,
                           uint64_t* d_hist) {
     GJ_ENTER(ctx);
@@ -647,6 +685,16 @@ int gj_combine_plan_create(gj_ctx* ctx, const gj_combine_copy* copies, int n_cop
     (void)hipSetDevice(ctx->device);
     return combine_plan_create(ctx, copies, n_copies, captures, n_captures, rows_bytes, d_arena, arena_bytes, nperseg, pct, rise_db,
                                d_pairs, d_lags, d_peaks, d_margins, out);
+}
+
+// the host-side validation of gj_combine_plan_create alone: touches no GPU, needs no context
+int gj_combine_plan_check(const gj_combine_copy* copies, int n_copies, const gj_combine_capture* captures, int n_captures,
+                          size_t rows_bytes, const void* d_arena, size_t arena_bytes, int nperseg, int have_pairs) {
+    if (!copies || !captures || !d_arena) return GJ_ERR_INVALID;
+    if (n_copies < 1 || n_copies > 65535 || n_captures < 1 || n_captures > 1024) return GJ_ERR_INVALID;
+    if (nperseg < 16 || nperseg > 4096 || (nperseg & (nperseg - 1))) return GJ_ERR_UNSUPPORTED;
+    return combine_plan_check(nullptr, copies, n_copies, captures, n_captures, rows_bytes, d_arena, arena_bytes, nperseg,
+                              have_pairs != 0, nullptr, nullptr, nullptr);
 }
 
 int gj_split_combine_dev(gj_ctx* ctx, const gj_combine_plan* plan, const double* d_rows) {

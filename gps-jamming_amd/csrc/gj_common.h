@@ -406,6 +406,8 @@ int launch_pack_part(gj_ctx*, const gj_part_pack&, double*);
 int launch_combine_stats(gj_ctx*, const gj_combine_capture*, int, float, float);
 int combine_plan_create(gj_ctx*, const gj_combine_copy*, int, const gj_combine_capture*, int, size_t, const void*, size_t, int, float,
                         float, const int32_t*, const int32_t*, const float*, const float*, gj_combine_plan**);
+int combine_plan_check(gj_ctx*, const gj_combine_copy*, int, const gj_combine_capture*, int, size_t, const void*, size_t, int, bool, size_t*,
+                       size_t*, int*);
 void combine_plan_destroy(gj_combine_plan*);
 int launch_split_combine(gj_ctx*, const gj_combine_plan*, const double*);
 int launch_acq_search(gj_ctx*, const uint8_t*, size_t, size_t, int, int, const int16_t*, int, const uint8_t*, int, int, double,

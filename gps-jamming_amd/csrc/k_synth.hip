@@ -323,16 +323,20 @@ namespace gj {
 static size_t copy_dst_bytes(uint32_t kind) { return kind == GJ_COPY_F64 ? 8 : 4; }
 static size_t copy_src_bytes(uint32_t kind) { return kind == GJ_COPY_F32 ? 4 : 8; }
 
-int combine_plan_create(gj_ctx* ctx, const gj_combine_copy* copies, int n_copies, const gj_combine_capture* caps, int n_caps,
-                        size_t rows_bytes, const void* d_arena, size_t arena_bytes, int nperseg, float pct, float rise_db,
-                        const int32_t* d_pairs, const int32_t* d_lags, const float* d_peaks, const float* d_margins,
-                        gj_combine_plan** out) {
-    // Everything the three kernels will index is checked HERE, once, on the host: a copy that reads outside the gathered
-    // vectors or writes outside the arena, or a descriptor whose arrays do not fit, never reaches the GPU.
-    const uintptr_t a0 = reinterpret_cast<uintptr_t>(d_arena), a1 = a0 + arena_bytes;
-    auto inside = [&](const void* p, size_t bytes, size_t align) {
+// Everything the three kernels will index is checked HERE, once, on the host: a copy that reads outside the gathered
+// vectors or writes outside the arena, or a descriptor whose arrays do not fit, never reaches the GPU.  Every bound is
+// taken by DIVISION (count <= room / element): the fields are caller-supplied 64-bit numbers, and a product such as
+// count * stride wraps for count = 2^61 and would pass a comparison of sums.
+int combine_plan_check(gj_ctx* ctx, const gj_combine_copy* copies, int n_copies, const gj_combine_capture* caps, int n_caps,
+                       size_t rows_bytes, const void* d_arena, size_t arena_bytes, int nperseg, bool have_pairs, size_t* max_count_out,
+                       size_t* max_chunks_out, int* max_pair_cap_out) {
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(d_arena);
+    if (arena_bytes > UINTPTR_MAX - a0) return fail(ctx, GJ_ERR_INVALID, "the arena wraps the address space");
+    // `count` elements of `elem` bytes at p lie inside the arena
+    auto inside = [&](const void* p, unsigned long long count, size_t elem, size_t align) {
         const uintptr_t u = reinterpret_cast<uintptr_t>(p);
-        return p && u % align == 0 && u >= a0 && bytes <= arena_bytes && u + bytes <= a1;
+        if (!p || u % align != 0 || u < a0 || u - a0 > arena_bytes) return false;
+        return count <= (arena_bytes - (u - a0)) / elem;
     };
     size_t max_count = 0;
     for (int k = 0; k < n_copies; ++k) {
@@ -342,32 +346,53 @@ int combine_plan_create(gj_ctx* ctx, const gj_combine_copy* copies, int n_copies
         const size_t se = copy_src_bytes(c.kind), de = copy_dst_bytes(c.kind);
         if (c.src_stride < se || c.src_byte % se || c.src_stride % se)
             return fail(ctx, GJ_ERR_INVALID, "copy %d: source offset / stride not aligned to its element", k);
-        const size_t last = c.src_byte + (c.count - 1) * (size_t)c.src_stride + se;
-        if (last > rows_bytes) return fail(ctx, GJ_ERR_INVALID, "copy %d reads to byte %zu of %zu gathered", k, last, rows_bytes);
-        if (!inside(reinterpret_cast<const void*>(c.dst), c.count * de, de))
+        // last element ends at src_byte + (count - 1) * stride + se <= rows_bytes
+        if (rows_bytes < se || c.src_byte > rows_bytes - se || c.count - 1 > (rows_bytes - se - c.src_byte) / c.src_stride)
+            return fail(ctx, GJ_ERR_INVALID, "copy %d reads %llu elements from byte %llu, stride %u: beyond the %zu bytes gathered", k,
+                        (unsigned long long)c.count, (unsigned long long)c.src_byte, c.src_stride, rows_bytes);
+        if (!inside(reinterpret_cast<const void*>(c.dst), c.count, de, de))
             return fail(ctx, GJ_ERR_INVALID, "copy %d writes outside the arena", k);
-        if (c.count > max_count) max_count = c.count;
+        if (c.count > max_count) max_count = (size_t)c.count;
     }
     size_t max_chunks = 0;
     int max_pair_cap = 0;
     for (int a = 0; a < n_caps; ++a) {
         const gj_combine_capture& c = caps[a];
-        if (c.n_chunks == 0 || c.n_parts < 1 || c.n_pairs < 0 || c.n_pairs > c.pair_cap)
+        if (c.n_chunks == 0 || c.n_parts < 1 || c.n_pairs < 0 || c.pair_cap < 0 || c.n_pairs > c.pair_cap)
             return fail(ctx, GJ_ERR_INVALID, "capture %d: empty power map, no parts or more pairs than capacity", a);
         if (c.n_tiles != amp_tile_count(c.total_bytes))
             return fail(ctx, GJ_ERR_INVALID, "capture %d of %llu bytes has %zu tiles, not %llu", a, (unsigned long long)c.total_bytes,
                         amp_tile_count(c.total_bytes), (unsigned long long)c.n_tiles);
-        const size_t out_len = GJ_RESULT_HEADER + c.n_chunks + (size_t)nperseg + (size_t)GJ_RESULT_PAIR_FIELDS * c.pair_cap;
-        if (!inside(c.d_power, c.n_chunks * 4, 4) || !inside(c.d_stats, 12, 4) || !inside(c.d_tiles, c.n_tiles * 16, 8) ||
-            !inside(c.d_amp_parts, (size_t)c.n_parts * sizeof(gj_amp_part), 8) ||
-            !inside(c.d_onset_parts, (size_t)c.n_parts * sizeof(gj_onset), 8) || !inside(c.d_amp, sizeof(gj_amp_stats), 8) ||
-            !inside(c.d_onset, sizeof(gj_onset), 8) || !inside(c.d_psd, (c.rows ? c.rows : 1) * (size_t)nperseg * 4, 4) ||
-            !inside(c.d_out, out_len * 8, 8))
+        // result vector: 40 + n_chunks + nperseg + 5 pair_cap doubles; the sum cannot wrap once each term is below 2^60
+        if (c.n_chunks > (1ull << 60) || c.rows > (1ull << 60))
+            return fail(ctx, GJ_ERR_INVALID, "capture %d: %llu chunks, %llu rows", a, (unsigned long long)c.n_chunks, (unsigned long long)c.rows);
+        const unsigned long long out_len = GJ_RESULT_HEADER + c.n_chunks + (unsigned long long)nperseg +
+                                           (unsigned long long)GJ_RESULT_PAIR_FIELDS * (unsigned long long)c.pair_cap;
+        if (!inside(c.d_power, c.n_chunks, 4, 4) || !inside(c.d_stats, 3, 4, 4) || !inside(c.d_tiles, c.n_tiles, 16, 8) ||
+            !inside(c.d_amp_parts, (unsigned long long)c.n_parts, sizeof(gj_amp_part), 8) ||
+            !inside(c.d_onset_parts, (unsigned long long)c.n_parts, sizeof(gj_onset), 8) || !inside(c.d_amp, 1, sizeof(gj_amp_stats), 8) ||
+            !inside(c.d_onset, 1, sizeof(gj_onset), 8) || !inside(c.d_psd, c.rows ? c.rows : 1, (size_t)nperseg * 4, 4) ||
+            !inside(c.d_out, out_len, 8, 8))
             return fail(ctx, GJ_ERR_INVALID, "capture %d: an array lies outside the arena", a);
-        if (c.n_pairs && (!d_pairs || !d_lags || !d_peaks || !d_margins)) return fail(ctx, GJ_ERR_INVALID, "null pair buffer");
-        if (c.n_chunks > max_chunks) max_chunks = c.n_chunks;
+        if (c.n_pairs && !have_pairs) return fail(ctx, GJ_ERR_INVALID, "null pair buffer");
+        if (c.n_chunks > max_chunks) max_chunks = (size_t)c.n_chunks;
         if (c.pair_cap > max_pair_cap) max_pair_cap = c.pair_cap;
     }
+    if (max_count_out) *max_count_out = max_count;
+    if (max_chunks_out) *max_chunks_out = max_chunks;
+    if (max_pair_cap_out) *max_pair_cap_out = max_pair_cap;
+    return GJ_OK;
+}
+
+int combine_plan_create(gj_ctx* ctx, const gj_combine_copy* copies, int n_copies, const gj_combine_capture* caps, int n_caps,
+                        size_t rows_bytes, const void* d_arena, size_t arena_bytes, int nperseg, float pct, float rise_db,
+                        const int32_t* d_pairs, const int32_t* d_lags, const float* d_peaks, const float* d_margins,
+                        gj_combine_plan** out) {
+    size_t max_count = 0, max_chunks = 0;
+    int max_pair_cap = 0;
+    const int rc = combine_plan_check(ctx, copies, n_copies, caps, n_caps, rows_bytes, d_arena, arena_bytes, nperseg,
+                                      d_pairs && d_lags && d_peaks && d_margins, &max_count, &max_chunks, &max_pair_cap);
+    if (rc) return rc;
     gj_combine_plan* p = new (std::nothrow) gj_combine_plan();
     if (!p) return GJ_ERR_NOMEM;
     p->n_copies = n_copies; p->n_caps = n_caps; p->nperseg = nperseg; p->max_count = max_count; p->max_chunks = max_chunks;

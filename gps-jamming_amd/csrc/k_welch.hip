@@ -62,6 +62,12 @@
 #ifndef GJ_W_CARRY_MASK
 #define GJ_W_CARRY_MASK 0x1400u   // bit k set: transform size 2^k carries.  1024 and 4096; 2048 spills with it (+2 %, measured)
 #endif
+#ifndef GJ_W_WAVEFENCE
+// 1: for N <= 1024 the LDS exchange is ordered by a wavefront fence (a transform lies inside one wave); 0: by the
+// workgroup barrier, as for the larger sizes.  The second form is built as libgpsjam_hip_barrier.so (Makefile) and
+// tests/test_round5_gpu.py compares the two byte for byte: the fence path must never depend on a barrier it removed.
+#define GJ_W_WAVEFENCE 1
+#endif
 #ifndef GJ_W_XPOSE
 #define GJ_W_XPOSE 1     // 1: N = 4096 uses the bank-conflict-free exchange schedule (fft_core.h X4096)
 #endif
@@ -125,7 +131,7 @@ struct WelchBins {   // (thread, slot) that ends up holding bin k
 // four times per segment (round 4: welch_kernel<1024> is the reference's own FFT size, skrypty/widmo_plot.py:10).
 template <int N>
 __device__ __forceinline__ void welch_exchange_sync() {
-    if constexpr (N / 16 <= 64) {
+    if constexpr (N / 16 <= 64 && GJ_W_WAVEFENCE != 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -197,6 +203,13 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
     __shared__ cf lds1[Cfg::dbuf ? SPAN : 1];
     // (sum I, sum Q) per wave; three slots when half-segment sums are carried over (see HS below)
     __shared__ float wsum[3][B][WPF][2];
+    // What welch_exchange_sync<N>'s wave fence (N <= 1024) rests on: a transform group is an aligned
+    // fraction of ONE wave -- group index tid / TF with TF | 64 -- so every LDS word a lane gathers was scattered by a
+    // lane of its own wave; and the group's (sum I, sum Q) slot wsum[.][b][0] is written by a lane of that wave and read
+    // only by lanes of it (WPF == 1).  Changing the block size, the thread-to-group mapping or adding a cross-wave LDS
+    // use for these sizes must bring the workgroup barrier back.
+    static_assert(TF > 64 || (64 % TF == 0 && WPF == 1 && kBlockThreads % 64 == 0 && B * TF == kBlockThreads),
+                  "the wave-fence exchange needs a transform group inside one wave");
     const int tid = threadIdx.x;
     // a transform group of one wave or more: its index is wave-uniform, so the run bookkeeping lives in SGPRs
     const int b = (TF >= 64) ? __builtin_amdgcn_readfirstlane(tid / TF) : tid / TF;

@@ -614,6 +614,15 @@ class Device:
                                            fs, _ffi.GJ_WELCH_SHIFT if shift else 0, _ptr(d_psd),
                                            _ptr(d_psd_db) or None))
 
+    def welch_timed_dev(self, d_iq, nbytes, chunk_samples, nperseg, fs, d_psd, d_psd_db=None, shift=True):
+        """welch_dev with events around the transform kernel and around the finalize launch; synchronises.
+        Returns (kernel_ms, finalize_ms) (gj_welch_timed_dev)."""
+        k, f = C.c_float(0), C.c_float(0)
+        self._check(self._lib.gj_welch_timed_dev(self._ctx, _ptr(d_iq), nbytes, chunk_samples, nperseg, fs,
+                                                 _ffi.GJ_WELCH_SHIFT if shift else 0, _ptr(d_psd), _ptr(d_psd_db) or None,
+                                                 C.byref(k), C.byref(f)))
+        return float(k.value), float(f.value)
+
     def byte_histogram_dev(self, d_iq, nbytes, chunk_samples, nperseg, stride, d_hist):
         self._check(self._lib.gj_byte_histogram_dev(self._ctx, _ptr(d_iq), nbytes, chunk_samples,
                                                     nperseg, stride, _ptr(d_hist)))

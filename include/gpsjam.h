@@ -187,6 +187,12 @@ int gj_welch_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_s
 int gj_welch_u8(gj_ctx* ctx, const uint8_t* iq, size_t nbytes, size_t chunk_samples,
                 int nperseg, double fs, int flags, float* psd, float* psd_db, size_t cap_floats,
                 size_t* rows_out, float* kernel_ms);
+/* Measurement: gj_welch_dev with HIP events around the transform launch and around the finalize launch (the sum over
+ * the per-workgroup spectra, scaling, fftshift, dB), on the context's stream; synchronises and reports both.  bench.py
+ * times K2 at nperseg 4096 and 1024 with it, interleaved, so that the two figures of one line come from the same
+ * minute of the same box. */
+int gj_welch_timed_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_samples, int nperseg, double fs,
+                       int flags, float* d_psd, float* d_psd_db, float* kernel_ms, float* finalize_ms);
 /* workspace bytes gj_welch_dev needs for this input (for gj_reserve) */
 size_t gj_welch_workspace(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int nperseg);
 
@@ -497,6 +503,11 @@ int gj_combine_plan_create(gj_ctx* ctx, const gj_combine_copy* copies, int n_cop
                            float pct, float rise_db, const int32_t* d_pairs /* every solved pair, static */,
                            const int32_t* d_lags, const float* d_peaks, const float* d_margins /* assembled */,
                            gj_combine_plan** out);
+/* The validation of gj_combine_plan_create alone (host arithmetic only; no context, no GPU): GJ_OK, or the status the
+ * create call would return for these lists.  Bounds are taken by division, so a count or stride chosen to wrap a 64-bit
+ * product is refused like any other out-of-range value. */
+int gj_combine_plan_check(const gj_combine_copy* copies, int n_copies, const gj_combine_capture* captures, int n_captures,
+                          size_t rows_bytes, const void* d_arena, size_t arena_bytes, int nperseg, int have_pairs);
 int gj_split_combine_dev(gj_ctx* ctx, const gj_combine_plan* plan, const double* d_rows);
 int gj_combine_plan_destroy(gj_ctx* ctx, gj_combine_plan* plan); /* idempotent on NULL; synchronises the context's stream */
 

@@ -98,6 +98,19 @@ def test_self_launch_two_ranks_share_gpu():
     assert line["self_check"]["devices_ok"] is True     # --share-gpu announced it
 
 
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_rccl_ranks_on_one_gpu_do_not_pass_as_a_two_gpu_run():
+    """`--gpus 2 --share-gpu` WITHOUT `--backend gloo`: two RCCL ranks cannot share a device.  Whatever the library makes
+    of it -- refusing the communicator, or timing out -- the run must end non-zero and must not print a line that reads
+    as a two-GPU result."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--share-gpu", "--rendezvous-only", "--no-diagnosis",
+                        "--launch-timeout", "240"], capture_output=True, text=True, env=_env(), timeout=560)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode != 0, (r.stdout[-500:], r.stderr[-1500:])
+    assert not any('"rendezvous": "ok"' in ln or '"n_gpus": 2' in ln for ln in lines), lines
+
+
 def test_self_check_refuses_ranks_on_one_device():
     """N ranks that report fewer than N physical devices without --share-gpu fail the line's self_check."""
     sys.path.insert(0, REPO)

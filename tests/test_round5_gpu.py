@@ -364,3 +364,44 @@ def test_probe_cap_and_checked_search(dev):
         assert ok and streams.runs_beside(dev, main, s) and not streams.runs_beside(dev, main, main)
     finally:
         dev.set_stream(None, external=False)
+
+
+# ----------------------------------------------------------------------------- K2's wave-fence exchange against plain barriers
+WELCH_CHILD = r"""
+import hashlib, os, sys
+sys.path.insert(0, os.path.join(sys.argv[1], "gps-jamming_amd"))
+import numpy as np
+import gpsjam
+from gpsjam.synth import StreamSpec, generate
+raw = generate(StreamSpec(seed=404, jam_start=300_000, jam_end=900_000, jam_sigma=45.0, dc_i_q8=384, dc_q_q8=-192), 1_200_000)
+with gpsjam.Device(0) as dev:
+    print("LIB", os.path.basename(gpsjam.library_path()))
+    for n in (16, 32, 64, 128, 256, 512, 1024, 2048, 4096):
+        for chunk in (200_000, 131_072 + 7 * n):
+            psd, _ = dev.welch(raw, chunk_samples=chunk, nperseg=n, want_db=False)
+            print("PSD", n, chunk, psd.shape[0], hashlib.sha256(np.ascontiguousarray(psd).tobytes()).hexdigest())
+"""
+
+
+def test_welch_wave_fence_exchange_equals_the_barrier_build(tmp_path):
+    """For N <= 1024 K2 orders its LDS exchange with a wavefront fence instead of a workgroup barrier (a transform lies
+    inside one wave).  The same sources built with -DGJ_W_WAVEFENCE=0 (csrc/libgpsjam_hip_barrier.so, made by the
+    Makefile next to the product library) must give the same PSD bytes at every size, full and ragged chunks -- a race
+    the removed barriers used to hide would show as differing bits."""
+    libdir = os.path.join(REPO, "gps-jamming_amd", "csrc")
+    variant = os.path.join(libdir, "libgpsjam_hip_barrier.so")
+    if not os.path.exists(variant):
+        subprocess.run(["make", "-C", libdir, "-j", "8", "libgpsjam_hip_barrier.so"], check=True, timeout=900)
+    script = tmp_path / "welch_child.py"
+    script.write_text(WELCH_CHILD)
+    outs = {}
+    for name, lib in (("fence", None), ("barrier", variant)):
+        env = dict(os.environ)
+        env.pop("GPSJAM_LIB", None)
+        if lib:
+            env["GPSJAM_LIB"] = lib
+        p = subprocess.run([sys.executable, str(script), REPO], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stdout + p.stderr
+        outs[name] = p.stdout.splitlines()
+    assert outs["fence"][0] == "LIB libgpsjam_hip.so" and outs["barrier"][0] == "LIB libgpsjam_hip_barrier.so"
+    assert len(outs["fence"]) == 19 and outs["fence"][1:] == outs["barrier"][1:]

@@ -152,3 +152,55 @@ def test_copy_list_rebuilds_every_capture_in_order(sizes, world):
         # the pairs in the order of the static pair table rank 0 packs beside them
         assert st._d_all_pairs.tolist()[:2 * q] == [x for r in sorted(st.deal) for pr in st.deal[r] for x in pr]
     st.close()
+
+
+# ----------------------------------------------------------------------------- the plan's bounds must not wrap
+def _plan_lists(arena, n_chunks=8, nperseg=1024):
+    """One capture whose arrays sit in `arena` (a numpy buffer standing in for device memory: the check is address
+    arithmetic only) + one honest copy into its power map."""
+    base = arena.ctypes.data
+    off = iter(range(0, 1 << 20, 1 << 12))
+    cap = _ffi.CombineCapture(n_chunks=n_chunks, rows=1, n_tiles=n_chunks, total_bytes=n_chunks * 65536, n_parts=2, antenna=0,
+                              n_pairs=0, pair_cap=3, d_power=base + next(off), d_stats=base + next(off), d_tiles=base + next(off),
+                              d_amp_parts=base + next(off), d_onset_parts=base + next(off), d_amp=base + next(off),
+                              d_onset=base + next(off), d_psd=base + 0x10000, d_out=base + 0x20000)
+    copy = _ffi.CombineCopy(src_byte=40 * 8, dst=cap.d_power, count=n_chunks, src_stride=8, kind=_ffi.GJ_COPY_F64_F32)
+    return cap, copy
+
+
+def _check(lib, copies, caps, rows_bytes, arena, nperseg=1024):
+    cs = (_ffi.CombineCopy * len(copies))(*copies)
+    ca = (_ffi.CombineCapture * len(caps))(*caps)
+    return lib.gj_combine_plan_check(cs, len(copies), ca, len(caps), rows_bytes, arena.ctypes.data, arena.nbytes, nperseg, 0)
+
+
+def test_combine_plan_bounds_are_taken_by_division():
+    """gj_combine_plan_create promises that a bad copy or descriptor never reaches the GPU.  Its fields are caller-supplied
+    64-bit numbers: a count of 2^61 makes count * 8 wrap to 0, a count of 2^61 + 1 with stride 8 makes the last source
+    byte wrap to a small number -- sums and products pass where the honest bound does not.  gj_combine_plan_check is the
+    create call's validation alone (host arithmetic, no GPU)."""
+    lib = _ffi.load()
+    arena = np.zeros(1 << 20, np.uint8)
+    rows_bytes = 4096
+    cap, copy = _plan_lists(arena)
+    assert _check(lib, [copy], [cap], rows_bytes, arena) == 0                       # the honest plan passes
+    bad = []
+    for count, stride in ((1 << 61, 8), ((1 << 61) + 1, 8), (1 << 63, 8), ((1 << 64) - 1, 8), (1 << 32, 1 << 31), (513, 8)):
+        c = _ffi.CombineCopy(src_byte=copy.src_byte, dst=copy.dst, count=count, src_stride=stride, kind=copy.kind)
+        bad.append(("count %d stride %d" % (count, stride), [c], [cap]))
+    c = _ffi.CombineCopy(src_byte=(1 << 64) - 8, dst=copy.dst, count=2, src_stride=8, kind=copy.kind)   # src_byte + stride wraps
+    bad.append(("src_byte at the top of the address space", [c], [cap]))
+    c = _ffi.CombineCopy(src_byte=0, dst=arena.ctypes.data + arena.nbytes - 4, count=2, src_stride=8, kind=copy.kind)
+    bad.append(("destination runs off the arena", [c], [cap]))
+    for field, value in (("n_chunks", 1 << 62), ("n_chunks", (1 << 64) - 40), ("rows", 1 << 61), ("n_parts", 1 << 30),
+                         ("pair_cap", (1 << 31) - 1)):
+        cap2, _ = _plan_lists(arena)
+        setattr(cap2, field, value)
+        if field == "n_chunks":
+            cap2.n_tiles, cap2.total_bytes = 8, 8 * 65536
+        bad.append((f"capture {field} = {value}", [copy], [cap2]))
+    for what, copies, caps in bad:
+        assert _check(lib, copies, caps, rows_bytes, arena) == -1, what               # GJ_ERR_INVALID, never a wrapped "ok"
+    # limits of the lists themselves
+    assert lib.gj_combine_plan_check(None, 1, None, 1, 0, None, 0, 1024, 0) == -1
+    assert _check(lib, [copy], [cap], rows_bytes, arena, nperseg=1000) == -5

@@ -21,7 +21,10 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 FAMILIES = {
     # run_kernel.py mode -> (kernel-name substrings of the family, sources hashed)
-    "fscan": (("stream_scan_kernel", "amp_finalize", "onset_", "chunk_power_finalize"), ("k_scan.hip",)),
+    "fscan": (("stream_scan_kernel", "scan_tail_kernel", "amp_finalize", "onset_", "chunk_power_finalize"), ("k_scan.hip",)),
+    # round 5: what a pipeline step launches per capture (gj_capture_scan_dev: fused pass + tail with threshold; the slot
+    # kernel only for slices beyond the tail's own limit)
+    "cscan": (("stream_scan_kernel", "scan_tail_kernel", "tdoa_slot_kernel", "chunk_power_finalize"), ("k_scan.hip",)),
     "xcorr3": (("xc_",), ("k_xcorr.hip", "fft_core.h")),
     "acq": (("acq_",), ("k_acq.hip", "fft_core.h")),
     "welch": (("welch_",), ("k_welch.hip", "fft_core.h")),
