@@ -450,6 +450,13 @@ int gj_welch_timed_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t c
     return rc;
 }
 
+int gj_welch_batch_dev(gj_ctx* ctx, const uint8_t* const* d_iq, int n_captures, size_t nbytes_each, size_t chunk_samples, int nperseg,
+                       double fs, int flags, float* const* d_psd) {
+    GJ_ENTER(ctx);
+    if (!d_iq || !d_psd) return fail(ctx, GJ_ERR_INVALID, "null buffer");
+    return launch_welch_batch(ctx, d_iq, n_captures, nbytes_each, chunk_samples, nperseg, fs, flags, d_psd);
+}
+
 int gj_byte_histogram_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_samples, int nperseg, int stride,
                           uint64_t* d_hist) {
     GJ_ENTER(ctx);
@@ -685,6 +692,14 @@ int gj_combine_plan_create(gj_ctx* ctx, const gj_combine_copy* copies, int n_cop
     (void)hipSetDevice(ctx->device);
     return combine_plan_create(ctx, copies, n_copies, captures, n_captures, rows_bytes, d_arena, arena_bytes, nperseg, pct, rise_db,
                                d_pairs, d_lags, d_peaks, d_margins, out);
+}
+
+int gj_pack_results_dev(gj_ctx* ctx, const gj_combine_capture* captures, int n_captures, int nperseg, const int32_t* d_pairs,
+                        const int32_t* d_lags, const float* d_peaks, const float* d_margins) {
+    GJ_ENTER(ctx);
+    if (!captures) return fail(ctx, GJ_ERR_INVALID, "null argument");
+    if (nperseg < 16 || nperseg > 4096 || (nperseg & (nperseg - 1))) return fail(ctx, GJ_ERR_UNSUPPORTED, "nperseg %d", nperseg);
+    return launch_pack_results(ctx, captures, n_captures, nperseg, d_pairs, d_lags, d_peaks, d_margins);
 }
 
 // the host-side validation of gj_combine_plan_create alone: touches no GPU, needs no context

@@ -474,17 +474,17 @@ __device__ long long amp_block_first(const AmpTile* __restrict__ tiles, size_t n
     if (threadIdx.x == 0) *first_s = 0x7fffffffffffffffll;
     __syncthreads();
     long long f = 0x7fffffffffffffffll;
-    // eight independent loads in flight per thread: this single workgroup is latency-bound, and beside K2 every
-    // round trip is slow
-    for (size_t t = threadIdx.x; t < ntiles; t += 8 * (size_t)blockDim.x) {
-        long long v[8];
+    // sixteen independent loads in flight per thread: this single workgroup is latency-bound (a 1-GiB capture has
+    // 16 384 tiles = 64 per thread: four round trips instead of eight), and beside K2 every round trip is slow
+    for (size_t t = threadIdx.x; t < ntiles; t += 16 * (size_t)blockDim.x) {
+        long long v[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 16; ++k) {
             const size_t tt = t + (size_t)k * blockDim.x;
             v[k] = tt < ntiles ? tiles[tt].first : 0x7fffffffffffffffll;
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) f = v[k] < f ? v[k] : f;
+        for (int k = 0; k < 16; ++k) f = v[k] < f ? v[k] : f;
     }
     if (f != 0x7fffffffffffffffll) atomicMin(first_s, f);
     __syncthreads();
@@ -504,14 +504,24 @@ __device__ double amp_block_tail(const uint8_t* __restrict__ iq, size_t nsamples
 
 __device__ double amp_block_total(const AmpTile* __restrict__ tiles, size_t ntiles, size_t t0, double* sh) {
     double acc = 0.0;
-    for (size_t t = t0 + 1 + threadIdx.x; t < ntiles; t += 8 * (size_t)blockDim.x) {
-        double v[8];
+    // The ORDER of the additions is fixed (it is what makes a capture's sum the same bits whether it is summed here, on
+    // the combining rank of a split run or after an ingest): per thread, groups of eight tiles a block-stride apart,
+    // each group added as ((v0+v1)+(v2+v3))+((v4+v5)+(v6+v7)), the groups in ascending order.  Round 5 only moves the
+    // LOADS: two groups' worth are issued before the first addition (16 in flight instead of 8).
+    for (size_t t = t0 + 1 + threadIdx.x; t < ntiles; t += 16 * (size_t)blockDim.x) {
+        double v[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 16; ++k) {
             const size_t tt = t + (size_t)k * blockDim.x;
             v[k] = tt < ntiles ? tiles[tt].sum : 0.0;
         }
-        acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            // a group that starts beyond the end adds +0.0 to a non-negative sum: the value is unchanged, as if the
+            // loop had ended there
+            if (t + (size_t)(8 * g) * blockDim.x < ntiles)
+                acc += ((v[8 * g] + v[8 * g + 1]) + (v[8 * g + 2] + v[8 * g + 3])) + ((v[8 * g + 4] + v[8 * g + 5]) + (v[8 * g + 6] + v[8 * g + 7]));
+        }
     }
     return block_sum_f64(acc, sh);
 }

@@ -305,6 +305,46 @@ __global__ __launch_bounds__(1024) void pack_result_batch_kernel(const gj_combin
                      c.n_pairs, c.pair_cap, pairs, lags, peaks, margins, c.d_out, part);
 }
 
+// the same with the descriptors in the kernel arguments (gj_pack_results_dev: up to GJ_MAX_ANTENNAS captures of one
+// deployment in ONE launch, no device-side descriptor array to keep)
+struct PackBatch {
+    gj_combine_capture c[GJ_MAX_ANTENNAS];
+};
+__global__ __launch_bounds__(1024) void pack_result_multi_kernel(PackBatch B, int nperseg, const int* __restrict__ pairs,
+                                                                 const int* __restrict__ lags, const float* __restrict__ peaks,
+                                                                 const float* __restrict__ margins) {
+    __shared__ float part[16][64];
+    const gj_combine_capture& c = B.c[blockIdx.y];
+    pack_result_body((size_t)c.n_chunks, c.d_power, c.d_stats, c.d_amp, c.d_onset, c.d_psd, (size_t)c.rows, nperseg, c.antenna,
+                     c.n_pairs, c.pair_cap, pairs, lags, peaks, margins, c.d_out, part);
+}
+
+int launch_pack_results(gj_ctx* ctx, const gj_combine_capture* caps, int n_caps, int nperseg, const int32_t* d_pairs,
+                        const int32_t* d_lags, const float* d_peaks, const float* d_margins) {
+    if (n_caps < 1 || n_caps > GJ_MAX_ANTENNAS) return fail(ctx, GJ_ERR_INVALID, "n_captures must be 1..%d", GJ_MAX_ANTENNAS);
+    PackBatch B;
+    memset(&B, 0, sizeof(B));
+    size_t max_chunks = 0;
+    int max_pair_cap = 0;
+    for (int a = 0; a < n_caps; ++a) {
+        const gj_combine_capture& c = caps[a];
+        if (!c.d_power || !c.d_stats || !c.d_amp || !c.d_onset || !c.d_psd || !c.d_out)
+            return fail(ctx, GJ_ERR_INVALID, "capture %d: null buffer", a);
+        if (c.n_pairs < 0 || c.pair_cap < 0 || c.n_pairs > c.pair_cap) return fail(ctx, GJ_ERR_INVALID, "capture %d: %d pairs, capacity %d", a, c.n_pairs, c.pair_cap);
+        if (c.n_pairs && (!d_pairs || !d_lags || !d_peaks || !d_margins)) return fail(ctx, GJ_ERR_INVALID, "null pair buffer");
+        B.c[a] = c;
+        if (c.n_chunks > max_chunks) max_chunks = (size_t)c.n_chunks;
+        if (c.pair_cap > max_pair_cap) max_pair_cap = c.pair_cap;
+    }
+    const unsigned spec_blocks = (unsigned)((nperseg + 63) / 64);
+    size_t copy_blocks = (GJ_RESULT_HEADER + max_chunks + (size_t)GJ_RESULT_PAIR_FIELDS * max_pair_cap + 1023) / 1024;
+    if (copy_blocks > 256) copy_blocks = 256;
+    hipLaunchKernelGGL(pack_result_multi_kernel, dim3(spec_blocks + (unsigned)copy_blocks, (unsigned)n_caps), dim3(1024), 0, ctx->stream,
+                       B, nperseg, d_pairs, d_lags, d_peaks, d_margins);
+    GJ_LAUNCH_CHECK(ctx);
+    return GJ_OK;
+}
+
 }   // namespace gj
 
 struct gj_combine_plan {

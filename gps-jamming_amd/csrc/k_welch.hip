@@ -180,11 +180,20 @@ __device__ __forceinline__ void welch_passes_x4096(c2 (&v)[16], cf* lds0, cf* ld
     fft_pass<4096, 2, GJ_W_TWOSTEP != 0, GJ_W_FMA != 0>(v, tw[2], ktw);
 }
 
-template <int N>
+// Several captures of ONE size in one launch (gj_welch_batch_dev: the reference's deployment is three antenna files of one
+// length, worker.py:97-101): chunk c of the launch is chunk c % rows_each of capture c / rows_each.  The single-capture
+// instantiation (BATCHED = false) is the kernel as it was: nothing of this reaches its code.
+struct WelchBatch {
+    const uint8_t* iq[GJ_MAX_ANTENNAS];
+    unsigned rows_each;
+};
+
+template <int N, bool BATCHED = false>
 __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_kernel(const uint8_t* __restrict__ iq, WelchGeom g,
                                                               const cf* __restrict__ twtab,
                                                               const float* __restrict__ wintab,
-                                                              float* __restrict__ partial, unsigned wg_base) {
+                                                              float* __restrict__ partial, unsigned wg_base,
+                                                              WelchBatch batch = WelchBatch()) {
     // wg_base: index of this launch's first workgroup in the whole capture's grid (0 unless the capture is
     // transformed piece by piece while it is still being uploaded, gj_ingest_*)
     constexpr int TF = N / 16, B = kBlockPoints / N, NP = fft_npass(N);
@@ -216,8 +225,14 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
     const int jl0 = tid % TF;   // jl0: butterfly of pass 0 (input index jl0 + TF s)
     const int jl = XP ? X4096::jl1(tid) : jl0;   // butterfly of the later passes = bins held at the end
     const unsigned wg = blockIdx.x + wg_base;
-    const unsigned c = wg / g.splits, part = wg % g.splits;
-    const unsigned nseg = (c + 1 == g.nchunks) ? g.nseg_last : g.nseg_full;
+    unsigned c = wg / g.splits;
+    const unsigned part = wg % g.splits;
+    if constexpr (BATCHED) {
+        const unsigned cap = c / batch.rows_each;
+        iq = batch.iq[cap];
+        c -= cap * batch.rows_each;
+    }
+    const unsigned nseg = (c + 1 == (BATCHED ? batch.rows_each : g.nchunks)) ? g.nseg_last : g.nseg_full;
     const unsigned seg_lo = (unsigned)((unsigned long long)part * nseg / g.splits);
     const unsigned seg_hi = (unsigned)((unsigned long long)(part + 1) * nseg / g.splits);
 
@@ -449,12 +464,17 @@ __global__ __launch_bounds__(256) void welch_finalize_scalar_kernel(const float*
 }
 
 // four consecutive bins per thread: 16-byte loads of the partial rows, 16-byte stores; the same order of summation
+struct WelchOut {
+    float* psd[GJ_MAX_ANTENNAS];
+    unsigned rows_each;    // 0: one capture, rows contiguous in `psd` / `psd_db`
+};
+
 __global__ __launch_bounds__(256) void welch_finalize_kernel(const float* __restrict__ partial, int n, unsigned per_chunk,
                                                              unsigned nchunks, float scale_full, float scale_last,
                                                              int shift, float* __restrict__ psd,
-                                                             float* __restrict__ psd_db) {
+                                                             float* __restrict__ psd_db, WelchOut outs = WelchOut()) {
     __shared__ float4 sh[4][64];
-    const unsigned c = blockIdx.y;
+    unsigned c = blockIdx.y;
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int k = 4 * (blockIdx.x * 64 + cx);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -471,6 +491,12 @@ __global__ __launch_bounds__(256) void welch_finalize_kernel(const float* __rest
     __syncthreads();
     if (ry != 0 || k >= n) return;
     const float4 a0 = sh[0][cx], a1 = sh[1][cx], a2 = sh[2][cx], a3 = sh[3][cx];
+    if (outs.rows_each) {               // batched: row c of the launch is row c % rows_each of capture c / rows_each
+        const unsigned cap = c / outs.rows_each;
+        psd = outs.psd[cap];
+        c -= cap * outs.rows_each;
+        nchunks = outs.rows_each;
+    }
     const float sc = (c + 1 == nchunks) ? scale_last : scale_full;
     const float4 val = make_float4(((a0.x + a1.x) + (a2.x + a3.x)) * sc, ((a0.y + a1.y) + (a2.y + a3.y)) * sc,
                                    ((a0.z + a1.z) + (a2.z + a3.z)) * sc, ((a0.w + a1.w) + (a2.w + a3.w)) * sc);
@@ -552,6 +578,62 @@ template <int N>
 static void welch_launch(gj_ctx* ctx, const uint8_t* d_iq, const WelchPlan& pl, float* partial, unsigned c0, unsigned c1) {
     hipLaunchKernelGGL(welch_kernel<N>, dim3((c1 - c0) * pl.g.splits), dim3(kBlockThreads), 0, ctx->stream, d_iq, pl.g,
                        ctx->d_twiddle, window_table(ctx, N), partial, c0 * pl.g.splits);
+}
+
+template <int N>
+static void welch_launch_batch(gj_ctx* ctx, const WelchPlan& pl, float* partial, const WelchBatch& batch, unsigned n_captures) {
+    hipLaunchKernelGGL((welch_kernel<N, true>), dim3(n_captures * batch.rows_each * pl.g.splits), dim3(kBlockThreads), 0, ctx->stream,
+                       (const uint8_t*)nullptr, pl.g, ctx->d_twiddle, window_table(ctx, N), partial, 0u, batch);
+}
+
+// n captures of ONE length in one K2 launch + one finalize launch.  Every capture is planned, cut into workgroups and
+// summed exactly as by launch_welch on its own (same plan, same per-chunk partial spectra, same fixed order), so each PSD
+// is the same bits; what goes away is n - 1 launch gaps, n - 1 grid tails and n - 1 finalize launches -- which is what a
+// step over the reference's 10-s captures consists of (profiles/r05_deployment_timeline_*.txt).
+int launch_welch_batch(gj_ctx* ctx, const uint8_t* const* d_iq, int n_captures, size_t nbytes, size_t chunk_samples, int nperseg,
+                       double fs, int flags, float* const* d_psd) {
+    if (n_captures < 1 || n_captures > GJ_MAX_ANTENNAS) return fail(ctx, GJ_ERR_INVALID, "n_captures must be 1..%d", GJ_MAX_ANTENNAS);
+    WelchJob job;
+    int rc = welch_begin(ctx, nbytes, chunk_samples, nperseg, fs, 0, job);
+    if (rc) return rc;
+    if (job.rows == 0) return GJ_OK;
+    WelchPlan pl;
+    memcpy(&pl, job.plan, sizeof(pl));
+    if ((unsigned long long)n_captures * pl.g.nchunks * pl.g.splits > 0x7fffffffull || (unsigned long long)n_captures * pl.g.nchunks > 65535ull)
+        return fail(ctx, GJ_ERR_UNSUPPORTED, "too many chunks for one launch");
+    WelchBatch batch;
+    WelchOut outs;
+    memset(&batch, 0, sizeof(batch));
+    memset(&outs, 0, sizeof(outs));
+    for (int a = 0; a < n_captures; ++a) {
+        if (!d_iq[a] || !d_psd[a]) return fail(ctx, GJ_ERR_INVALID, "null buffer %d", a);
+        if (reinterpret_cast<uintptr_t>(d_iq[a]) & 1) return fail(ctx, GJ_ERR_INVALID, "capture must be 2-byte aligned");
+        if (reinterpret_cast<uintptr_t>(d_psd[a]) & 15) return fail(ctx, GJ_ERR_INVALID, "PSD rows must be 16-byte aligned");
+        batch.iq[a] = d_iq[a];
+        outs.psd[a] = d_psd[a];
+    }
+    batch.rows_each = outs.rows_each = pl.g.nchunks;
+    rc = ensure_workspace(ctx, (size_t)n_captures * job.ws_bytes);
+    if (rc) return rc;
+    float* partial = reinterpret_cast<float*>(ctx->ws);
+    const unsigned n = (unsigned)n_captures;
+    switch (nperseg) {
+        case 16: welch_launch_batch<16>(ctx, pl, partial, batch, n); break;
+        case 32: welch_launch_batch<32>(ctx, pl, partial, batch, n); break;
+        case 64: welch_launch_batch<64>(ctx, pl, partial, batch, n); break;
+        case 128: welch_launch_batch<128>(ctx, pl, partial, batch, n); break;
+        case 256: welch_launch_batch<256>(ctx, pl, partial, batch, n); break;
+        case 512: welch_launch_batch<512>(ctx, pl, partial, batch, n); break;
+        case 1024: welch_launch_batch<1024>(ctx, pl, partial, batch, n); break;
+        case 2048: welch_launch_batch<2048>(ctx, pl, partial, batch, n); break;
+        default: welch_launch_batch<4096>(ctx, pl, partial, batch, n); break;
+    }
+    GJ_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(welch_finalize_kernel, dim3((nperseg / 4 + 63) / 64, n * pl.g.nchunks), dim3(256), 0, ctx->stream, partial,
+                       nperseg, pl.g.splits * (unsigned)pl.batch, n * pl.g.nchunks, (float)pl.scale_full, (float)pl.scale_last,
+                       (flags & GJ_WELCH_SHIFT) ? 1 : 0, (float*)nullptr, (float*)nullptr, outs);
+    GJ_LAUNCH_CHECK(ctx);
+    return GJ_OK;
 }
 
 // The transform of a capture in three steps, so that chunk ranges can be launched while later chunks are still on

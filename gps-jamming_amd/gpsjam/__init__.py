@@ -614,6 +614,21 @@ class Device:
                                            fs, _ffi.GJ_WELCH_SHIFT if shift else 0, _ptr(d_psd),
                                            _ptr(d_psd_db) or None))
 
+    def welch_batch_dev(self, d_iqs, nbytes_each, chunk_samples, nperseg, fs, d_psds, shift=True):
+        """K2 of several captures of ONE length in one launch + one finalize (gj_welch_batch_dev); same bits per capture
+        as welch_dev."""
+        n = len(d_iqs)
+        iq = (C.c_void_p * n)(*[_ptr(p) for p in d_iqs])
+        out = (C.c_void_p * n)(*[_ptr(p) for p in d_psds])
+        self._check(self._lib.gj_welch_batch_dev(self._ctx, iq, n, int(nbytes_each), chunk_samples, nperseg, fs,
+                                                 _ffi.GJ_WELCH_SHIFT if shift else 0, out))
+
+    def pack_results_dev(self, captures, nperseg, d_pairs=None, d_lags=None, d_peaks=None, d_margins=None):
+        """One result vector per capture in ONE launch (gj_pack_results_dev); ``captures``: list of _ffi.CombineCapture."""
+        ca = (_ffi.CombineCapture * len(captures))(*captures)
+        self._check(self._lib.gj_pack_results_dev(self._ctx, ca, len(captures), nperseg, _ptr(d_pairs) or None, _ptr(d_lags) or None,
+                                                  _ptr(d_peaks) or None, _ptr(d_margins) or None))
+
     def welch_timed_dev(self, d_iq, nbytes, chunk_samples, nperseg, fs, d_psd, d_psd_db=None, shift=True):
         """welch_dev with events around the transform kernel and around the finalize launch; synchronises.
         Returns (kernel_ms, finalize_ms) (gj_welch_timed_dev)."""

@@ -165,6 +165,7 @@ SIGNATURES = {
     "gj_power_threshold_dev": (_i, [_vp, _vp, _sz, _f, _f, _vp, _vp]),
     "gj_welch_rows": (_sz, [_sz, _sz, _i]),
     "gj_welch_dev": (_i, [_vp, _vp, _sz, _sz, _i, _d, _i, _vp, _vp]),
+    "gj_welch_batch_dev": (_i, [_vp, C.POINTER(_vp), _i, _sz, _sz, _i, _d, _i, C.POINTER(_vp)]),
     "gj_welch_timed_dev": (_i, [_vp, _vp, _sz, _sz, _i, _d, _i, _vp, _vp, C.POINTER(_f), C.POINTER(_f)]),
     "gj_welch_u8": (_i, [_vp, _vp, _sz, _sz, _i, _d, _i, _vp, _vp, _sz, _psz, _pf]),
     "gj_welch_workspace": (_sz, [_vp, _sz, _sz, _i]),
@@ -198,6 +199,7 @@ SIGNATURES = {
                                     _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
     "gj_split_combine_dev": (_i, [_vp, _vp, _vp]),
     "gj_combine_plan_destroy": (_i, [_vp, _vp]),
+    "gj_pack_results_dev": (_i, [_vp, C.POINTER(CombineCapture), _i, _i, _vp, _vp, _vp, _vp]),
     "gj_combine_plan_check": (_i, [C.POINTER(CombineCopy), _i, C.POINTER(CombineCapture), _i, _sz, _vp, _sz, _i, _i]),
     "gj_acq_search_dev": (_i, [_vp, _vp, _sz, _sz, _i, _i, _vp, _i, _vp, _i, _i, _d, _f, _vp, _vp]),
     "gj_acq_workspace": (_sz, [_vp, _i, _i, _i, _i, _i]),

@@ -6,13 +6,15 @@ skrypty/triangulateTDOA.py:60-90 for a pair of them).
 the third arrangement, and for captures of the reference's size (10 s = 41 MB) the one that matters: a step over such a
 capture is a dozen launches that each take microseconds, so what counts is how many dependent launches stand in a row,
 not bytes.  Per step:
-  main stream      K2 (Welch PSD) of every capture, one after the other -- a K2 launch fills the chip
+  main stream      K2 (Welch PSD) of every capture: ONE launch + one finalize when the captures are of one length
+                   (gj_welch_batch_dev), else one after the other -- a K2 launch fills the chip
   side stream a    capture a's fused scan (K1 power map, K3 amplitude statistics, K4 block sums) and its tail (noise-floor
                    threshold, amplitude totals, onset, TDOA slot): two launches (gj_capture_scan_dev; eight until round 5);
                    the captures' chains are independent of each other and run on streams of their own (up to three, each
                    tested to run beside the others: gpsjam/streams.py), so they overlap instead of queueing
   side stream 0    after all slots: K5 over every antenna pair (three launches)
-  main stream      one result vector per antenna (the layout of gj_pack_result_dev; antenna 0 carries the pair table)
+  main stream      one result vector per antenna, one launch for all (gj_pack_results_dev; the layout of
+                   gj_pack_result_dev; antenna 0 carries the pair table)
 From the second step on the whole step is replayed as ONE captured HIP graph (``graph=True``): ~45 launches of a few
 microseconds each are launch-bound when issued one by one.
 The kernels are those of the other two arrangements; results are byte-equal to `AntennaStream` run on each capture
@@ -83,8 +85,13 @@ class LocalAntennas:
         # one captured graph per result set (made at the second / third step); never on the legacy default stream
         self._graphs = [None, None] if (graph and self._main != torch.cuda.default_stream(d)) else None
         self._steps = 0
+        self._desc = {}
+        # K2 of all captures in one launch when they are of one length and every one has rows (the reference's deployment:
+        # three recordings made together); otherwise one launch per capture
+        self._k2_batched = (self.n_ant > 1 and len(set(self.nbytes)) == 1 and all(self.rows) and self.n_ant <= 16
+                            and all(p.data_ptr() % 16 == 0 for p in self.psd))
         # workspaces: nothing is allocated inside a step
-        dev.reserve(max(dev.welch_workspace(n, chunk_samples, nperseg) for n in self.nbytes))
+        dev.reserve(max(dev.welch_workspace(n, chunk_samples, nperseg) for n in self.nbytes) * (self.n_ant if self._k2_batched else 1))
         for k, (sdev, _) in enumerate(self._sides):
             ws = max(self.nbytes) // 48 + (1 << 20)
             if k == 0 and self.pairs:
@@ -98,6 +105,9 @@ class LocalAntennas:
         for _, s in self._sides:
             s.wait_event(self._ev_go)
         def k2():
+            if self._k2_batched:     # captures of one length: one transform launch + one finalize for all of them
+                self.dev.welch_batch_dev(self.caps, self.nbytes[0], self.chunk_samples, self.nperseg, self.fs, self.psd)
+                return
             for a, cap in enumerate(self.caps):
                 if self.rows[a]:
                     self.dev.welch_dev(cap, self.nbytes[a], self.chunk_samples, self.nperseg, self.fs, self.psd[a])
@@ -127,12 +137,24 @@ class LocalAntennas:
                                   self.peaks, self.margins)
         self._ev_side[0].record(s0)
         main.wait_event(self._ev_side[0])
-        for a in range(self.n_ant):
-            carries = a == 0 and bool(self.pairs)
-            self.dev.pack_result_dev(self.n_chunks[a], self.power[a], self.stats[a], self.amp[a], self.onset[a], self.psd[a],
-                                     self.rows[a], self.nperseg, a, len(self.pairs) if carries else 0, len(self.pairs),
-                                     self.d_pairs if carries else None, self.lags if carries else None,
-                                     self.peaks if carries else None, self.margins if carries else None, out[a])
+        self.dev.pack_results_dev(self._pack_desc(out), self.nperseg, self.d_pairs, self.lags, self.peaks, self.margins)
+
+    def _pack_desc(self, out: torch.Tensor):
+        """The captures' descriptors for gj_pack_results_dev (one launch for every antenna's result vector); antenna 0
+        carries the pair table."""
+        from . import _ffi
+        key = out.data_ptr()
+        if key not in self._desc:
+            d = []
+            for a in range(self.n_ant):
+                carries = a == 0 and bool(self.pairs)
+                d.append(_ffi.CombineCapture(n_chunks=self.n_chunks[a], rows=self.rows[a], n_tiles=0, total_bytes=self.nbytes[a], n_parts=1,
+                                             antenna=a, n_pairs=len(self.pairs) if carries else 0, pair_cap=len(self.pairs),
+                                             d_power=self.power[a].data_ptr(), d_stats=self.stats[a].data_ptr(), d_tiles=None,
+                                             d_amp_parts=None, d_onset_parts=None, d_amp=self.amp[a].data_ptr(),
+                                             d_onset=self.onset[a].data_ptr(), d_psd=self.psd[a].data_ptr(), d_out=out[a].data_ptr()))
+            self._desc[key] = d
+        return self._desc[key]
 
     def _capture(self, k: int):
         """The step for result set k as ONE HIP graph (stream capture on the main stream; the side streams join the

@@ -187,6 +187,12 @@ int gj_welch_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_s
 int gj_welch_u8(gj_ctx* ctx, const uint8_t* iq, size_t nbytes, size_t chunk_samples,
                 int nperseg, double fs, int flags, float* psd, float* psd_db, size_t cap_floats,
                 size_t* rows_out, float* kernel_ms);
+/* n captures of ONE length (nbytes_each) in one transform launch + one finalize launch: the reference's deployment is
+ * three antenna recordings of one length (GpsJammerApp/app/worker.py:97-101), and at 10-s captures a step's time is its
+ * launch gaps and grid tails, not its bytes.  Each capture is planned, cut into workgroups and summed exactly as by
+ * gj_welch_dev on its own, so d_psd[a] receives the same bits; d_psd[a] must be 16-byte aligned. */
+int gj_welch_batch_dev(gj_ctx* ctx, const uint8_t* const* d_iq, int n_captures, size_t nbytes_each, size_t chunk_samples,
+                       int nperseg, double fs, int flags, float* const* d_psd /* [n_captures] x [rows*nperseg] */);
 /* Measurement: gj_welch_dev with HIP events around the transform launch and around the finalize launch (the sum over
  * the per-workgroup spectra, scaling, fftshift, dB), on the context's stream; synchronises and reports both.  bench.py
  * times K2 at nperseg 4096 and 1024 with it, interleaved, so that the two figures of one line come from the same
@@ -378,6 +384,13 @@ int gj_pack_result_dev(gj_ctx* ctx, size_t n_chunks, const float* d_power, const
                        const gj_amp_stats* d_amp, const gj_onset* d_onset, const float* d_psd, size_t rows,
                        int nperseg, int rank, int n_pairs, int pair_capacity, const int32_t* d_pairs,
                        const int32_t* d_lags, const float* d_peaks, const float* d_margins, double* d_out);
+
+/* gj_pack_result_dev for up to GJ_MAX_ANTENNAS captures in ONE launch.  `captures` is a HOST array of gj_combine_capture
+ * (declared below) of which the fields n_chunks, rows, antenna (-> header field 13), n_pairs, pair_cap, d_power, d_stats,
+ * d_amp, d_onset, d_psd and d_out are read; the pair arrays are shared (the capture with n_pairs > 0 carries them). */
+struct gj_combine_capture;
+int gj_pack_results_dev(gj_ctx* ctx, const struct gj_combine_capture* captures, int n_captures, int nperseg,
+                        const int32_t* d_pairs, const int32_t* d_lags, const float* d_peaks, const float* d_margins);
 
 /* ------------------------------------------------- one capture over several GPUs ------ */
 /* "fewer files than GPUs => split one file into contiguous chunk ranges aligned to

@@ -405,3 +405,75 @@ def test_welch_wave_fence_exchange_equals_the_barrier_build(tmp_path):
         outs[name] = p.stdout.splitlines()
     assert outs["fence"][0] == "LIB libgpsjam_hip.so" and outs["barrier"][0] == "LIB libgpsjam_hip_barrier.so"
     assert len(outs["fence"]) == 19 and outs["fence"][1:] == outs["barrier"][1:]
+
+
+# ----------------------------------------------------------------------------- one K2 launch / one pack launch for a deployment
+@pytest.mark.parametrize("nperseg,chunk,n", [(1024, 131072, 900_000), (4096, 200_000, 1_000_000), (64, 65536, 300_001), (1024, 2048000, 20_480_000)])
+def test_welch_batch_gives_each_capture_the_bits_of_its_own_launch(dev, nperseg, chunk, n):
+    """gj_welch_batch_dev: three captures of one length in one transform launch + one finalize; every PSD byte equal to
+    gj_welch_dev on the capture alone (same plan, same partial spectra, same fixed order of summation) -- full chunks, a
+    ragged last chunk, the reference's 10-s shape."""
+    raws = [generate(StreamSpec(seed=500 + a, antenna=a, jam_start=n // 3, jam_end=2 * n // 3, jam_sigma=30.0 + 10 * a), n) for a in range(3)]
+    caps = [dev.alloc(2 * n + 16).upload(r) for r in raws]
+    rows = dev.welch_rows(2 * n, chunk, nperseg)
+    assert rows >= 1
+    alone = [dev.alloc(4 * rows * nperseg) for _ in range(3)]
+    batch = [dev.alloc(4 * rows * nperseg) for _ in range(3)]
+    for a in range(3):
+        dev.welch_dev(caps[a], 2 * n, chunk, nperseg, 2.048e6, alone[a])
+    dev.welch_batch_dev(caps, 2 * n, chunk, nperseg, 2.048e6, batch)
+    dev.synchronize()
+    for a in range(3):
+        assert alone[a].download(np.uint8).tobytes() == batch[a].download(np.uint8).tobytes(), f"capture {a}"
+    lin, _, _ = orc.widmo_waterfall(raws[1][:2 * min(n, 1_000_000)], nperseg=nperseg, chunk_samples=chunk) if n <= 1_000_000 else (None, None, None)
+    if lin is not None:
+        got = batch[1].download(np.float32, rows * nperseg).reshape(rows, nperseg)
+        keep = lin > 1e-12
+        assert float(np.max(np.abs(got[keep] - lin[keep]) / lin[keep])) < 1e-4
+    for b in caps + alone + batch:
+        b.free()
+    with pytest.raises(gpsjam.GpsJamError):
+        dev.welch_batch_dev([], 2 * n, chunk, nperseg, 2.048e6, [])
+
+
+def test_pack_results_in_one_launch_equals_one_launch_per_capture(dev):
+    """gj_pack_results_dev against gj_pack_result_dev, byte for byte: three captures, antenna 0 carrying the pair table."""
+    nperseg, n_ant = 1024, 3
+    rng = np.random.default_rng(9)
+    nch, rows = [625, 625, 400], [10, 10, 7]
+    f32 = lambda k: rng.random(k).astype(np.float32)
+    bufs = []
+
+    def up(a):
+        b = dev.alloc(max(a.nbytes, 16)).upload(a.view(np.uint8))
+        bufs.append(b)
+        return b
+    power = [up(f32(k)) for k in nch]
+    stats = [up(f32(3)) for _ in range(n_ant)]
+    amp = [up(rng.integers(0, 1 << 40, 4).astype(np.int64)) for _ in range(n_ant)]
+    onset = [up(rng.integers(0, 1 << 30, 4).astype(np.int64)) for _ in range(n_ant)]
+    psd = [up(f32(r * nperseg)) for r in rows]
+    pairs, lags = up(np.array([0, 1, 0, 2, 1, 2], np.int32)), up(np.array([3, -5, -8], np.int32))
+    peaks, margins = up(f32(3)), up(f32(3))
+    from gpsjam.sharded import result_len
+    ln = max(result_len(k, nperseg, 3) for k in nch)
+    one = [dev.alloc(8 * ln) for _ in range(n_ant)]
+    many = [dev.alloc(8 * ln) for _ in range(n_ant)]
+    for b in one + many:
+        b.upload(np.zeros(8 * ln, np.uint8))
+    desc = []
+    for a in range(n_ant):
+        carries = a == 0
+        dev.pack_result_dev(nch[a], power[a], stats[a], amp[a], onset[a], psd[a], rows[a], nperseg, a, 3 if carries else 0, 3,
+                            pairs if carries else None, lags if carries else None, peaks if carries else None,
+                            margins if carries else None, one[a])
+        desc.append(_ffi.CombineCapture(n_chunks=nch[a], rows=rows[a], n_tiles=0, total_bytes=0, n_parts=1, antenna=a,
+                                        n_pairs=3 if carries else 0, pair_cap=3, d_power=power[a].ptr, d_stats=stats[a].ptr,
+                                        d_tiles=None, d_amp_parts=None, d_onset_parts=None, d_amp=amp[a].ptr, d_onset=onset[a].ptr,
+                                        d_psd=psd[a].ptr, d_out=many[a].ptr))
+    dev.pack_results_dev(desc, nperseg, pairs, lags, peaks, margins)
+    dev.synchronize()
+    for a in range(n_ant):
+        assert one[a].download(np.uint8).tobytes() == many[a].download(np.uint8).tobytes(), f"capture {a}"
+    for b in bufs + one + many:
+        b.free()

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round-5 evidence:  bash tools/r05_profile.sh <tag>     (on the GPU box, from the repo root)
+#   (PMC passes: tools/r05_profile_pmc.sh)
 #   bench.py plain + under rocprofv3 --kernel-trace --stats; K2 solo at 4096 and 1024 from ONE box, back to back; the
 #   per-capture chain (gj_capture_scan_dev) solo at 1 GiB and at the reference's 10-s size; the deployment step (graph /
 #   eager) + its kernel trace; the split path as rank 0 of eight (emulated) + trace; PMC for welch 4096 / 1024, the
@@ -25,8 +26,4 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dep_trace -- python3 $ROOT/tools/deployment_probe.py > $OUT/dep_traced.txt 2>&1; echo "dep trace rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dep_trace_eager -- python3 $ROOT/tools/deployment_probe.py --eager > $OUT/dep_traced_eager.txt 2>&1; echo "dep eager trace rc=$?"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/split8_trace -- python3 $ROOT/bench.py --split --emulate-world 8 --force-exchange --steps 20 --warmup 5 --precondition 10 > $OUT/split8_traced.json 2> $OUT/split8_traced.err; echo "split8 trace rc=$?"
-cd $ROOT
-bash tools/pmc_welch.sh $TAG/pmc_welch4096 4096 > $OUT/pmc_welch4096.log 2>&1; echo "pmc welch4096 rc=$?"
-bash tools/pmc_welch.sh $TAG/pmc_welch1024 1024 > $OUT/pmc_welch1024.log 2>&1; echo "pmc welch1024 rc=$?"
-bash tools/pmc_secondary.sh $TAG/pmc_sec "cscan xcorr3" > $OUT/pmc_sec.log 2>&1; echo "pmc sec rc=$?"
 find $OUT -name "*kernel_stats.csv" | head -20
