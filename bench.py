@@ -126,6 +126,8 @@ def main():
                     help="N = 1 only, rehearsal: give this GPU the per-rank load of a W-antenna deployment -- W - 1 further "
                          "slots prepared before the timed region, rank 0's share of the pairs (W / 2 of them) instead of "
                          "all; with --force-exchange the collectives are issued too.  Not the reported configuration")
+    ap.add_argument("--pack-on-main", action="store_true",
+                    help="--split: pack the part vectors on the main stream behind K2 (round 4's order) instead of on the second stream")
     ap.add_argument("--side-priority", type=int, default=0, help="HIP priority of the second stream (0 default, -1 high)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="diagnostic: ranks only form the process group, all-reduce one number and print it")
@@ -500,11 +502,11 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
         # all ranks' part vectors; what the other ranks would send was computed here, once, before the timed region
         st = split.emulated_rank(dev, [nbytes] * A, make_buffer, make_noise, emulated, args.emulate_rank, nperseg=NPERSEG,
                                   chunk_samples=CHUNK_SAMPLES, slice_samples=SLICE, overlap=not args.no_overlap,
-                                  exchange_always=args.force_exchange)
+                                  exchange_always=args.force_exchange, pack_on_side=not args.pack_on_main)
     else:
         st = split.SplitStreams(dev, [nbytes] * A, make_buffer, make_noise, rank=rank, world_size=world, nperseg=NPERSEG,
                                 chunk_samples=CHUNK_SAMPLES, slice_samples=SLICE, overlap=not args.no_overlap,
-                                exchange_always=args.force_exchange and world == 1)
+                                exchange_always=args.force_exchange and world == 1, pack_on_side=not args.pack_on_main)
     torch.cuda.synchronize()
 
     def barrier():

@@ -233,7 +233,10 @@ class PartStream:
         self.tiles = torch.zeros(2 * max(self.n_tiles, 1), dtype=torch.float64, device=d)   # (sum, first) records
         self.amp = torch.zeros(4, dtype=torch.int64, device=d)                                 # gj_amp_part
         self.onset = torch.zeros(4, dtype=torch.int64, device=d)                               # gj_onset
-        self.psd = torch.empty((max(self.rows, 1), nperseg), dtype=torch.float32, device=d)
+        # two PSD buffers, written alternately: a step's packing (which reads one) may run on the second stream while the
+        # main stream has gone on to the next step's K2 + finalize (which writes the other)
+        self.psd2 = [torch.empty((max(self.rows, 1), nperseg), dtype=torch.float32, device=d) for _ in range(2)]
+        self.psd = self.psd2[0]
 
     def scan(self, slot: Optional[torch.Tensor] = None):
         """K1 + K3 + K4 of the part in two launches; with ``slot`` the TDOA slot at the part's own onset is cut by the
@@ -248,7 +251,8 @@ class PartStream:
                                                 slice_samples=self.slice_samples, d_slot=slot)
             self._slot_cut = slot.data_ptr()
 
-    def welch(self):
+    def welch(self, which: int = 0):
+        self.psd = self.psd2[which]
         self.dev.part_welch_dev(self.view, self.chunk_samples, self.nperseg, self.fs, self.psd)
 
     def slot(self, out: torch.Tensor):
@@ -269,7 +273,7 @@ class SplitStreams:
                  chunk_bytes: int = 65536, chunk_samples: int = 2048000, nperseg: int = 4096, fs: float = 2.048e6,
                  slice_samples: int = 1 << 19, noise_samples: int = 200000, window: int = 1000, factor: float = 50.0,
                  rssi_threshold: float = 0.0, overlap: Optional[bool] = None, device=None, exchange_always: bool = False,
-                 emulate: bool = False):
+                 emulate: bool = False, pack_on_side: bool = True):
         self.dev, self.rank, self.world = dev, rank, world_size
         # one rank of a world_size-rank plan alone on its GPU: no collective, local copies into the world-size buffers
         self.emulate = bool(emulate)
@@ -288,6 +292,8 @@ class SplitStreams:
         self.is_root = rank == 0
         self.overlap = bool(d.type == "cuda" if overlap is None else overlap)
         self.dev_side = dev
+        self._pack_on_side = bool(pack_on_side)
+        self._pidx = 0
         self._main = torch.cuda.current_stream(d) if d.type == "cuda" else None
         if self._main is not None:
             dev.set_stream(self._main.cuda_stream)
@@ -298,6 +304,12 @@ class SplitStreams:
             self.dev_side.set_stream(self._side.cuda_stream)
             self._ev_free, self._ev_side, self._ev_packed = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
             self._ev_free.record(self._main)
+            # Packing on the SECOND stream (behind K5, where its inputs come from): the main stream then carries nothing but
+            # K2 + finalize, step after step, and never waits for the side chain -- at the per-rank load of an eight-way
+            # split the wait, the packing launch and the two cross-stream joins were 45 us of a 0.58-ms step between two K2
+            # launches (profiles/NOTES_r05.md).  Needs the two PSD buffers of PartStream.
+            self._ev_psd = [torch.cuda.Event(), torch.cuda.Event()]         # main: finalize has written psd2[i]
+            self._ev_psd_read = [None, None]                                # side: the packing has read psd2[i]
         else:
             self._side = self._main
         # Rank 0's gather + combine get a THIRD stream (and a context bound to it): on the second stream they would sit
@@ -408,8 +420,15 @@ class SplitStreams:
 
     def welch(self):
         """K2 of every part of this rank (main stream)."""
+        side_pack = self.overlap and self._pack_on_side
+        if side_pack:
+            self._pidx ^= 1
+            if self._ev_psd_read[self._pidx] is not None:           # the packing of two steps ago has read this buffer
+                self._main.wait_event(self._ev_psd_read[self._pidx])
         for s in self.streams:
-            s.welch()
+            s.welch(self._pidx)
+        if side_pack:
+            self._ev_psd[self._pidx].record(self._main)
 
     def scan(self):
         self.stream_scan()
@@ -450,12 +469,17 @@ class SplitStreams:
                 self._ev_side.record(self._side)
 
     def pack(self) -> torch.Tensor:
-        if self.overlap:
+        side_pack = self.overlap and self._pack_on_side
+        stream = self._side if side_pack else self._main
+        dev = self.dev_side if side_pack else self.dev
+        if side_pack:
+            stream.wait_event(self._ev_psd[self._pidx])             # this step's PSD rows (main stream) are written
+        elif self.overlap:
             self._main.wait_event(self._ev_side)
         self._idx ^= 1
         vec = self._vecs[self._idx]
         if self.overlap and self._ev_vec_free[self._idx] is not None:
-            self._main.wait_event(self._ev_vec_free[self._idx])     # the gather / combine of two steps ago has read it
+            stream.wait_event(self._ev_vec_free[self._idx])         # the gather / combine of two steps ago has read it
         for j, s in enumerate(self.streams):
             p = s.part
             carries = j == 0                      # the pairs this rank solved ride on its first part's vector
@@ -465,10 +489,14 @@ class SplitStreams:
                               s.power.data_ptr(), s.amp.data_ptr(), s.onset.data_ptr(), s.tiles.data_ptr(),
                               s.psd.data_ptr(), self.d_pairs.data_ptr(), self.lags.data_ptr(), self.peaks.data_ptr(),
                               self.margins.data_ptr())
-            self.dev.pack_part_dev(a, vec[j])
+            dev.pack_part_dev(a, vec[j])
         if self.overlap:
-            self._ev_free.record(self._main)
-            self._ev_packed.record(self._main)
+            self._ev_free.record(stream)
+            self._ev_packed.record(stream)
+            if side_pack:
+                if self._ev_psd_read[self._pidx] is None:
+                    self._ev_psd_read[self._pidx] = torch.cuda.Event()
+                self._ev_psd_read[self._pidx].record(stream)
         return vec
 
     def exchange(self, dst: int = 0) -> Optional[StepResults]:

@@ -191,6 +191,18 @@ def test_noise_span_that_ends_inside_a_block(dev):
         _same(got, sep, f"noise span {noise}")
 
 
+@pytest.mark.parametrize("window", [1, 8, 511, 512, 513, 4096, 8192])
+def test_onset_windows_from_one_sample_to_the_largest(dev, window):
+    """K4's window from 1 to 8192 samples (the library's limit): the exact scan's LDS tile is sized by the window
+    (2048 positions + window - 1 samples), the screening's reach is (window + 510) / 512 + 1 blocks."""
+    n, burst = (1_300_000, 700_123) if window <= 513 else (400_000, 250_123)      # the oracle's np.convolve is O(n * window)
+    raw = _levels(n, [(0, 6.0), (burst, 60.0)], seed=40 + window)
+    got = _fused(dev, raw, window=window, noise=100_000, slice_samples=4096)
+    z = orc.tdoa_unpack(raw)
+    assert got[4]["start"] == orc.tdoa_onset(z, 100_000, window, FACTOR), window
+    _same(got, _separate(dev, raw, window=window, noise=100_000, slice_samples=4096), f"window {window}")
+
+
 def test_tail_launches_back_to_back_leave_their_counter_at_zero(dev):
     """Forty fused scans of alternating captures queued without a host synchronisation in between: each launch finds the
     arrival counter at zero (the previous one's last workgroup put it back) and sees only its own records."""
