@@ -468,7 +468,7 @@ __device__ double block_sum_f64(double v, double* sh /* [blockDim/64] */) {
 //           the tile's own sum when the hit is the tile's first sample)
 //   total : sum of the tile sums BEHIND that tile (fixed thread stride over the global tile index) + tail
 // A whole capture runs the three in one kernel; a capture split over GPUs runs first + tail where the bytes are
-// (amp_part_finalize_kernel) and total where the tile sums have been gathered (amp_combine_kernel): same code, same
+// (the amplitude role of scan_tail_kernel) and total where the tile sums have been gathered (amp_combine_kernel): same code, same
 // order, same bits.
 __device__ long long amp_block_first(const AmpTile* __restrict__ tiles, size_t ntiles, long long* first_s) {
     if (threadIdx.x == 0) *first_s = 0x7fffffffffffffffll;
@@ -564,31 +564,6 @@ __global__ __launch_bounds__(256) void amp_finalize_kernel(const uint8_t* __rest
         out->sum = total;
         out->mean = (float)(total / (double)cnt);
         out->reserved = 0.f;
-    }
-}
-
-// One part of a split capture: first hit (made global with `sample0`) and the tail of its tile; the tile sums travel
-// to the combining rank as they are.  `iq` / `tiles`: the part's OWN range.
-__global__ __launch_bounds__(256) void amp_part_finalize_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
-                                                                 const AmpTile* __restrict__ tiles, size_t ntiles,
-                                                                 long long sample0, gj_amp_part* __restrict__ out, Unpack up,
-                                                                 float* __restrict__ power, size_t nchunks, size_t nbytes,
-                                                                 size_t chunk_bytes, int flags) {
-    power_edge_cases(power, nchunks, nbytes, chunk_bytes, flags);
-    __shared__ double sh[16];
-    __shared__ long long first_s;
-    const long long first = amp_block_first(tiles, ntiles, &first_s);
-    if (first == 0x7fffffffffffffffll) {
-        if (threadIdx.x == 0) { out->first_index = -1; out->count = 0; out->sum = 0.0; out->tail = 0.0; }
-        return;
-    }
-    const double tail = amp_block_tail(iq, nsamples, tiles, first, up, sh);
-    const double behind = amp_block_total(tiles, ntiles, (size_t)first / kAmpTileSamples, sh);
-    if (threadIdx.x == 0) {
-        out->first_index = sample0 + first;
-        out->count = nsamples - (size_t)first;
-        out->sum = behind + tail;            // of this part alone (informational)
-        out->tail = tail;
     }
 }
 
@@ -724,8 +699,9 @@ __device__ __forceinline__ int onset_pad(int k) { return k + (k >> 5); }   // sp
 // block j lies inside those blocks and 4|z|^2 >= 0, so U[j] <= threshold proves that no start
 // index in block j crosses the threshold; only the first block that fails the proof is handed
 // to the exact scan below (sc->cand = its first sample).
-//   BS = 8  : c8 straight from the capture, one 16-byte load per block (v_dot4_u32_u8) -- HBM-bound
-//   BS = 512: c512 precomputed by the fused stream scan (4 MB per GiB of capture)
+//   BS = 8  : c8 straight from the capture, one 16-byte load per block (v_dot4_u32_u8) -- HBM-bound; K4 ALONE (gj_onset_dev)
+//   BS = 512: the fused path -- c512 comes from the stream scan (4 MB per GiB) and the screening is a role of
+//             scan_tail_kernel (tail_onset_range), not this kernel
 constexpr int kCoarseBlocks = 4096;   // blocks per workgroup
 constexpr int kCoarseHalo = (kOnsetMaxWin + 6) / 8 + 1;
 
@@ -1542,7 +1518,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_tail_kernel(TailArgs A) {
         --b;
     }
     if (b == 0) {
-        // amplitude totals + the chunk-power edge cases: the bodies of amp_finalize_kernel / amp_part_finalize_kernel
+        // amplitude totals + the chunk-power edge cases: the body of amp_finalize_kernel; a part of a split capture
+        // reports its first hit (made global with own_sample0) and the tail of its tile, the tile sums travel as they are
         power_edge_cases(A.power, (size_t)A.nchunks, (size_t)A.own_bytes, (size_t)A.chunk_bytes, A.flags);
         const long long first = amp_block_first(A.tiles, (size_t)A.own_tiles, &first_s);
         if (first == 0x7fffffffffffffffll) {

@@ -28,7 +28,7 @@ for a, b in (("bench.json", "r05_bench.json"), ("force_exchange.json", "r05_forc
              ("split_emulated8_rank0.json", "r05_split_emulated8_rank0.json"), ("split_emulated4.json", "r05_split_emulated4_rank0.json"),
              ("split_emulated8_rank1.json", "r05_split_emulated8_rank1.json"), ("split_emulated8_rank2.json", "r05_split_emulated8_rank2.json"),
              ("split_emulated8_rank7.json", "r05_split_emulated8_rank7.json"), ("deployment.txt", "r05_deployment_probe.txt"),
-             ("solo_welch.txt", "r05_solo_welch.txt"), ("solo_cscan.txt", "r05_solo_cscan.txt"), ("solo_xcorr3.txt", "r05_solo_xcorr3.txt")):
+             ("k2_ab_probe.txt", "r05_k2_ab_probe.txt")):
     cp(a, b)
 
 
