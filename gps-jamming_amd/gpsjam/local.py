@@ -15,8 +15,8 @@ not bytes.  Per step:
   side stream 0    after all slots: K5 over every antenna pair (three launches)
   main stream      one result vector per antenna, one launch for all (gj_pack_results_dev; the layout of
                    gj_pack_result_dev; antenna 0 carries the pair table)
-From the second step on the whole step is replayed as ONE captured HIP graph (``graph=True``): ~45 launches of a few
-microseconds each are launch-bound when issued one by one.
+From the second step on the whole step is replayed as ONE captured HIP graph (``graph=True``): a dozen launches of a few
+microseconds each (round 4: ~45) are launch-bound when issued one by one -- 0.21 ms replayed, 0.22 eager.
 The kernels are those of the other two arrangements; results are byte-equal to `AntennaStream` run on each capture
 (tests/test_local_gpu.py).  `step()` returns a `gpsjam.sharded.StepResults`.
 """
@@ -158,11 +158,12 @@ class LocalAntennas:
 
     def _capture(self, k: int):
         """The step for result set k as ONE HIP graph (stream capture on the main stream; the side streams join the
-        capture through the events).  A step over 10-s captures is ~45 launches of a few microseconds each: launched one
-        by one the host is the bottleneck (0.37-0.38 ms per step); replayed as a graph 0.345-0.352 ms -- the runtime's
-        graph executor still starts the branches one after the other, so the gain is 7 %, not the 2x the GPU's own
-        critical path would allow (profiles/r04_deployment.txt).  Everything in a step is capturable: kernel launches, two memsets, event
-        fork / join; nothing is allocated.  If the runtime refuses the capture the step stays eager (same kernels)."""
+        capture through the events).  Round 4: ~45 launches per step, 0.37-0.38 ms launched one by one against 0.345-0.352 ms
+        replayed (the runtime's graph executor starts the branches one after the other: profiles/r04_deployment.txt).
+        Round 5: twelve launches per step (one K2 + finalize, two per capture on the side, three for K5, one pack), 0.22 ms
+        eager against 0.20-0.21 ms replayed (profiles/r05_deployment_timeline_*.txt).  Everything in a step is capturable --
+        kernel launches and event fork / join, no memset, no allocation.  If the runtime refuses the capture the step stays
+        eager (same kernels)."""
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()

@@ -112,6 +112,60 @@ int main(void) {
         CHECK(gj_power_threshold_dev(ctx, d_power, nchunks, 5.0f, 6.0f, d_stats, NULL));
         CHECK(gj_welch_dev(ctx, d_iq, nbytes, chunk_samples, nperseg, 2.048e6, GJ_WELCH_SHIFT, d_psd, NULL));
         CHECK(gj_tdoa_slot_dev(ctx, d_iq, nbytes, (const int64_t*)d_on /* &start_index */, nslice, d_slot));
+        /* round 5: the same scan + threshold + slot in TWO launches, K2 of two captures in one launch, both result vectors in
+         * one launch -- every byte equal to the calls above (only gj_onset.margin_before, a bound, is left out) */
+        {
+            void *p2, *s2, *a2, *o2, *sl2, *psd_a, *psd_b, *res_a, *res_b;
+            CHECK(gj_malloc(ctx, nchunks * 4, &p2));
+            CHECK(gj_malloc(ctx, 16, &s2));
+            CHECK(gj_malloc(ctx, sizeof(gj_amp_stats), &a2));
+            CHECK(gj_malloc(ctx, sizeof(gj_onset), &o2));
+            CHECK(gj_malloc(ctx, sb, &sl2));
+            CHECK(gj_malloc(ctx, rows * nperseg * 4, &psd_a));
+            CHECK(gj_malloc(ctx, rows * nperseg * 4, &psd_b));
+            CHECK(gj_malloc(ctx, rlen * 8, &res_a));
+            CHECK(gj_malloc(ctx, rlen * 8, &res_b));
+            gj_scan_extra extra = {5.0f, 6.0f, (float*)s2, NULL, nslice, (uint8_t*)sl2};
+            CHECK(gj_capture_scan_dev(ctx, d_iq, nbytes, chunk_bytes, 1e-10f, 0, p2, 0.5f, a2, 200000, 1000, 50.0f, o2, &extra));
+            const uint8_t* caps2[2] = {d_iq, d_iq};
+            float* psds2[2] = {(float*)psd_a, (float*)psd_b};
+            CHECK(gj_welch_batch_dev(ctx, caps2, 2, nbytes, chunk_samples, nperseg, 2.048e6, GJ_WELCH_SHIFT, psds2));
+            struct { void *got, *want; size_t n; const char* what; } cmp[] = {
+                {p2, d_power, nchunks * 4, "power map"}, {s2, d_stats, 12, "threshold statistics"}, {a2, d_amp, sizeof(gj_amp_stats), "amplitude record"},
+                {sl2, d_slot, sb, "TDOA slot"}, {psd_a, d_psd, rows * nperseg * 4, "PSD (batch, capture 0)"}, {psd_b, d_psd, rows * nperseg * 4, "PSD (batch, capture 1)"}};
+            for (size_t k = 0; k < sizeof(cmp) / sizeof(cmp[0]); ++k) {
+                unsigned char *g = (unsigned char*)malloc(cmp[k].n), *w = (unsigned char*)malloc(cmp[k].n);
+                CHECK(gj_memcpy_d2h(ctx, g, cmp[k].got, cmp[k].n));
+                CHECK(gj_memcpy_d2h(ctx, w, cmp[k].want, cmp[k].n));
+                if (memcmp(g, w, cmp[k].n) != 0) { fprintf(stderr, "two-launch path: %s differs\n", cmp[k].what); return 1; }
+                free(g); free(w);
+            }
+            gj_onset og, ow;
+            CHECK(gj_memcpy_d2h(ctx, &og, o2, sizeof(og)));
+            CHECK(gj_memcpy_d2h(ctx, &ow, d_on, sizeof(ow)));
+            if (og.start_index != ow.start_index || og.guard_index != ow.guard_index || og.noise_power != ow.noise_power ||
+                og.threshold != ow.threshold || og.margin_hit != ow.margin_hit || og.start_index != on.start_index) {
+                fprintf(stderr, "two-launch path: onset %lld / %lld guard %lld / %lld\n", (long long)og.start_index, (long long)ow.start_index,
+                        (long long)og.guard_index, (long long)ow.guard_index);
+                return 1;
+            }
+            gj_combine_capture two[2];
+            memset(two, 0, sizeof(two));
+            for (int a = 0; a < 2; ++a) {
+                two[a].n_chunks = nchunks; two[a].rows = rows; two[a].antenna = a; two[a].n_pairs = 0; two[a].pair_cap = 1;
+                two[a].d_power = (float*)d_power; two[a].d_stats = (float*)d_stats; two[a].d_amp = (gj_amp_stats*)d_amp;
+                two[a].d_onset = (gj_onset*)d_on; two[a].d_psd = (float*)d_psd; two[a].d_out = (double*)(a ? res_b : res_a);
+            }
+            CHECK(gj_pack_results_dev(ctx, two, 2, nperseg, NULL, NULL, NULL, NULL));
+            CHECK(gj_pack_result_dev(ctx, nchunks, d_power, d_stats, d_amp, d_on, d_psd, rows, nperseg, 1, 0, 1, NULL, NULL, NULL, NULL, d_res));
+            double *rb = (double*)malloc(rlen * 8), *rw = (double*)malloc(rlen * 8);
+            CHECK(gj_memcpy_d2h(ctx, rb, res_b, rlen * 8));
+            CHECK(gj_memcpy_d2h(ctx, rw, d_res, rlen * 8));
+            if (memcmp(rb, rw, rlen * 8) != 0) { fprintf(stderr, "gj_pack_results_dev differs from gj_pack_result_dev\n"); return 1; }
+            free(rb); free(rw);
+            void* mine[] = {p2, s2, a2, o2, sl2, psd_a, psd_b, res_a, res_b};
+            for (size_t k = 0; k < sizeof(mine) / sizeof(mine[0]); ++k) CHECK(gj_free(ctx, mine[k]));
+        }
         unsigned char id[GJ_COMM_ID_BYTES];
         gj_comm* comm = NULL;
         const int rc_id = gj_comm_unique_id(id);
