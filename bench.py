@@ -1062,7 +1062,8 @@ def deployment(np, torch, gpsjam, dev, StreamSpec, reps=20, graph=True, **local_
             "what": "resident_step: back-to-back steps over three captures already in HBM (rate) and one step alone (latency); "
                     "file_to_results: three page-cache-resident files through gj_ingest_file (pieces sized to the capture, kernels "
                     "on what has landed), one file after the other as the drop-ins do (three at once, one thread and lane each, was "
-                    "measured: 5.8-7.3 against 5.6-6.0 ms, no gain -- each ingest already runs eight fill threads) + K5 on the "
+                    "measured: 5.8-7.3 against 5.6-6.0 ms with eight fill threads each; with two each 4.0 ms in a bare probe but 5-11 ms from "
+                    "Python threads -- profiles/NOTES_r05.md section 8) + K5 on the "
                     "resident captures, wall clock with PCIe, best of three"}
     return {"line": line, "gpu": gpu}
 

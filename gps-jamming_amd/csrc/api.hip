@@ -250,6 +250,14 @@ int gj_set_unpack(gj_ctx* ctx, double offset, double scale) {
     return GJ_OK;
 }
 
+int gj_set_fill_threads(gj_ctx* ctx, int n) {
+    if (!ctx) return GJ_ERR_INVALID;
+    if (n < 0 || n > 16) return fail(ctx, GJ_ERR_INVALID, "fill threads %d (0 = by capture size, 1..16)", n);
+    Guard g(ctx);
+    ctx->fill_threads = n;
+    return GJ_OK;
+}
+
 int gj_get_unpack(gj_ctx* ctx, double* offset, double* scale) {
     if (!ctx) return GJ_ERR_INVALID;
     Guard g(ctx);

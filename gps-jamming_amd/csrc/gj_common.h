@@ -79,6 +79,7 @@ struct gj_ctx {
     std::vector<gj_lane*> lanes;
     std::vector<gj_comm*> comms;   // communicators created on this context (gj_destroy takes them down)
     int lanes_reclaimed = 0;
+    int fill_threads = 0;          // gj_set_fill_threads: 0 = by capture size
     int inject_owner_alive = 0;    // gj_debug_inject: the next probes of a busy lane skip the owner check ("alive")
     // unpack convention (gj_set_unpack): sample = (u8 - offset) * scale; off2 = 2 * offset is an integer
     int off2 = 255;

@@ -272,23 +272,34 @@ constexpr size_t kMinPiece = 1u << 20;        // smallest: whole 64-KiB scan til
 constexpr size_t kPinThreshold = 4u << 20;    // below this: one copy, no helper threads
 constexpr int kMaxFillThreads = gj_lane::kPinBufs / 2;
 
-// fill threads of one staged copy: GPSJAM_FILL_THREADS (1..16), default 8 (one memcpy thread tops out at ~31 GB/s
-// end to end, below what the link carries; pread out of the page cache needs the extra threads more than memcpy)
-int fill_threads() {
+// fill threads of one staged copy: GPSJAM_FILL_THREADS (1..16) fixes the number; the default is by capture size, at most
+// 8 (one memcpy thread tops out at ~31 GB/s end to end, below what the link carries; pread out of the page cache needs
+// the extra threads more than memcpy).  By size since round 5: eight threads are right from ~80 MB up, but for the
+// reference's 10-s captures (41 MB) starting and joining eight threads costs more than they carry -- three such files one
+// after the other: 5.04 ms with eight threads each, 4.54 with four, 4.95 with three, 5.08 with two
+// (tools/ingest3_probe.py, profiles/NOTES_r05.md section 8).
+int fill_threads_env() {
     static const int n = [] {
         const char* e = getenv("GPSJAM_FILL_THREADS");
-        int v = e ? atoi(e) : 8;
-        if (v < 1) v = 1;
+        int v = e ? atoi(e) : 0;
         if (v > kMaxFillThreads) v = kMaxFillThreads;
-        return v;
+        return v < 0 ? 0 : v;
     }();
     return n;
 }
+int fill_threads(const gj_ctx* ctx, size_t nbytes) {
+    if (const int fixed = fill_threads_env()) return fixed;
+    if (ctx->fill_threads > 0) return ctx->fill_threads < kMaxFillThreads ? ctx->fill_threads : kMaxFillThreads;   // gj_set_fill_threads
+    size_t t = nbytes / (8u << 20);       // one thread per 8 MiB: four for a 10-s capture
+    if (t < 2) t = 2;
+    if (t > 8) t = 8;
+    return (int)t;
+}
 
 // Piece size of a staged copy of `nbytes`: about four pieces per fill thread, whole MiB, at most 16 MiB (reached from
-// 512 MiB up with the default eight threads: the GiB-class figures of profiles/r0*_ingest*.txt were measured with it).
-size_t piece_bytes(size_t nbytes) {
-    size_t p = align_up(nbytes / (4 * (size_t)fill_threads()) + 1, kMinPiece);
+// 512 MiB up with eight threads: the GiB-class figures of profiles/r0*_ingest*.txt were measured with it).
+size_t piece_bytes(const gj_ctx* ctx, size_t nbytes) {
+    size_t p = align_up(nbytes / (4 * (size_t)fill_threads(ctx, nbytes)) + 1, kMinPiece);
     if (p > kPinBytes) p = kPinBytes;
     return p;
 }
@@ -323,9 +334,9 @@ template <typename Fill, typename Meanwhile = NoMeanwhile>
 int staged_copy(gj_ctx* ctx, gj_lane* L, hipStream_t stream, unsigned char* d_dst, size_t nbytes, Fill&& fill,
                 PieceSink* sink = nullptr, hipEvent_t* piece_events = nullptr, Meanwhile&& meanwhile = Meanwhile()) {
     if (nbytes == 0) return GJ_OK;
-    const size_t piece_len = piece_bytes(nbytes);
+    const size_t piece_len = piece_bytes(ctx, nbytes);
     const size_t npieces = (nbytes + piece_len - 1) / piece_len;
-    const int nthreads = (int)(npieces < (size_t)fill_threads() ? npieces : (size_t)fill_threads());
+    const int nthreads = (int)(npieces < (size_t)fill_threads(ctx, nbytes) ? npieces : (size_t)fill_threads(ctx, nbytes));
     for (int k = 0; k < 2 * nthreads; ++k) {   // two bounce buffers per fill thread, made (or grown) on first use
         const int prc = lane_pin(ctx, L, k, piece_len);
         if (prc) return prc;
@@ -673,7 +684,7 @@ int ingest_impl(gj_ctx* ctx, size_t nbytes, Fill&& fill, const gj_ingest_plan& p
         rc = welch_begin(ctx, nbytes, plan.chunk_samples, plan.nperseg, plan.fs, 0, wj);
         if (rc) return bail(rc);
     }
-    const size_t piece_len = piece_bytes(nbytes);
+    const size_t piece_len = piece_bytes(ctx, nbytes);
     const size_t npieces = (nbytes + piece_len - 1) / piece_len;
     const size_t ws_scan = fused ? sj.ws_bytes : 0;
     rc = lane_ingest_resources(ctx, L, npieces ? npieces : 1, ws_scan + (want_welch ? wj.ws_bytes : 0) + 256);

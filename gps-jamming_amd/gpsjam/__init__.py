@@ -443,6 +443,10 @@ class Device:
         (127.5, 1/127.5) is the Python reference's convention, (128, 1/128) gnssdec's."""
         self._check(self._lib.gj_set_unpack(self._ctx, float(offset), float(scale)))
 
+    def set_fill_threads(self, n: int = 0):
+        """Host threads per staged copy (gj_set_fill_threads): 0 = by capture size, 1..16 = that many."""
+        self._check(self._lib.gj_set_fill_threads(self._ctx, int(n)))
+
     def get_unpack(self):
         o, s = C.c_double(0), C.c_double(0)
         self._check(self._lib.gj_get_unpack(self._ctx, C.byref(o), C.byref(s)))

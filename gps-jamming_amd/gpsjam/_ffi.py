@@ -139,6 +139,7 @@ SIGNATURES = {
     "gj_set_stream": (_i, [_vp, _vp, _i]),
     "gj_synchronize": (_i, [_vp]),
     "gj_set_unpack": (_i, [_vp, _d, _d]),
+    "gj_set_fill_threads": (_i, [_vp, _i]),
     "gj_get_unpack": (_i, [_vp, C.POINTER(_d), C.POINTER(_d)]),
     "gj_device_info": (_i, [_vp, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(C.c_uint64)]),
     "gj_device_identity": (_i, [_vp, C.c_char_p, _sz]),

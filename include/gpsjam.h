@@ -142,6 +142,13 @@ int gj_upload(gj_ctx* ctx, const uint8_t* host, size_t nbytes, void** dptr);
 int gj_upload_file(gj_ctx* ctx, const char* path, size_t offset, size_t max_bytes, void** dptr,
                    size_t* nbytes_out);
 
+/* Host threads that fill the pinned bounce buffers of ONE staged copy (gj_upload*, gj_ingest_*): 0 = by capture size (two
+ * to eight: four for the reference's 10-s captures, eight from 64 MiB up -- starting and joining eight threads costs a
+ * 41-MB capture more than they carry), 1..16 = that many.  For a host that brings in several files at once from threads
+ * of its own (one lane per call) and wants them to share the cores.  GPSJAM_FILL_THREADS in the environment overrides
+ * both. */
+int gj_set_fill_threads(gj_ctx* ctx, int n);
+
 /* HIP-event stopwatch on the context's stream (what bench.py's roofline uses) */
 int gj_timer_start(gj_ctx* ctx);
 int gj_timer_stop(gj_ctx* ctx, float* elapsed_ms); /* synchronises on the stop event */

@@ -489,3 +489,27 @@ def test_pack_results_in_one_launch_equals_one_launch_per_capture(dev):
         assert one[a].download(np.uint8).tobytes() == many[a].download(np.uint8).tobytes(), f"capture {a}"
     for b in bufs + one + many:
         b.free()
+
+
+# ----------------------------------------------------------------------------- fill threads of a staged copy
+def test_fill_threads_change_the_copy_not_the_results(dev):
+    """gj_set_fill_threads: 0 = by capture size (four for a 10-s capture), 1..16 fixed.  Pieces and threads differ, the
+    bytes in HBM and every result that rides on the capture do not; values outside 0..16 are refused."""
+    raw = generate(StreamSpec(seed=77, jam_start=3_000_000, jam_end=1 << 40, jam_sigma=50.0), 9_000_000)    # 18 MB: staged
+    want = None
+    try:
+        for n in (0, 1, 2, 5, 16):
+            dev.set_fill_threads(n)
+            with dev.ingest(raw, rssi_threshold=0.0, welch=(2048000, 1024)) as cap:
+                got = (hashlib.sha256(cap.download().tobytes()).hexdigest(), dev.chunk_power(cap).tobytes(), bytes(dev.amp_stats(cap, 0.0)),
+                       bytes(dev.onset(cap)), dev.welch(cap, nperseg=1024, want_db=False)[0].tobytes())
+            want = want or got
+            assert got == want, n
+            with dev.capture(raw) as cap:
+                assert hashlib.sha256(cap.download().tobytes()).hexdigest() == want[0]
+        for bad in (-1, 17):
+            with pytest.raises(gpsjam.GpsJamError):
+                dev.set_fill_threads(bad)
+    finally:
+        dev.set_fill_threads(0)
+    assert want[0] == hashlib.sha256(raw.tobytes()).hexdigest()
