@@ -102,3 +102,15 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b|gpsjam_oracle", txt, flags=re.M):
                     bad.append(os.path.join(root, f))
     assert not bad, f"product files reference the oracle: {bad}"
+
+
+def test_header_is_plain_c_and_cxx(tmp_path):
+    """include/gpsjam.h is the boundary: it must compile on its own as C11 (-pedantic) and as C++17, warnings as errors."""
+    src = '#include "gpsjam.h"\nint main(void) { return gj_version() == GJ_VERSION ? 0 : 1; }\n'
+    for name, cc, std in (("h.c", "gcc", "-std=c11"), ("h.cpp", "g++", "-std=c++17")):
+        f = tmp_path / name
+        f.write_text(src)
+        extra = ["-pedantic"] if cc == "gcc" else []
+        r = subprocess.run([cc, std, "-Wall", "-Wextra", "-Werror", *extra, "-I", os.path.join(REPO, "include"), "-fsyntax-only", str(f)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
