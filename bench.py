@@ -126,6 +126,8 @@ def main():
                     help="N = 1 only, rehearsal: give this GPU the per-rank load of a W-antenna deployment -- W - 1 further "
                          "slots prepared before the timed region, rank 0's share of the pairs (W / 2 of them) instead of "
                          "all; with --force-exchange the collectives are issued too.  Not the reported configuration")
+    ap.add_argument("--pack-on-side", action="store_true",
+                    help="one capture per GPU: pack the result vector on the second stream (measured neutral on the 1-GiB step: NOTES_r05)")
     ap.add_argument("--pack-on-main", action="store_true",
                     help="--split: pack the part vectors on the main stream behind K2 (round 4's order) instead of on the second stream")
     ap.add_argument("--side-priority", type=int, default=0, help="HIP priority of the second stream (0 default, -1 high)")
@@ -228,7 +230,8 @@ def main():
     stream = AntennaStream(dev, cap, nperseg=NPERSEG, chunk_samples=CHUNK_SAMPLES, slice_samples=SLICE,
                            rank=rank, world_size=world, overlap=not args.no_overlap, aux_slots=aux,
                            transport=args.transport, exchange_always=args.force_exchange and world == 1,
-                           pairs=only_pairs if world == 1 else None, side_priority=args.side_priority)
+                           pairs=only_pairs if world == 1 else None, side_priority=args.side_priority,
+                           pack_on_side=args.pack_on_side)
     torch.cuda.synchronize()
 
     def barrier():

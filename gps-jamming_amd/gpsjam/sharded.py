@@ -370,7 +370,7 @@ class AntennaStream:
                  factor: float = 50.0, rssi_threshold: float = 0.0, rank: int = 0, world_size: int = 1,
                  overlap: Optional[bool] = None, aux_slots: Optional[torch.Tensor] = None,
                  transport="torch", side_device=None, exchange_always: bool = False, pairs=None,
-                 side_priority: int = 0):
+                 side_priority: int = 0, pack_on_side: bool = False):
         assert capture.dtype == torch.uint8 and capture.is_contiguous()
         self.dev, self.cap = dev, capture
         # K2 is bound by VALU issue and leaves ~90 % of the HBM bandwidth idle, the fused scan is HBM
@@ -412,7 +412,16 @@ class AntennaStream:
         self.power = torch.empty(self.n_chunks, dtype=torch.float32, device=d)
         self.stats = torch.empty(3, dtype=torch.float32, device=d)
         self.mask = torch.empty(self.n_chunks, dtype=torch.uint8, device=d)
-        self.psd = torch.empty((max(self.rows, 1), nperseg), dtype=torch.float32, device=d)
+        # ``pack_on_side``: the result vector is packed on the second stream (behind K5, where its inputs come from), so the
+        # main stream carries K2 + finalize and nothing else; needs two PSD buffers, written alternately (gpsjam/split.py
+        # does the same, where it pays: NOTES_r05 section 5).  Off by default: on the 1-GiB step it is measured neutral.
+        self._pack_on_side = bool(pack_on_side) and self.overlap
+        self.psd2 = [torch.empty((max(self.rows, 1), nperseg), dtype=torch.float32, device=d) for _ in range(2 if self._pack_on_side else 1)]
+        self.psd = self.psd2[0]
+        self._pidx = 0
+        if self._pack_on_side:
+            self._ev_psd = [torch.cuda.Event(), torch.cuda.Event()]
+            self._ev_psd_read = [None, None]
         self.amp = torch.zeros(4, dtype=torch.int64, device=d)        # gj_amp_stats (32 bytes)
         self.onset = torch.zeros(4, dtype=torch.int64, device=d)      # gj_onset (32 bytes)
         # collectives
@@ -490,7 +499,14 @@ class AntennaStream:
             self._ev_side.record(self._side)
 
     def welch(self):
+        if self._pack_on_side:
+            self._pidx ^= 1
+            self.psd = self.psd2[self._pidx]
+            if self._ev_psd_read[self._pidx] is not None:           # the packing of two steps ago has read this buffer
+                self._main.wait_event(self._ev_psd_read[self._pidx])
         self.dev.welch_dev(self.cap, self.nbytes, self.chunk_samples, self.nperseg, self.fs, self.psd)
+        if self._pack_on_side:
+            self._ev_psd[self._pidx].record(self._main)
 
     def scan(self):
         """Everything that only needs this rank's capture (no host synchronisation)."""
@@ -519,16 +535,24 @@ class AntennaStream:
 
     def pack(self) -> torch.Tensor:
         """Result vector of this stream, built by one kernel (layout = pack_results)."""
-        if self.overlap:
+        side = self._pack_on_side
+        stream, dev = (self._side, self.dev_side) if side else (self._main, self.dev)
+        if side:
+            stream.wait_event(self._ev_psd[self._pidx])
+        elif self.overlap:
             self._main.wait_event(self._ev_side)
         self._idx ^= 1
         self.result = self._results[self._idx]
-        self.dev.pack_result_dev(self.n_chunks, self.power, self.stats, self.amp, self.onset, self.psd, self.rows,
-                                 self.nperseg, self.rank, len(self.pairs), self.pair_cap, self.d_pairs, self.lags,
-                                 self.peaks, self.margins, self.result)
+        dev.pack_result_dev(self.n_chunks, self.power, self.stats, self.amp, self.onset, self.psd, self.rows,
+                            self.nperseg, self.rank, len(self.pairs), self.pair_cap, self.d_pairs, self.lags,
+                            self.peaks, self.margins, self.result)
         if self.overlap:
-            self._ev_free.record(self._main)       # the next step's scan / K5 may overwrite their outputs now
-            self._ev_packed.record(self._main)
+            self._ev_free.record(stream)       # the next step's scan / K5 may overwrite their outputs now
+            self._ev_packed.record(stream)
+            if side:
+                if self._ev_psd_read[self._pidx] is None:
+                    self._ev_psd_read[self._pidx] = torch.cuda.Event()
+                self._ev_psd_read[self._pidx].record(stream)
         return self.result
 
     def exchange(self, dst: int = 0) -> Optional[StepResults]:
@@ -544,7 +568,7 @@ class AntennaStream:
         if not self._exchange:
             rows = vec.unsqueeze(0)
             if self._done[k] is not None:
-                self._done[k].record(self._main)
+                self._done[k].record(self._side if self._pack_on_side else self._main)
         else:
             if self.overlap:
                 self._side.wait_event(self._ev_packed)
