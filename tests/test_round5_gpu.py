@@ -513,3 +513,45 @@ def test_fill_threads_change_the_copy_not_the_results(dev):
     finally:
         dev.set_fill_threads(0)
     assert want[0] == hashlib.sha256(raw.tobytes()).hexdigest()
+
+
+# ----------------------------------------------------------------------------- packing on the second stream (optional)
+def test_antenna_stream_with_the_packing_on_the_second_stream():
+    """AntennaStream(pack_on_side=True): the main stream carries K2 + finalize only, the result vector is packed behind K5 on
+    the second stream from one of two PSD buffers.  Six steps back to back: every step's vector byte-equal to the default
+    arrangement's (both buffer sets, both PSD buffers in use)."""
+    import torch
+    from gpsjam import sharded
+    n = 900_000
+    raws = [generate(StreamSpec(seed=31, antenna=a, delay=d, jam_start=400_000, jam_end=800_000, jam_sigma=55.0), n)
+            for a, d in enumerate((0, 6, -4))]
+    work = torch.cuda.Stream()
+    torch.cuda.set_stream(work)
+    out = {}
+    try:
+        for side in (False, True):
+            with gpsjam.Device(0) as dev:
+                dev.set_stream(work.cuda_stream)
+                caps = [torch.from_numpy(r).cuda() for r in raws]
+                sl = 50000
+                aux = torch.zeros((2, dev.tdoa_slot_bytes(sl)), dtype=torch.uint8, device="cuda")
+                d_on = torch.zeros(4, dtype=torch.int64, device="cuda")
+                for a in (1, 2):
+                    dev.onset_dev(caps[a], caps[a].numel(), 200000, 1000, 50.0, d_on)
+                    dev.tdoa_slot_dev(caps[a], caps[a].numel(), d_on, sl, aux[a - 1])
+                st = sharded.AntennaStream(dev, caps[0], nperseg=1024, chunk_samples=131072, slice_samples=sl, aux_slots=aux,
+                                           pack_on_side=side)
+                assert st._pack_on_side is side and len(st.psd2) == (2 if side else 1)
+                vecs = []
+                for _ in range(6):
+                    got = st.step()
+                    got.wait()
+                    vecs.append(got.vectors.clone())
+                torch.cuda.synchronize()
+                res, td = got.unpack()
+                out[side] = ([v.cpu().numpy().tobytes() for v in vecs], td.lags, st.psd[:st.rows].cpu().numpy().tobytes())
+                st.close()
+        assert out[True] == out[False] and len(set(out[True][0])) == 1
+        assert len(out[True][1]) == 3 and all(abs(l) < 64 for l in out[True][1])      # three solved pairs, slots cut at their own onsets
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream())
