@@ -94,3 +94,58 @@ def test_capture_part_arguments_are_checked(dev):
     assert pm.shape == (4,)
     for b in (buf, d_pow, d_tiles, d_amp, d_on, d_psd):
         b.free()
+
+
+def test_round5_entry_points_check_their_arguments(dev):
+    """gj_capture_scan_dev, gj_welch_batch_dev, gj_pack_results_dev, gj_set_fill_threads, gj_debug_inject, gj_probe_busy_dev:
+    bad arguments come back as a status, nothing is launched, and the context keeps working."""
+    from gpsjam import _ffi
+    n = 400_000
+    raw = generate(StreamSpec(seed=8, jam_start=250_000, jam_end=1 << 40, jam_sigma=50.0), n)
+    cap = dev.alloc(2 * n + 16).upload(raw)
+    nch = dev.chunk_count(2 * n, 65536)
+    d_pow, d_st, d_amp, d_on = dev.alloc(4 * nch), dev.alloc(16), dev.alloc(32), dev.alloc(32)
+    d_slot = dev.alloc(dev.tdoa_slot_bytes(4096) + 16)
+    with pytest.raises(gpsjam.GpsJamError) as e:                     # a slot that is not 16-byte aligned
+        dev.capture_scan_dev(cap, 2 * n, 65536, d_pow, 0.0, d_amp, 200000, 1000, 50.0, d_on, slice_samples=4096, d_slot=d_slot.ptr + 8)
+    assert e.value.status == GJ_ERR_INVALID and "aligned" in str(e.value)
+    with pytest.raises(gpsjam.GpsJamError) as e:                     # a slot of no samples
+        dev.capture_scan_dev(cap, 2 * n, 65536, d_pow, 0.0, d_amp, 200000, 1000, 50.0, d_on, slice_samples=0, d_slot=d_slot)
+    assert e.value.status == GJ_ERR_INVALID
+    with pytest.raises(gpsjam.GpsJamError) as e:
+        dev.capture_scan_dev(cap, 2 * n, 65536, d_pow, 0.0, d_amp, 200000, 9000, 50.0, d_on)       # window > 8192
+    assert e.value.status == GJ_ERR_UNSUPPORTED
+    with pytest.raises(gpsjam.GpsJamError) as e:
+        dev.capture_scan_dev(cap, 2 * n, 0, d_pow, 0.0, d_amp, 200000, 1000, 50.0, d_on)
+    assert e.value.status == GJ_ERR_INVALID
+    rows = dev.welch_rows(2 * n, 100_000, 1024)
+    psd = dev.alloc(4 * rows * 1024 + 16)
+    with pytest.raises(gpsjam.GpsJamError) as e:                     # PSD rows off a 16-byte boundary
+        dev.welch_batch_dev([cap, cap], 2 * n, 100_000, 1024, 2.048e6, [psd, psd.ptr + 4])
+    assert e.value.status == GJ_ERR_INVALID and "aligned" in str(e.value)
+    with pytest.raises(gpsjam.GpsJamError) as e:
+        dev.welch_batch_dev([cap] * 17, 2 * n, 100_000, 1024, 2.048e6, [psd] * 17)
+    assert e.value.status == GJ_ERR_INVALID
+    with pytest.raises(gpsjam.GpsJamError) as e:
+        dev.welch_batch_dev([cap, cap], 2 * n, 100_000, 1000, 2.048e6, [psd, psd])
+    assert e.value.status == GJ_ERR_UNSUPPORTED
+    desc = _ffi.CombineCapture(n_chunks=nch, rows=rows, n_tiles=0, total_bytes=0, n_parts=1, antenna=0, n_pairs=2, pair_cap=1,
+                               d_power=d_pow.ptr, d_stats=d_st.ptr, d_tiles=None, d_amp_parts=None, d_onset_parts=None, d_amp=d_amp.ptr,
+                               d_onset=d_on.ptr, d_psd=psd.ptr, d_out=psd.ptr)
+    with pytest.raises(gpsjam.GpsJamError) as e:                     # more pairs than capacity
+        dev.pack_results_dev([desc], 1024)
+    assert e.value.status == GJ_ERR_INVALID
+    desc.n_pairs, desc.d_out = 0, None
+    with pytest.raises(gpsjam.GpsJamError) as e:                     # no output vector
+        dev.pack_results_dev([desc], 1024)
+    assert e.value.status == GJ_ERR_INVALID
+    for call in (lambda: dev.set_fill_threads(99), lambda: dev.debug_inject(7, 1), lambda: dev.probe_busy_dev(-1.0)):
+        with pytest.raises(gpsjam.GpsJamError) as e:
+            call()
+        assert e.value.status == GJ_ERR_INVALID
+    # and the context still works: the scan that was refused four times now runs
+    dev.capture_scan_dev(cap, 2 * n, 65536, d_pow, 0.0, d_amp, 200000, 1000, 50.0, d_on, d_stats=d_st, slice_samples=4096, d_slot=d_slot)
+    dev.synchronize()
+    assert int(d_on.download(np.int64, 1)[0]) > 0 and np.isfinite(d_pow.download(np.float32, nch)).all()
+    for b in (cap, d_pow, d_st, d_amp, d_on, d_slot, psd):
+        b.free()
