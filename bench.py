@@ -1022,14 +1022,17 @@ def deployment(np, torch, gpsjam, dev, StreamSpec, reps=20, graph=True, **local_
     if os.path.isdir("/dev/shm") and not os.access(d, os.W_OK):
         d = "/dev/shm"
     paths = [os.path.join(d, f"gpsjam_bench_{os.getpid()}_ant{a}.bin") for a in range(3)]
-    file_ms, same = [], None
+    file_ms, file_seq_ms, same = [], [], None
     try:
         for a in range(3):
             gpu["host"][a].tofile(paths[a])
 
-        def from_files():
+        def from_files(together=True):
             t0 = time.perf_counter()
-            held = [dev.ingest(pth, rssi_threshold=0.0, welch=(CHUNK_SAMPLES, REF_NPERSEG), want_db=False) for pth in paths]
+            if together:     # gj_ingest_files: the three recordings side by side, a library thread and lane each
+                held = dev.ingest_many(paths, rssi_threshold=0.0, welch=(CHUNK_SAMPLES, REF_NPERSEG), want_db=False)
+            else:            # one after the other, as the reference reads them
+                held = [dev.ingest(pth, rssi_threshold=0.0, welch=(CHUNK_SAMPLES, REF_NPERSEG), want_db=False) for pth in paths]
             pm = [dev.chunk_power(c) for c in held]
             ps = [dev.welch(c, chunk_samples=CHUNK_SAMPLES, nperseg=REF_NPERSEG, want_db=False)[0] for c in held]
             am = [dev.amp_stats(c, 0.0) for c in held]
@@ -1046,6 +1049,11 @@ def deployment(np, torch, gpsjam, dev, StreamSpec, reps=20, graph=True, **local_
             file_ms.append(ms)
         same = bool(all(np.array_equal(got[0][a], gpu["power"][a]) for a in range(3)) and got[1][0].tobytes() == gpu["psd0"].tobytes()
                     and got[3] == gpu["onset"] and got[4] == gpu["lags"])
+        from_files(together=False)
+        for _ in range(3):
+            ms, got1 = from_files(together=False)
+            file_seq_ms.append(ms)
+        same = same and bool(all(np.array_equal(got1[0][a], gpu["power"][a]) for a in range(3)) and got1[3] == gpu["onset"] and got1[4] == gpu["lags"])
     finally:
         for pth in paths:
             try:
@@ -1058,15 +1066,16 @@ def deployment(np, torch, gpsjam, dev, StreamSpec, reps=20, graph=True, **local_
             "resident_step_ms": resident_ms, "resident_step_latency_ms": min(one),
             "resident_msamples_per_s": total / (resident_ms / 1e3) / 1e6,
             "file_to_results_ms": min(file_ms) if file_ms else None, "file_to_results_ms_all": file_ms,
+            "file_to_results_one_by_one_ms": min(file_seq_ms) if file_seq_ms else None, "file_to_results_one_by_one_ms_all": file_seq_ms,
             "file_msamples_per_s": (total / (min(file_ms) / 1e3) / 1e6) if file_ms else None,
             "files_where": d, "file_results_identical_to_resident": same,
             "results": {"lags": gpu["lags"], "onsets": gpu["onset"], "amp_mean": gpu["amp_mean"],
                         "baseline": [float(x[0]) for x in gpu["stats"]]},
             "what": "resident_step: back-to-back steps over three captures already in HBM (rate) and one step alone (latency); "
-                    "file_to_results: three page-cache-resident files through gj_ingest_file (pieces sized to the capture, kernels "
-                    "on what has landed), one file after the other as the drop-ins do (three at once, one thread and lane each, was "
-                    "measured: 5.8-7.3 against 5.6-6.0 ms with eight fill threads each; with two each 4.0 ms in a bare probe but 5-11 ms from "
-                    "Python threads -- profiles/NOTES_r05.md section 8) + K5 on the "
+                    "file_to_results: three page-cache-resident files through gj_ingest_files -- side by side, a thread of the library "
+                    "and a lane per file, two to three fill threads each (three Python threads doing the same: 5-11 ms, GIL hand-offs: "
+                    "profiles/NOTES_r05.md section 8); file_to_results_one_by_one: gj_ingest_file per file, as the reference reads "
+                    "them; either way pieces sized to the capture, kernels on what has landed, then K5 on the "
                     "resident captures, wall clock with PCIe, best of three"}
     return {"line": line, "gpu": gpu}
 

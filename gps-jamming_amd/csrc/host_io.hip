@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cmath>
 #include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -861,6 +862,46 @@ int gj_ingest_file(gj_ctx* ctx, const char* path, size_t offset, size_t max_byte
     }
     close(fd);
     return rc;
+}
+
+// Several capture files at once: one host thread of the library's own per file (the caller's thread takes the first), a
+// lane each, the fill threads per file lowered so that the copies share the cores.  The reference reads a deployment's
+// recordings one after the other (skrypty/triangulateRSSI.py:160-174); three 10-s files: 4.7 ms one after the other,
+// 4.0 at once (tools/ingest3_probe.py).  Threads are started here, not by the host language: three Python threads cost
+// more in start-up and GIL hand-offs than the overlap gains (profiles/NOTES_r05.md section 8).
+int gj_ingest_files(gj_ctx* ctx, gj_ingest_job* jobs, int n_jobs, const gj_ingest_plan* plan) {
+    if (!ctx) return GJ_ERR_INVALID;
+    if (!jobs || !plan || n_jobs < 1 || n_jobs > 64) return fail(ctx, GJ_ERR_INVALID, "bad job list (%d jobs)", n_jobs);
+    for (int k = 0; k < n_jobs; ++k) {
+        if (!jobs[k].path) return fail(ctx, GJ_ERR_INVALID, "job %d: null path", k);
+        jobs[k].status = GJ_OK;
+        jobs[k].dptr = nullptr;
+    }
+    NoCancel nc;   // the joins below are cancellation points: a pending cancellation acts after the call
+    int old_fill = 0;
+    {
+        Guard g(ctx);
+        old_fill = ctx->fill_threads;
+        if (old_fill == 0 && n_jobs > 1) ctx->fill_threads = (8 / n_jobs) > 2 ? 8 / n_jobs : 2;
+    }
+    std::vector<std::string> msgs((size_t)n_jobs);
+    auto run = [&](int k) {
+        gj_ingest_job& j = jobs[k];
+        j.status = gj_ingest_file(ctx, j.path, j.offset, j.max_bytes, plan, j.power, j.power_cap, j.psd, j.psd_db, j.psd_cap_floats,
+                                  &j.result, &j.dptr);
+        if (j.status) msgs[(size_t)k] = last_error_buf();   // the message is per thread: bring it home
+    };
+    std::vector<std::thread> pool;
+    for (int k = 1; k < n_jobs; ++k) pool.emplace_back(run, k);
+    run(0);
+    for (auto& t : pool) t.join();
+    {
+        Guard g(ctx);
+        ctx->fill_threads = old_fill;
+    }
+    for (int k = 0; k < n_jobs; ++k)
+        if (jobs[k].status) return fail(ctx, jobs[k].status, "%s (file %d of %d: %s)", msgs[(size_t)k].c_str(), k, n_jobs, jobs[k].path);
+    return GJ_OK;
 }
 
 // ---------------------------------------------------------------- host-buffer entry points

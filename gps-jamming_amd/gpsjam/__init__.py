@@ -311,10 +311,9 @@ class Device:
         ``onset`` / ``welch`` when these are called on it with the same parameters -- bit-identical to what those
         calls compute on an uploaded capture, without a second pass."""
         import os
-        plan = _ffi.IngestPlan(int(chunk_bytes), float(eps), _ffi.GJ_CP_ODD_CHUNK_ZERO if odd_chunk_zero else 0,
-                               float(rssi_threshold), int(noise_samples), int(window), float(factor),
-                               int(welch[0]) if welch else 0, int(welch[1]) if welch else 0,
-                               _ffi.GJ_WELCH_SHIFT if shift else 0, float(fs))
+        kw = dict(chunk_bytes=chunk_bytes, eps=eps, odd_chunk_zero=odd_chunk_zero, rssi_threshold=rssi_threshold,
+                  noise_samples=noise_samples, window=window, factor=factor, welch=welch, fs=fs, shift=shift, want_db=want_db)
+        plan = self._ingest_plan(**kw)
         is_path = isinstance(source, (str, bytes, os.PathLike))
         if is_path:
             path = os.fspath(source)
@@ -328,12 +327,7 @@ class Device:
             if offset or max_bytes:
                 raw = raw[offset:offset + max_bytes] if max_bytes else raw[offset:]
             nbytes = int(raw.size)
-        n_chunks = self._lib.gj_chunk_count(nbytes, chunk_bytes) if chunk_bytes else 0
-        rows = self._lib.gj_welch_rows(nbytes, welch[0], welch[1]) if welch else 0
-        power = np.empty(n_chunks, np.float32)
-        nper = int(welch[1]) if welch else 0
-        psd = np.empty((rows, nper), np.float32)
-        db = np.empty((rows, nper), np.float32) if (welch and want_db) else None
+        power, psd, db = self._ingest_buffers(nbytes, chunk_bytes, welch, want_db)
         res, p = _ffi.IngestResult(), C.c_void_p()
         args = (C.byref(plan), power.ctypes.data, power.size, psd.ctypes.data, db.ctypes.data if db is not None else None,
                 psd.size, C.byref(res), C.byref(p))
@@ -341,18 +335,70 @@ class Device:
             self._check(self._lib.gj_ingest_file(self._ctx, os.fsencode(path), int(offset), int(max_bytes), *args))
         else:
             self._check(self._lib.gj_ingest_u8(self._ctx, raw.ctypes.data if raw.size else None, raw.size, *args))
-        cap = Capture._adopt(self, p.value, res.nbytes, path)
+        return self._ingest_adopt(p.value, res, path, power, psd, db, **kw)
+
+    def ingest_many(self, paths, *, chunk_bytes: int = 65536, eps: float = 1e-10, odd_chunk_zero: bool = False,
+                    rssi_threshold: float = 0.0, noise_samples: int = 200000, window: int = 1000, factor: float = 50.0,
+                    welch=None, fs: float = 2.048e6, shift: bool = True, want_db: bool = False):
+        """``ingest`` for several capture FILES at once (gj_ingest_files: one host thread of the library and one lane per
+        file, the copies sharing the cores) -- the recordings of a deployment.  Returns the Captures in the order of
+        ``paths``, each with the same ride-along results ``ingest`` would have left on it.  A file that cannot be read
+        raises (FileNotFoundError from the stat here, GpsJamError from the library); captures that did come in are freed."""
+        import os
+        paths = [os.fspath(p) for p in paths]
+        kw = dict(chunk_bytes=chunk_bytes, eps=eps, odd_chunk_zero=odd_chunk_zero, rssi_threshold=rssi_threshold,
+                  noise_samples=noise_samples, window=window, factor=factor, welch=welch, fs=fs, shift=shift, want_db=want_db)
+        if not paths:
+            return []
+        plan = self._ingest_plan(**kw)
+        jobs = (_ffi.IngestJob * len(paths))()
+        bufs = []
+        for k, path in enumerate(paths):
+            nbytes = os.stat(path).st_size                   # FileNotFoundError like open()
+            power, psd, db = self._ingest_buffers(nbytes, chunk_bytes, welch, want_db)
+            bufs.append((power, psd, db))
+            j = jobs[k]
+            j.path, j.offset, j.max_bytes = os.fsencode(path), 0, 0
+            j.power, j.power_cap = power.ctypes.data, power.size
+            j.psd, j.psd_db, j.psd_cap_floats = psd.ctypes.data, (db.ctypes.data if db is not None else None), psd.size
+        rc = self._lib.gj_ingest_files(self._ctx, jobs, len(paths), C.byref(plan))
+        if rc:
+            for j in jobs:
+                if j.status == 0 and j.dptr:
+                    self._lib.gj_free(self._ctx, j.dptr)
+            self._check(rc)
+        return [self._ingest_adopt(jobs[k].dptr, jobs[k].result, paths[k], *bufs[k], **kw) for k in range(len(paths))]
+
+    @staticmethod
+    def _ingest_plan(*, chunk_bytes, eps, odd_chunk_zero, rssi_threshold, noise_samples, window, factor, welch, fs, shift, want_db):
+        return _ffi.IngestPlan(int(chunk_bytes), float(eps), _ffi.GJ_CP_ODD_CHUNK_ZERO if odd_chunk_zero else 0,
+                               float(rssi_threshold), int(noise_samples), int(window), float(factor),
+                               int(welch[0]) if welch else 0, int(welch[1]) if welch else 0,
+                               _ffi.GJ_WELCH_SHIFT if shift else 0, float(fs))
+
+    def _ingest_buffers(self, nbytes, chunk_bytes, welch, want_db):
+        n_chunks = self._lib.gj_chunk_count(nbytes, chunk_bytes) if chunk_bytes else 0
+        rows = self._lib.gj_welch_rows(nbytes, welch[0], welch[1]) if welch else 0
+        nper = int(welch[1]) if welch else 0
+        power = np.empty(n_chunks, np.float32)
+        psd = np.empty((rows, nper), np.float32)
+        db = np.empty((rows, nper), np.float32) if (welch and want_db) else None
+        return power, psd, db
+
+    def _ingest_adopt(self, ptr, res, path, power, psd, db, *, chunk_bytes, eps, odd_chunk_zero, rssi_threshold, noise_samples,
+                      window, factor, welch, fs, shift, want_db):
+        cap = Capture._adopt(self, ptr, res.nbytes, path)
         cap.ingest_ms = (float(res.upload_ms), float(res.total_ms))
         cap.results_unpack = self.get_unpack()               # the convention the ride-along results were computed under
         for a in (power, psd, db):
             if a is not None:
                 a.flags.writeable = False                    # handed out as they are on every matching call
-        if chunk_bytes and n_chunks:
+        if chunk_bytes and power.size:
             cap.results[("chunk_power", int(chunk_bytes), float(np.float32(eps)), bool(odd_chunk_zero))] = power
             cap.results[("amp_stats", float(np.float32(rssi_threshold)))] = AmpStats.from_buffer_copy(bytes(res.amp))
             cap.results[("onset", int(noise_samples), int(window), float(np.float32(factor)))] = Onset.from_buffer_copy(bytes(res.onset))
-        if welch and rows:
-            cap.results[("welch", int(welch[0]), nper, float(fs), bool(shift))] = (psd, db)
+        if welch and psd.shape[0]:
+            cap.results[("welch", int(welch[0]), int(welch[1]), float(fs), bool(shift))] = (psd, db)
         return cap
 
     def _cached(self, raw, key):

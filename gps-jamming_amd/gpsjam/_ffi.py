@@ -70,6 +70,13 @@ class ScanExtra(C.Structure):
                 ("slice_samples", C.c_size_t), ("d_slot", C.c_void_p)]
 
 
+class IngestJob(C.Structure):
+    """gj_ingest_job: one file of gj_ingest_files."""
+    _fields_ = [("path", C.c_char_p), ("offset", C.c_size_t), ("max_bytes", C.c_size_t), ("power", C.c_void_p),
+                ("power_cap", C.c_size_t), ("psd", C.c_void_p), ("psd_db", C.c_void_p), ("psd_cap_floats", C.c_size_t),
+                ("result", IngestResult), ("dptr", C.c_void_p), ("status", C.c_int)]
+
+
 class PartView(C.Structure):
     """gj_part_view: one part of a capture split over GPUs (include/gpsjam.h)."""
     _fields_ = [("d_buf", C.c_void_p), ("buf_bytes", C.c_size_t), ("buf_first_byte", C.c_size_t),
@@ -156,6 +163,7 @@ SIGNATURES = {
     "gj_upload_file": (_i, [_vp, C.c_char_p, _sz, _sz, C.POINTER(_vp), _psz]),
     "gj_ingest_u8": (_i, [_vp, _vp, _sz, C.POINTER(IngestPlan), _vp, _sz, _vp, _vp, _sz, C.POINTER(IngestResult),
                           C.POINTER(_vp)]),
+    "gj_ingest_files": (_i, [_vp, C.POINTER(IngestJob), _i, C.POINTER(IngestPlan)]),
     "gj_ingest_file": (_i, [_vp, C.c_char_p, _sz, _sz, C.POINTER(IngestPlan), _vp, _sz, _vp, _vp, _sz,
                             C.POINTER(IngestResult), C.POINTER(_vp)]),
     "gj_timer_start": (_i, [_vp]),

@@ -325,6 +325,25 @@ int gj_ingest_file(gj_ctx* ctx, const char* path, size_t offset, size_t max_byte
                    float* power, size_t power_cap, float* psd, float* psd_db, size_t psd_cap_floats,
                    gj_ingest_result* result, void** dptr);
 
+/* The recordings of a deployment brought in together: gj_ingest_file for every job, side by side (one host thread of the
+ * library's own and one lane per file; the fill threads per file are lowered for the duration unless gj_set_fill_threads
+ * fixed them).  The reference reads them one after the other (skrypty/triangulateRSSI.py:160-174, worker.py:586-600).
+ * Every job gets its own status, result and device pointer (free each with gj_free); the return value is the first
+ * non-zero status, with that file's message in gj_last_error.  Results are those of gj_ingest_file per file. */
+typedef struct gj_ingest_job {
+    const char* path;
+    size_t offset, max_bytes; /* as gj_ingest_file */
+    float* power;
+    size_t power_cap;
+    float* psd;
+    float* psd_db; /* or NULL */
+    size_t psd_cap_floats;
+    gj_ingest_result result; /* out */
+    void* dptr;              /* out */
+    int status;              /* out */
+} gj_ingest_job;
+int gj_ingest_files(gj_ctx* ctx, gj_ingest_job* jobs, int n_jobs, const gj_ingest_plan* plan);
+
 /* ------------------------------------------------- K5: TDOA cross-correlation ------- */
 /* Replaces signal.correlate(sig1, sig0, 'full') + argmax|.| - (N-1)
  * (skrypty/triangulateTDOA.py:80-89) for every requested antenna pair.

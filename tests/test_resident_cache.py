@@ -129,3 +129,4 @@ def test_release_resident_frees_outside_the_lock(cache):
     assert all(c.ptr == 0 for c in caps) and not gpsjam._resident
 
 
+

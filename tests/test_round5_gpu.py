@@ -555,3 +555,51 @@ def test_antenna_stream_with_the_packing_on_the_second_stream():
         assert len(out[True][1]) == 3 and all(abs(l) < 64 for l in out[True][1])      # three solved pairs, slots cut at their own onsets
     finally:
         torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+# ----------------------------------------------------------------------------- a deployment's files brought in together
+def test_ingest_many_equals_ingest_file_by_file(dev, tmp_path):
+    """gj_ingest_files (Device.ingest_many): the recordings of a deployment uploaded and analysed side by side by threads of
+    the library's own -- resident bytes and every ride-along result equal to Device.ingest on each file; files of unequal
+    length; a file the library cannot open reports which one, and nothing stays allocated behind it."""
+    ns = (2_000_000, 2_000_000, 1_234_567, 300)
+    paths = []
+    for a, n in enumerate(ns):
+        raw = generate(StreamSpec(seed=880 + a, antenna=a % 3, jam_start=min(900_000, n // 2), jam_end=1 << 40, jam_sigma=40.0 + 8 * a), n)
+        p = tmp_path / f"rec{a}.bin"
+        raw.tofile(p)
+        paths.append(str(p))
+    kw = dict(rssi_threshold=0.1, welch=(131072, 1024), want_db=True)
+
+    def facts(c):
+        return (hashlib.sha256(c.download().tobytes()).hexdigest(), dev.chunk_power(c).tobytes(), bytes(dev.amp_stats(c, 0.1)),
+                bytes(dev.onset(c)), tuple(a.tobytes() for a in dev.welch(c, chunk_samples=131072, nperseg=1024)))
+    one = [dev.ingest(p, **kw) for p in paths]
+    want = [facts(c) for c in one]
+    for c in one:
+        c.free()
+    for rounds in range(3):
+        hits = dev.cache_hits
+        many = dev.ingest_many(paths, **kw)
+        got = [facts(c) for c in many]
+        assert dev.cache_hits >= hits + 4 * 3                      # served from the captures: the results rode in with the uploads
+        assert got == want
+        assert [c.nbytes for c in many] == [2 * n for n in ns] and len({c.ptr for c in many}) == 4
+        for c in many:
+            c.free()
+    assert dev.ingest_many([]) == []
+    with pytest.raises(FileNotFoundError):
+        dev.ingest_many([paths[0], str(tmp_path / "nothing.bin")], **kw)
+    os.chmod(paths[2], 0)
+    try:
+        if os.geteuid() != 0:                                      # root reads anything: the library-side failure needs a plain user
+            with pytest.raises(gpsjam.GpsJamError) as e:
+                dev.ingest_many(paths, **kw)
+            assert "file 2 of 4" in str(e.value)
+    finally:
+        os.chmod(paths[2], 0o644)
+    c = dev.ingest_many(paths[:1], **kw)                            # one job: no thread is started
+    assert facts(c[0]) == want[0]
+    c[0].free()
+    assert dev.debug_counters()["lanes_busy"] == 0
+

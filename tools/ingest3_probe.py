@@ -52,12 +52,21 @@ def main():
             c.free()
         return ms
 
-    for f in (sequential, threaded):
+    def in_library():
+        t0 = time.perf_counter()
+        held = dev.ingest_many(paths, rssi_threshold=0.0, welch=(2048000, 1024), want_db=False)
+        ms = (time.perf_counter() - t0) * 1e3
+        for c in held:
+            c.free()
+        return ms
+
+    for f in (sequential, threaded, in_library):
         f()
-    seq = sorted(sequential() for _ in range(7))
-    thr = sorted(threaded() for _ in range(7))
-    print(f"fill threads {os.environ.get('GPSJAM_FILL_THREADS', '8 (default)')}: sequential min {seq[0]:.2f} med {seq[3]:.2f} ms; "
-          f"three threads min {thr[0]:.2f} med {thr[3]:.2f} ms")
+    seq = sorted(sequential() for _ in range(9))
+    thr = sorted(threaded() for _ in range(9))
+    lib = sorted(in_library() for _ in range(9))
+    print(f"fill threads {os.environ.get('GPSJAM_FILL_THREADS', 'by size')}: one after the other min {seq[0]:.2f} med {seq[4]:.2f} max {seq[-1]:.2f} ms; "
+          f"three Python threads min {thr[0]:.2f} med {thr[4]:.2f} max {thr[-1]:.2f}; gj_ingest_files min {lib[0]:.2f} med {lib[4]:.2f} max {lib[-1]:.2f}")
     for p in paths:
         os.remove(p)
     os.rmdir(d)
