@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GJ_VERSION 140 /* 0.1.4: lane ownership by robust mutex (gj_debug_inject), gj_probe_busy_dev (was gj_debug_busy_dev), fused scan tail */
+#define GJ_VERSION 140 /* 0.1.4: lane ownership by robust mutex (gj_debug_inject), gj_probe_busy_dev (was gj_debug_busy_dev), the scan's tail in one launch (gj_capture_scan_dev), K2 / packing of several captures in one launch (gj_welch_batch_dev, gj_pack_results_dev), gj_ingest_files, gj_set_fill_threads */
 
 typedef struct gj_ctx gj_ctx;
 
