@@ -29,7 +29,7 @@ import torch
 import logging
 
 from .sharded import LAG_INVALID, StepResults, all_pairs, result_len
-from .streams import stream_beside
+from .streams import stream_beside_checked
 
 _log = logging.getLogger("gpsjam.local")
 
@@ -54,9 +54,13 @@ class LocalAntennas:
         dev.set_stream(self._main.cuda_stream)
         # side streams, each on a hardware queue of its own (tested), each with a context (= workspace) bound to it
         self._sides: List[tuple] = []
+        #: True when every side stream was TESTED to run beside the main stream and the other side streams; False: the
+        #: step is still correct (cross-stream order is by events) but its chains run one after the other (a warning is logged)
+        self.streams_overlap = True
         for _ in range(max(1, min(self.n_ant, int(side_streams)))):
             sdev = type(dev)(dev.index)
-            s = stream_beside([(dev, self._main)] + self._sides, device=d)
+            s, ok = stream_beside_checked([(dev, self._main)] + self._sides, device=d)
+            self.streams_overlap = self.streams_overlap and ok
             sdev.set_stream(s.cuda_stream)
             self._sides.append((sdev, s))
         self.nbytes = [int(c.numel()) for c in self.caps]

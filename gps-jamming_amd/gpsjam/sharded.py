@@ -379,6 +379,7 @@ class AntennaStream:
         if overlap is None:
             overlap = capture.is_cuda and hasattr(dev, "_ctx")
         self.overlap = bool(overlap)
+        self.streams_overlap = None        # one stream: nothing to overlap
         self.dev_side = dev
         self._main = None
         if capture.is_cuda and hasattr(dev, "_ctx"):
@@ -392,8 +393,9 @@ class AntennaStream:
             # side_priority < 0: a high-priority HIP stream -- its (short) kernels are dispatched ahead of K2's waiting
             # workgroups, which shortens the scan -> slot -> exchange -> K5 chain without changing the total work
             # ... on a hardware queue of its own: two streams the runtime has mapped to one queue run one after the other
-            from .streams import stream_beside
-            self._side = stream_beside([(dev, self._main)], device=capture.device, priority=int(side_priority))
+            from .streams import stream_beside_checked
+            #: False: no stream could be found that runs beside the main one (results unaffected, chains serialised)
+            self._side, self.streams_overlap = stream_beside_checked([(dev, self._main)], device=capture.device, priority=int(side_priority))
             self.dev_side.set_stream(self._side.cuda_stream)
             self._ev_free = torch.cuda.Event()      # main: previous results consumed, buffers may be rewritten
             self._ev_side = torch.cuda.Event()      # side: scan / TDOA results ready

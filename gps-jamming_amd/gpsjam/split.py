@@ -292,15 +292,17 @@ class SplitStreams:
         self.is_root = rank == 0
         self.overlap = bool(d.type == "cuda" if overlap is None else overlap)
         self.dev_side = dev
+        self.streams_overlap = None        # one stream: nothing to overlap
         self._pack_on_side = bool(pack_on_side)
         self._pidx = 0
         self._main = torch.cuda.current_stream(d) if d.type == "cuda" else None
         if self._main is not None:
             dev.set_stream(self._main.cuda_stream)
         if self.overlap:
-            from .streams import stream_beside
+            from .streams import stream_beside_checked
             self.dev_side = type(dev)(dev.index)
-            self._side = stream_beside([(dev, self._main)], device=d)     # on a hardware queue of its own (gpsjam/streams.py)
+            # on a hardware queue of its own (gpsjam/streams.py); streams_overlap False: none found, chains serialised
+            self._side, self.streams_overlap = stream_beside_checked([(dev, self._main)], device=d)
             self.dev_side.set_stream(self._side.cuda_stream)
             self._ev_free, self._ev_side, self._ev_packed = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
             self._ev_free.record(self._main)
@@ -322,7 +324,8 @@ class SplitStreams:
             # The runtime deals streams over a few hardware queues and two streams on one queue run one after the other: a
             # third stream once landed on the MAIN stream's queue and K2 queued behind the combine.  stream_beside tests
             # candidates until one runs beside both other streams; more queues (GPU_MAX_HW_QUEUES=8) give it room.
-            self._comb = stream_beside([(dev, self._main), (self.dev_side, self._side)], device=d)
+            self._comb, ok = stream_beside_checked([(dev, self._main), (self.dev_side, self._side)], device=d)
+            self.streams_overlap = self.streams_overlap and ok
             self.dev_comb.set_stream(self._comb.cuda_stream)
         kw = dict(chunk_bytes=chunk_bytes, chunk_samples=chunk_samples, nperseg=nperseg, fs=fs, slice_samples=slice_samples,
                   noise_samples=noise_samples, window=window, factor=factor, rssi_threshold=rssi_threshold)

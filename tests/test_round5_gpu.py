@@ -334,6 +334,7 @@ with local.LocalAntennas(dev, caps, chunk_samples=131072, nperseg=1024, slice_sa
         got = st.step()
     got.wait()
     torch.cuda.synchronize()
+    print("OVERLAP", st.streams_overlap)
     print("RESULT", hashlib.sha256(got.vectors.cpu().numpy().tobytes()).hexdigest())
     res, td = got.unpack()
     print("LAGS", td.lags, [r.onset for r in res])
@@ -361,6 +362,7 @@ def test_pipelines_stay_correct_when_no_stream_overlaps(tmp_path):
     pick = lambda text, key: [ln for ln in text.splitlines() if ln.startswith(key)]
     assert pick(one, "RESULT") == pick(four, "RESULT") and len(pick(one, "RESULT")) == 1
     assert pick(one, "LAGS") == pick(four, "LAGS") and len(pick(one, "LAGS")) == 1
+    assert pick(one, "OVERLAP") == ["OVERLAP False"] and pick(four, "OVERLAP") == ["OVERLAP True"]   # and the pipeline says which it is
 
 
 def test_probe_cap_and_checked_search(dev):
