@@ -389,6 +389,7 @@ int launch_chunk_power(gj_ctx*, const uint8_t*, size_t, size_t, float, int, floa
 int launch_power_threshold(gj_ctx*, const float*, size_t, float, float, float*, uint8_t*);
 int launch_amp_stats(gj_ctx*, const uint8_t*, size_t, float, gj_amp_stats*);
 int launch_onset(gj_ctx*, const uint8_t*, size_t, int, int, float, gj_onset*);
+int launch_amp_onset(gj_ctx*, const uint8_t*, size_t, float, gj_amp_stats*, int, int, float, gj_onset*);   // either output may be nullptr
 int launch_stream_scan(gj_ctx*, const uint8_t*, size_t, size_t, float, int, float*, float, gj_amp_stats*, int, int,
                        float, gj_onset*, const ScanExtra* extra = nullptr);
 int launch_histogram(gj_ctx*, const uint8_t*, size_t, size_t, int, int, unsigned long long*);

@@ -776,10 +776,9 @@ int ingest_impl(gj_ctx* ctx, size_t nbytes, Fill&& fill, const gj_ingest_plan& p
         rc = follow();
         if (rc) {
         } else if (fused) rc = scan_end(ctx, sj);
-        else if (want_scan && n_chunks) {   // odd chunk sizes / unaligned: the three separate passes
+        else if (want_scan && n_chunks) {   // odd chunk sizes: K1 alone, then the pass for K3 + K4
             rc = launch_chunk_power(ctx, d_cap, nbytes, plan.chunk_bytes, plan.eps, plan.power_flags, d_power);
-            if (!rc) rc = launch_amp_stats(ctx, d_cap, nbytes, plan.rssi_threshold, d_amp);
-            if (!rc) rc = launch_onset(ctx, d_cap, nbytes, plan.noise_samples, plan.window, plan.factor, d_onset);
+            if (!rc) rc = launch_amp_onset(ctx, d_cap, nbytes, plan.rssi_threshold, d_amp, plan.noise_samples, plan.window, plan.factor, d_onset);
         }
         if (!rc && want_welch && rows) rc = welch_end(ctx, wj, plan.welch_flags, d_psd, d_db);
         if (!rc && (hipEventRecord(L->ev_stop, s) != hipSuccess ||

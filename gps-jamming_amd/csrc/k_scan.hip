@@ -387,71 +387,6 @@ struct AmpTile {
     long long first;   // absolute sample index or LLONG_MAX
 };
 
-__global__ __launch_bounds__(kScanThreads) void amp_tiles_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
-                                                                 float thr, AmpTile* __restrict__ tiles, Unpack up) {
-    __shared__ double rs[kScanThreads / 64];
-    __shared__ long long rf[kScanThreads / 64];
-    const size_t s0 = (size_t)blockIdx.x * kAmpTileSamples;
-    const size_t s1 = (s0 + kAmpTileSamples < nsamples) ? s0 + kAmpTileSamples : nsamples;
-    const int tid = threadIdx.x;
-    double sum = 0.0;
-    long long first = 0x7fffffffffffffffll;
-    // tiles start at multiples of 64 KiB, so the base is 16-byte aligned when iq is
-    const bool aligned = ((reinterpret_cast<uintptr_t>(iq) & 15) == 0);
-    const size_t nfull = aligned ? ((s1 - s0) >> 3) : 0;   // groups of 8 samples = 16 bytes
-    const uint4* v = reinterpret_cast<const uint4*>(iq + 2 * s0);
-    unsigned k2 = 0x00020002u, km255 = pk_minus_off2(up.off2);
-    asm volatile("" : "+v"(k2), "+v"(km255));   // both in VGPRs (one constant-bus slot per op)
-    // The arithmetic -- and its ORDER -- is that of the fused scan (stream_scan_kernel): per 16-byte vector the eight
-    // sqrt(m) are added in float, the vector sums in double, the tile total is scaled by half_scale once; the ragged
-    // end of the stream (< 8 samples) is added by thread 0.  K3 alone and K3 inside the fused pass give the same bits.
-    for (size_t gidx = tid; gidx < nfull; gidx += kScanThreads) {
-        const uint4 w = v[gidx];
-        const unsigned ws[4] = {w.x, w.y, w.z, w.w};
-        float part = 0.f;
-        const long long base = (long long)(s0 + gidx * 8);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float r0 = __fsqrt_rn((float)msq_of_half<0>(ws[k], k2, km255)), r1 = __fsqrt_rn((float)msq_of_half<1>(ws[k], k2, km255));
-            part += r0;
-            part += r1;
-            if (r0 * up.half_scale > thr && base + 2 * k < first) first = base + 2 * k;
-            if (r1 * up.half_scale > thr && base + 2 * k + 1 < first) first = base + 2 * k + 1;
-        }
-        sum += (double)part;
-    }
-    if (aligned) {
-        if (tid == 0)
-            for (size_t s = s0 + nfull * 8; s < s1; ++s) {
-                const float r = __fsqrt_rn((float)m_of(iq[2 * s], iq[2 * s + 1], up.off2));
-                sum += (double)r;
-                if (r * up.half_scale > thr && (long long)s < first) first = (long long)s;
-            }
-    } else {
-        for (size_t s = s0 + tid; s < s1; s += kScanThreads) {
-            const float r = __fsqrt_rn((float)m_of(iq[2 * s], iq[2 * s + 1], up.off2));
-            sum += (double)r;
-            if (r * up.half_scale > thr && (long long)s < first) first = (long long)s;
-        }
-    }
-    sum = wave_sum_f64(sum);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const long long o = __shfl_xor(first, off, 64);
-        first = o < first ? o : first;
-    }
-    if ((tid & 63) == 0) { rs[tid >> 6] = sum; rf[tid >> 6] = first; }
-    __syncthreads();
-    if (tid == 0) {
-        AmpTile t;
-        t.sum = ((rs[0] + rs[1]) + (rs[2] + rs[3])) * (double)up.half_scale;
-        long long f = rf[0];
-        for (int k = 1; k < 4; ++k) f = rf[k] < f ? rf[k] : f;
-        t.first = f;
-        tiles[blockIdx.x] = t;
-    }
-}
-
 __device__ double block_sum_f64(double v, double* sh /* [blockDim/64] */) {
     v = wave_sum_f64(v);
     __syncthreads();
@@ -467,9 +402,9 @@ __device__ double block_sum_f64(double v, double* sh /* [blockDim/64] */) {
 //   tail  : sum of the amplitudes from `first` to the end of ITS tile (block reduction over a fixed thread stride;
 //           the tile's own sum when the hit is the tile's first sample)
 //   total : sum of the tile sums BEHIND that tile (fixed thread stride over the global tile index) + tail
-// A whole capture runs the three in one kernel; a capture split over GPUs runs first + tail where the bytes are
-// (the amplitude role of scan_tail_kernel) and total where the tile sums have been gathered (amp_combine_kernel): same code, same
-// order, same bits.
+// A whole capture runs the three in the amplitude role of scan_tail_kernel; a capture split over GPUs runs first + tail
+// where the bytes are (the same role) and total where the tile sums have been gathered (amp_combine_kernel): same code,
+// same order, same bits.
 __device__ long long amp_block_first(const AmpTile* __restrict__ tiles, size_t ntiles, long long* first_s) {
     if (threadIdx.x == 0) *first_s = 0x7fffffffffffffffll;
     __syncthreads();
@@ -526,47 +461,17 @@ __device__ double amp_block_total(const AmpTile* __restrict__ tiles, size_t ntil
     return block_sum_f64(acc, sh);
 }
 
-// (fused scan only) the last chunk when no tile wrote it or the odd-chunk rule applies
-__device__ __forceinline__ void power_edge_cases(float* __restrict__ power, size_t nchunks, size_t nbytes, size_t chunk_bytes,
-                                                 int flags) {
-    if (power && nchunks && threadIdx.x == 0) {
-        const size_t off = (nchunks - 1) * chunk_bytes;
-        const size_t len = nbytes - off;
-        if ((flags & GJ_CP_ODD_CHUNK_ZERO) && (len & 1)) power[nchunks - 1] = 0.0f;
-        else if ((len >> 1) == 0) power[nchunks - 1] = __builtin_nanf("");
-    }
+// (fused scan only) the last chunk when no tile wrote it or the odd-chunk rule applies: true when the LAST chunk's
+// power is decided by the rule, not by the chunk's sums.  The word is written by a one-word memset in front of the tail
+// launch (scan_end): until round 6 the tail's amplitude workgroup wrote it while the threshold workgroup of the SAME
+// launch read the map -- no order between the two.  Rare by construction (odd length, or length = 1 mod chunk).
+static inline bool power_edge_value(size_t nchunks, size_t nbytes, size_t chunk_bytes, int flags, float* val) {
+    if (!nchunks) return false;
+    const size_t len = nbytes - (nchunks - 1) * chunk_bytes;
+    if ((flags & GJ_CP_ODD_CHUNK_ZERO) && (len & 1)) { *val = 0.0f; return true; }
+    if ((len >> 1) == 0) { *val = __builtin_nanf(""); return true; }
+    return false;
 }
-
-// 256 threads: a workgroup this size fits into whatever a finishing K2 workgroup frees (a 1024-thread one needs four
-// waves on every SIMD of one CU at once and waited ~100 us for that beside K2)
-__global__ __launch_bounds__(256) void amp_finalize_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
-                                                            const AmpTile* __restrict__ tiles, size_t ntiles,
-                                                            gj_amp_stats* __restrict__ out, Unpack up,
-                                                            float* __restrict__ power = nullptr, size_t nchunks = 0,
-                                                            size_t nbytes = 0, size_t chunk_bytes = 1, int flags = 0) {
-    power_edge_cases(power, nchunks, nbytes, chunk_bytes, flags);
-    __shared__ double sh[16];
-    __shared__ long long first_s;
-    const long long first = amp_block_first(tiles, ntiles, &first_s);
-    if (first == 0x7fffffffffffffffll) {
-        if (threadIdx.x == 0) {
-            out->first_index = -1; out->count = 0; out->sum = 0.0; out->mean = 0.f; out->reserved = 0.f;
-        }
-        return;
-    }
-    const double tail = amp_block_tail(iq, nsamples, tiles, first, up, sh);
-    const double behind = amp_block_total(tiles, ntiles, (size_t)first / kAmpTileSamples, sh);
-    if (threadIdx.x == 0) {
-        const double total = behind + tail;
-        const unsigned long long cnt = nsamples - (size_t)first;
-        out->first_index = first;
-        out->count = cnt;
-        out->sum = total;
-        out->mean = (float)(total / (double)cnt);
-        out->reserved = 0.f;
-    }
-}
-
 // The combining rank: tile sums of the WHOLE capture (gathered, in tile order) + the parts' first hits and tails.
 __device__ __forceinline__ void amp_combine_body(const AmpTile* __restrict__ tiles, size_t ntiles,
                                                  const gj_amp_part* __restrict__ parts, int n_parts, size_t nsamples,
@@ -628,47 +533,18 @@ int launch_combine_stats(gj_ctx* ctx, const gj_combine_capture* d_caps, int n_ca
     return GJ_OK;
 }
 
-int launch_amp_stats(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, float threshold, gj_amp_stats* d_out) {
-    const size_t nsamples = nbytes / 2;
-    const size_t ntiles = (nsamples + kAmpTileSamples - 1) / kAmpTileSamples;
-    if (ntiles > 0x7fffffffull) return fail(ctx, GJ_ERR_UNSUPPORTED, "capture too long");
-    int rc = ensure_workspace(ctx, (ntiles + 1) * sizeof(AmpTile));
-    if (rc) return rc;
-    AmpTile* tiles = reinterpret_cast<AmpTile*>(ctx->ws);
-    if (ntiles) {
-        hipLaunchKernelGGL(amp_tiles_kernel, dim3((unsigned)ntiles), dim3(kScanThreads), 0, ctx->stream, d_iq, nsamples,
-                           threshold, tiles, unpack_of(ctx));
-        GJ_LAUNCH_CHECK(ctx);
-    }
-    hipLaunchKernelGGL(amp_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, d_iq, nsamples, tiles, ntiles, d_out,
-                       unpack_of(ctx));
-    GJ_LAUNCH_CHECK(ctx);
-    return GJ_OK;
-}
-
 // ---------------------------------------------------------------------------------------
 // K4 onset: moving average of |z|^2 against factor x noise, exact integer window sums
 // ---------------------------------------------------------------------------------------
-constexpr int kOnsetOut = 2048;    // moving-average positions per workgroup tile of the exact scan
+constexpr int kOnsetOut = 2048;    // moving-average positions per tile of the exact scan
 constexpr int kOnsetMaxWin = 8192;
-constexpr int kOnsetLds = kOnsetOut + kOnsetMaxWin;   // u32 words (64 KiB)
 
-// All-zero = initial state (one hipMemsetAsync): the two minima are kept INVERTED (atomicMax of
-// ~index, 0 = none) so that zero means "nothing found yet".
+// What the scan launch hands the tail besides the block sums: the noise sum of a part that does not hold the capture's
+// noise span (summed from the copy it brought along), and the threshold the first onset workgroup derived for the record.
 struct OnsetScratch {
-    unsigned long long first_inv;   // ~(min index whose moving average is above the threshold)
-    unsigned long long cand_inv;    // ~(first sample of the first block that fails the screening proof)
     unsigned long long noise_S;     // sum of (2I-255)^2 + (2Q-255)^2 = 4 |z|^2 over the first noise_samples samples
-    unsigned long long guard_inv;   // ~(min index whose moving average is above threshold * (1 - kOnsetGuard))
     float noise;
     float thr;
-    // decision margin (gj_onset.margin_before): the largest window sum that stayed below the
-    // threshold -- exact over the positions the scan kernel looked at, and the screening bound
-    // (scaled to one window: U covers `cb` blocks) over the blocks proven quiet.  A workgroup that
-    // runs ahead of the first crossing may add values from positions BEHIND it: that only makes the
-    // reported margin smaller (the guard more cautious), never larger.
-    unsigned max_below;
-    unsigned max_screen;
 };
 
 // Rounding band of the decision (gj_onset.guard_index): the window sums here are exact, the reference's carry ~3e-7
@@ -676,299 +552,7 @@ struct OnsetScratch {
 // threshold * (1 - kOnsetGuard) is below the reference's threshold whatever its rounding did.
 constexpr double kOnsetGuard = 1e-6;
 
-__device__ __forceinline__ float onset_threshold(const OnsetScratch* sc, int noise_samples, float factor, float* noise_out) {
-    float noise = (float)((double)sc->noise_S / (4.0 * (double)noise_samples));
-    if (noise == 0.f) noise = 1e-9f;          // triangulateTDOA.py:42
-    if (noise_out) *noise_out = noise;
-    return noise * factor;
-}
-
-
-__global__ __launch_bounds__(kScanThreads) void onset_noise_kernel(const uint8_t* __restrict__ iq, int noise_samples,
-                                                                   OnsetScratch* __restrict__ sc, int o2) {
-    unsigned long long s2 = 0, s1 = 0;
-    block_byte_moments(iq, 0, (size_t)2 * noise_samples, s2, s1);
-    if (threadIdx.x == 0)
-        sc->noise_S = (unsigned long long)(4ll * (long long)s2 - 4ll * o2 * (long long)s1 + (long long)o2 * o2 * (2ll * noise_samples));
-}
-
 __device__ __forceinline__ int onset_pad(int k) { return k + (k >> 5); }   // spreads stride-`per` accesses over banks
-
-// Screening pass: exact block sums c[j] of 4|z|^2 over BS samples, then U[j] = sum of the
-// CB = (window + BS - 2)/BS + 1 blocks starting at block j.  Every window that STARTS inside
-// block j lies inside those blocks and 4|z|^2 >= 0, so U[j] <= threshold proves that no start
-// index in block j crosses the threshold; only the first block that fails the proof is handed
-// to the exact scan below (sc->cand = its first sample).
-//   BS = 8  : c8 straight from the capture, one 16-byte load per block (v_dot4_u32_u8) -- HBM-bound; K4 ALONE (gj_onset_dev)
-//   BS = 512: the fused path -- c512 comes from the stream scan (4 MB per GiB) and the screening is a role of
-//             scan_tail_kernel (tail_onset_range), not this kernel
-constexpr int kCoarseBlocks = 4096;   // blocks per workgroup
-constexpr int kCoarseHalo = (kOnsetMaxWin + 6) / 8 + 1;
-
-template <int BS>
-__global__ __launch_bounds__(kScanThreads) void onset_coarse_kernel(const uint8_t* __restrict__ iq,
-                                                                    const unsigned* __restrict__ cblk, size_t nsamples,
-                                                                    int window, int noise_samples, float factor,
-                                                                    OnsetScratch* __restrict__ sc, int o2) {
-    __shared__ unsigned pre[kCoarseBlocks + kCoarseHalo + (kCoarseBlocks + kCoarseHalo) / 32 + 8];
-    __shared__ unsigned thread_tot[kScanThreads];
-    const size_t nout = nsamples - (size_t)window + 1;
-    const size_t j0 = (size_t)blockIdx.x * kCoarseBlocks;   // first block of this tile
-    const int tid = threadIdx.x;
-    float noise;
-    const float thr_f = onset_threshold(sc, noise_samples, factor, &noise);
-    if (blockIdx.x == 0 && tid == 0) { sc->noise = noise; sc->thr = thr_f; }   // for the exact scan + report
-    const double thr = (double)thr_f * (1.0 - kOnsetGuard);   // screening proves blocks quiet against the guard band
-    if (BS * j0 >= nout) return;
-    if (~__hip_atomic_load(&sc->cand_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < BS * j0) return;
-    const int cb = (window + BS - 2) / BS + 1;
-    const size_t nblk_total = (nsamples + BS - 1) / BS;
-    size_t jend = j0 + kCoarseBlocks;
-    if (BS * jend > nout) jend = (nout + BS - 1) / BS;   // blocks holding a valid start index
-    const int nloc = (int)(jend - j0);
-    const int need = nloc + cb - 1;                      // blocks [j0, j0 + need)
-    const uint4* v = reinterpret_cast<const uint4*>(iq);
-    for (int k = tid; k < need; k += kScanThreads) {
-        const size_t j = j0 + k;
-        unsigned c = 0;
-        if (j < nblk_total) {
-            if constexpr (BS == 8) {
-                if (8 * j + 8 <= nsamples) {
-                    const uint4 q = v[j];
-                    unsigned s2 = 0, s1 = 0;
-                    acc_moments(q, s2, s1);
-                    c = 4u * s2 - 4u * (unsigned)o2 * s1 + 16u * (unsigned)(o2 * o2);
-                } else {
-                    for (size_t n = 8 * j; n < nsamples; ++n) c += m_of(iq[2 * n], iq[2 * n + 1], o2);
-                }
-            } else {
-                c = cblk[j];
-            }
-        }
-        pre[onset_pad(k + 1)] = c;
-    }
-    if (tid == 0) pre[0] = 0;
-    __syncthreads();
-    const int per = (need + kScanThreads - 1) / kScanThreads;
-    const int lo = tid * per;
-    const int hi = (lo + per < need) ? lo + per : need;
-    unsigned run = 0;
-    for (int k = lo; k < hi; ++k) {
-        run += pre[onset_pad(k + 1)];
-        pre[onset_pad(k + 1)] = run;
-    }
-    thread_tot[tid] = run;
-    __syncthreads();
-    if (tid < 64) {
-        unsigned t0 = thread_tot[4 * tid], t1 = thread_tot[4 * tid + 1], t2 = thread_tot[4 * tid + 2],
-                 t3 = thread_tot[4 * tid + 3];
-        unsigned tot = t0 + t1 + t2 + t3, inc = tot;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned o = __shfl_up(inc, off, 64);
-            if (tid >= off) inc += o;
-        }
-        const unsigned ex = inc - tot;
-        thread_tot[4 * tid] = ex;
-        thread_tot[4 * tid + 1] = ex + t0;
-        thread_tot[4 * tid + 2] = ex + t0 + t1;
-        thread_tot[4 * tid + 3] = ex + t0 + t1 + t2;
-    }
-    __syncthreads();
-    const unsigned add = thread_tot[tid];
-    for (int k = lo; k < hi; ++k) pre[onset_pad(k + 1)] += add;
-    __syncthreads();
-    const double scale = 0.25 / (double)window;
-    unsigned long long best = ~0ull;
-    unsigned quiet = 0;   // largest U among the blocks this thread proved quiet
-    for (int k = tid; k < nloc; k += kScanThreads) {
-        const unsigned U = pre[onset_pad(k + cb)] - pre[onset_pad(k)];
-        if ((double)U * scale > thr) { best = (unsigned long long)(j0 + k) * BS; break; }
-        quiet = U > quiet ? U : quiet;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(best, off, 64);
-        best = o < best ? o : best;
-        const unsigned oq = __shfl_xor(quiet, off, 64);
-        quiet = oq > quiet ? oq : quiet;
-    }
-    if ((tid & 63) == 0) {
-        if (best != ~0ull) atomicMax(&sc->cand_inv, ~best);
-        if (quiet) atomicMax(&sc->max_screen, quiet);
-    }
-}
-
-// Exact scan from the candidate on: prefix sums of 4|z|^2 in LDS, window sums by difference.
-// Persistent: workgroup g takes tiles g, g + grid, ... after the candidate and stops as soon
-// as an earlier tile has reported a hit (or the stream ends), so the common case -- onset in the
-// first tile after the candidate -- costs one tile per workgroup.
-__global__ __launch_bounds__(kScanThreads) void onset_scan_kernel(const uint8_t* __restrict__ iq, size_t nsamples,
-                                                                  int window, OnsetScratch* __restrict__ sc, int o2) {
-    __shared__ unsigned pre[kOnsetLds + kOnsetLds / 32 + 2];
-    __shared__ unsigned thread_tot[kScanThreads];
-    const size_t nout = nsamples - (size_t)window + 1;   // valid positions
-    const unsigned long long cand = ~sc->cand_inv;       // written by the screening kernel before this launch
-    if (cand == ~0ull) return;                           // proven: nothing crosses the threshold
-    const int tid = threadIdx.x;
-    const uint16_t* iq16_all = reinterpret_cast<const uint16_t*>(iq);
-    for (size_t tile = blockIdx.x;; tile += gridDim.x) {
-        const size_t o0 = (size_t)cand + tile * kOnsetOut;
-        if (o0 >= nout) return;
-        // everything before this tile already decided?
-        if (~__hip_atomic_load(&sc->first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < o0) return;
-        const size_t o1 = (o0 + kOnsetOut < nout) ? o0 + kOnsetOut : nout;
-        const int need = (int)(o1 - o0) + window - 1;   // samples [o0, o0+need)
-        // (A) coalesced load: pre[1 + k] = 4|z_k|^2
-        const uint16_t* iq16 = iq16_all + o0;
-        for (int k = tid; k < need; k += kScanThreads) {
-            const unsigned w = iq16[k];
-            pre[onset_pad(k + 1)] = m_of(w & 255u, w >> 8, o2);
-        }
-        if (tid == 0) pre[0] = 0;
-        __syncthreads();
-        // (B) inclusive prefix inside each thread's contiguous span
-        const int per = (need + kScanThreads - 1) / kScanThreads;
-        const int lo = tid * per;
-        const int hi = (lo + per < need) ? lo + per : need;
-        unsigned run = 0;
-        for (int k = lo; k < hi; ++k) {
-            run += pre[onset_pad(k + 1)];
-            pre[onset_pad(k + 1)] = run;
-        }
-        thread_tot[tid] = run;
-        __syncthreads();
-        // (C) exclusive scan of the 256 span totals
-        if (tid < 64) {
-            unsigned t0 = thread_tot[4 * tid], t1 = thread_tot[4 * tid + 1], t2 = thread_tot[4 * tid + 2],
-                     t3 = thread_tot[4 * tid + 3];
-            unsigned tot = t0 + t1 + t2 + t3, inc = tot;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned o = __shfl_up(inc, off, 64);
-                if (tid >= off) inc += o;
-            }
-            const unsigned ex = inc - tot;
-            thread_tot[4 * tid] = ex;
-            thread_tot[4 * tid + 1] = ex + t0;
-            thread_tot[4 * tid + 2] = ex + t0 + t1;
-            thread_tot[4 * tid + 3] = ex + t0 + t1 + t2;
-        }
-        __syncthreads();
-        // (D) fold the span offsets in
-        const unsigned add = thread_tot[tid];
-        for (int k = lo; k < hi; ++k) pre[onset_pad(k + 1)] += add;
-        __syncthreads();
-        const double thr = (double)sc->thr, thr_lo = thr * (1.0 - kOnsetGuard);
-        const double scale = 0.25 / (double)window;
-        unsigned long long best = ~0ull, best_lo = ~0ull;
-        unsigned below = 0;   // largest window sum at the positions in front of this thread's first crossing
-        const int nloc = (int)(o1 - o0);
-        for (int k = tid; k < nloc; k += kScanThreads) {
-            const unsigned S = pre[onset_pad(k + window)] - pre[onset_pad(k)];
-            const double ma = (double)S * scale;
-            if (ma > thr_lo) {
-                if (best_lo == ~0ull) best_lo = o0 + k;   // inside the rounding band (or above it)
-                if (ma > thr) { best = o0 + k; break; }
-            }
-            below = S > below ? S : below;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(best, off, 64);
-            best = o < best ? o : best;
-            const unsigned long long ol = __shfl_xor(best_lo, off, 64);
-            best_lo = ol < best_lo ? ol : best_lo;
-            const unsigned ob = __shfl_xor(below, off, 64);
-            below = ob > below ? ob : below;
-        }
-        if ((tid & 63) == 0) {
-            if (best != ~0ull) atomicMax(&sc->first_inv, ~best);
-            if (best_lo != ~0ull) atomicMax(&sc->guard_inv, ~best_lo);
-            if (below) atomicMax(&sc->max_below, below);
-        }
-        __syncthreads();   // LDS is reused by the next tile
-    }
-}
-
-__global__ void onset_set_cand_kernel(OnsetScratch* __restrict__ sc, int noise_samples, float factor) {
-    // unaligned capture: no screening, scan from sample 0
-    sc->cand_inv = ~0ull;
-    float noise;
-    sc->thr = onset_threshold(sc, noise_samples, factor, &noise);
-    sc->noise = noise;
-}
-
-// One wave.  Besides the index: the two decision margins of gj_onset (exact window sum at the
-// crossing, recomputed here from the capture; largest sum that stayed below, from the scratch).
-// `sample0`: index of iq[0] in the whole capture (0 unless the buffer is a part of a split capture).
-__global__ __launch_bounds__(64) void onset_finalize_kernel(const uint8_t* __restrict__ iq, const OnsetScratch* __restrict__ sc,
-                                                            int window, int valid, gj_onset* __restrict__ out, int o2,
-                                                            long long sample0 = 0) {
-    const int tid = threadIdx.x;
-    if (!valid) {
-        if (tid == 0) {
-            out->start_index = -1; out->noise_power = 0.f; out->threshold = 0.f;
-            out->margin_hit = 0.f; out->margin_before = 0.f; out->guard_index = -1;
-        }
-        return;
-    }
-    const bool found = sc->first_inv != 0ull;
-    const unsigned long long i0 = ~sc->first_inv;
-    unsigned long long S = 0;
-    if (found)
-        for (int k = tid; k < window; k += 64) S += m_of(iq[2 * (i0 + k)], iq[2 * (i0 + k) + 1], o2);
-    S = wave_sum_u64(S);
-    if (tid == 0) {
-        const double thr = (double)sc->thr, scale = 0.25 / (double)window;
-        // the screening sums cover cb blocks >= one window: they bound every window sum inside
-        const unsigned mb = sc->max_below > sc->max_screen ? sc->max_below : sc->max_screen;
-        out->start_index = found ? sample0 + (long long)i0 + window / 2 : -1;
-        out->noise_power = sc->noise;
-        out->threshold = sc->thr;
-        out->margin_hit = found ? (float)(((double)S * scale - thr) / thr) : 0.f;
-        out->margin_before = (float)((thr - (double)mb * scale) / thr);
-        // first position inside (or above) the rounding band.  A tile in front of the crossing always runs to its
-        // end, so every band position before i0 has been seen; one behind i0 cannot be first.
-        unsigned long long ig = sc->guard_inv != 0ull ? ~sc->guard_inv : ~0ull;
-        if (found && i0 < ig) ig = i0;
-        out->guard_index = ig != ~0ull ? sample0 + (long long)ig + window / 2 : -1;
-    }
-}
-
-int launch_onset(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, int noise_samples, int window, float factor,
-                 gj_onset* d_out) {
-    if (noise_samples <= 0 || window <= 0) return fail(ctx, GJ_ERR_INVALID, "noise_samples and window must be > 0");
-    if (window > kOnsetMaxWin) return fail(ctx, GJ_ERR_UNSUPPORTED, "window > %d", kOnsetMaxWin);
-    if ((reinterpret_cast<uintptr_t>(d_iq) & 1) != 0) return fail(ctx, GJ_ERR_INVALID, "capture must be 2-byte aligned");
-    const size_t nsamples = nbytes / 2;
-    int rc = ensure_workspace(ctx, sizeof(OnsetScratch));
-    if (rc) return rc;
-    OnsetScratch* sc = reinterpret_cast<OnsetScratch*>(ctx->ws);
-    GJ_HIP(ctx, hipMemsetAsync(sc, 0, sizeof(OnsetScratch), ctx->stream));
-    const int valid = nsamples >= (size_t)noise_samples + (size_t)window;   // triangulateTDOA.py:39
-    if (valid) {
-        hipLaunchKernelGGL(onset_noise_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_iq, noise_samples, sc, ctx->off2);
-        GJ_LAUNCH_CHECK(ctx);
-        const size_t nout = nsamples - window + 1;
-        const size_t ntiles = (nout + kOnsetOut - 1) / kOnsetOut;
-        if (ntiles > 0x7fffffffull) return fail(ctx, GJ_ERR_UNSUPPORTED, "capture too long");
-        if ((reinterpret_cast<uintptr_t>(d_iq) & 15) == 0) {
-            const size_t nct = ((nout + 7) / 8 + kCoarseBlocks - 1) / kCoarseBlocks;
-            hipLaunchKernelGGL(onset_coarse_kernel<8>, dim3((unsigned)nct), dim3(kScanThreads), 0, ctx->stream, d_iq,
-                               (const unsigned*)nullptr, nsamples, window, noise_samples, factor, sc, ctx->off2);
-        } else {
-            hipLaunchKernelGGL(onset_set_cand_kernel, dim3(1), dim3(1), 0, ctx->stream, sc, noise_samples, factor);
-        }
-        GJ_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(onset_scan_kernel, dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(kScanThreads), 0,
-                           ctx->stream, d_iq, nsamples, window, sc, ctx->off2);
-        GJ_LAUNCH_CHECK(ctx);
-    }
-    hipLaunchKernelGGL(onset_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, d_iq, sc, window, valid, d_out, ctx->off2);
-    GJ_LAUNCH_CHECK(ctx);
-    return GJ_OK;
-}
 
 // ---------------------------------------------------------------------------------------
 // Fused stream scan: ONE pass over the capture feeds K1 (chunk power), K3 (amplitude
@@ -1150,7 +734,7 @@ __global__ __launch_bounds__(kScanThreads) void stream_scan_kernel(const uint8_t
 // threshold -- and a sixth for the TDOA slot; beside K2 each of them waited 5-50 us for its turn, and at the sizes the
 // reference runs (10-s captures) that chain, not K2, was the step.  Here they are ROLES of one grid:
 //   workgroup 0                 noise-floor threshold of the power map   (power_threshold_body, as it is)
-//   workgroup 1                 amplitude totals + chunk-power edge cases (amp_finalize / amp_part_finalize bodies)
+//   workgroup 1                 amplitude totals (first hit, tail of its tile, tiles behind)
 //   workgroups 2 .. 2 + nct-1   K4 over kTailBlocks 512-sample blocks each: screening of its blocks against the guard
 //                               band, and -- instead of handing a candidate to a second kernel -- the exact scan of
 //                               every stretch of ITS range that fails the proof, in order, up to its first crossing.
@@ -1195,12 +779,11 @@ struct TailArgs {
     uint8_t* mask;
     // amplitude role (the OWN range of a part)
     const uint8_t* own_iq;
-    unsigned long long own_samples, own_tiles, own_bytes, chunk_bytes;
+    unsigned long long own_samples, own_tiles;
     const AmpTile* tiles;
     gj_amp_stats* amp;
     gj_amp_part* amp_part;
     long long own_sample0;
-    int flags;
     // onset role
     int window, noise_samples, noise_in_scratch;
     float factor;
@@ -1286,8 +869,8 @@ __device__ __forceinline__ void block_min2_max(unsigned long long& a, unsigned l
     __syncthreads();
 }
 
-// Inclusive prefix sums, in place, of the `need` words pre[onset_pad(1)] .. pre[onset_pad(need)] (pre[0] = 0): the
-// three-step scan of onset_scan_kernel / onset_coarse_kernel (thread spans, span totals, fold).
+// Inclusive prefix sums, in place, of the `need` words pre[onset_pad(1)] .. pre[onset_pad(need)] (pre[0] = 0), in three
+// steps: thread spans, span totals, fold.
 __device__ __forceinline__ void block_prefix_u32(unsigned* pre, unsigned* thread_tot, int need) {
     const int tid = threadIdx.x;
     const int per = (need + kScanThreads - 1) / kScanThreads;
@@ -1443,7 +1026,7 @@ __device__ void tail_onset_range(const TailArgs& A, unsigned w, unsigned* pre_c,
     }
 }
 
-// The last onset workgroup to arrive: records -> gj_onset (the arithmetic of onset_finalize_kernel), then the slot.
+// The last onset workgroup to arrive: records -> gj_onset, then the slot.
 __device__ void tail_onset_finish(const TailArgs& A, TailShared& sh) {
     const int tid = threadIdx.x;
     const int window = A.window;
@@ -1518,9 +1101,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_tail_kernel(TailArgs A) {
         --b;
     }
     if (b == 0) {
-        // amplitude totals + the chunk-power edge cases: the body of amp_finalize_kernel; a part of a split capture
+        // amplitude totals; a part of a split capture
         // reports its first hit (made global with own_sample0) and the tail of its tile, the tile sums travel as they are
-        power_edge_cases(A.power, (size_t)A.nchunks, (size_t)A.own_bytes, (size_t)A.chunk_bytes, A.flags);
         const long long first = amp_block_first(A.tiles, (size_t)A.own_tiles, &first_s);
         if (first == 0x7fffffffffffffffll) {
             if (tid == 0) {
@@ -1626,7 +1208,7 @@ static int scan_begin_impl(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size
     st.off_blk = st.off_acc + align_up(st.nchunks * 16, 256);
     // triangulateTDOA.py:39 speaks of the whole capture; a part must itself hold at least one window
     const size_t total_samples = part ? part->total_samples : st.nsamples;
-    st.valid = total_samples >= (size_t)noise_samples + (size_t)window && st.nsamples >= (size_t)window;
+    st.valid = d_onset && total_samples >= (size_t)noise_samples + (size_t)window && st.nsamples >= (size_t)window;
     // K4's noise sum: a buffer that starts with the span gets it from the scan's own block sums (tail kernel); a part
     // that does not hold the span brings a copy (d_noise), summed by one extra workgroup of the scan launch
     st.noise_bytes = (size_t)2 * noise_samples;
@@ -1645,7 +1227,8 @@ static int scan_begin_impl(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size
     st.off_rec = align_up(st.off_blk + (nblk + 16) * sizeof(unsigned), 256);
     {
         const size_t nout = st.valid ? st.nsamples - (size_t)window + 1 : 0;
-        const size_t nct = st.valid ? ((nout + 511) / 512 + kTailBlocks - 1) / kTailBlocks : 1;
+        // nobody asked for the onset (K3 alone): no onset workgroups at all
+        const size_t nct = st.valid ? ((nout + 511) / 512 + kTailBlocks - 1) / kTailBlocks : (d_onset ? 1 : 0);
         if (nct > 0x7ffffff0ull) return fail(ctx, GJ_ERR_UNSUPPORTED, "capture too long");
         st.nct = (unsigned)nct;
     }
@@ -1711,6 +1294,14 @@ int scan_end(gj_ctx* ctx, const ScanJob& job, const ScanExtra* extra) {
                            ctx->stream, acc, st.nchunks, st.own_bytes, st.chunk_bytes, st.eps, st.flags, st.d_power, ctx->off2, true);
         GJ_LAUNCH_CHECK(ctx);
     }
+    {
+        float edge;
+        if (st.d_power && power_edge_value(st.nchunks, st.own_bytes, st.chunk_bytes, st.flags, &edge)) {
+            unsigned bits;
+            memcpy(&bits, &edge, 4);
+            GJ_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(st.d_power + (st.nchunks - 1)), (int)bits, 1, ctx->stream));
+        }
+    }
     TailArgs A;
     memset(&A, 0, sizeof(A));
     A.iq = st.d_iq;
@@ -1731,13 +1322,10 @@ int scan_end(gj_ctx* ctx, const ScanJob& job, const ScanExtra* extra) {
     A.own_iq = st.d_iq + halo;
     A.own_samples = st.own_samples;
     A.own_tiles = st.own_tiles;
-    A.own_bytes = st.own_bytes;
-    A.chunk_bytes = st.chunk_bytes;
     A.tiles = tiles;
     A.amp = st.d_amp;
     A.amp_part = st.part.d_amp;
     A.own_sample0 = A.sample0 + (long long)(halo / 2);
-    A.flags = st.flags;
     A.window = st.window;
     A.noise_samples = st.noise_samples;
     A.noise_in_scratch = st.valid && !st.noise_here;
@@ -1788,13 +1376,61 @@ static int stream_scan_impl(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, siz
     return rc;
 }
 
+// K3 and / or K4 WITHOUT a power map (gj_amp_stats_dev, gj_onset_dev, their *_u8 forms, and captures whose chunk size the
+// fused pass does not take): the same pass and the same tail -- neither quantity depends on the chunk size, so the pass
+// runs with one-tile chunks and its power map lands in the workspace; an output nobody asked for (d_amp or d_onset
+// == nullptr) gets no role in the tail (onset) or a scratch record (amplitude: the pass produces the tile sums anyway).
+// Same tiles, same integer window sums, same fixed summation orders => the bits of gj_capture_scan_dev.  Until round 6
+// these entry points ran chains of their own (amp_tiles -> amp_finalize; onset_noise -> onset_coarse<8> -> onset_scan ->
+// onset_finalize: 0.62 ms per GiB for ONE onset against 0.23 ms for the whole fused scan + tail).
+// A capture that is not 16-byte aligned (a caller's pointer into the middle of a buffer: resident captures, staging
+// areas and parts are all aligned) is first copied to an aligned place in the workspace -- one device-to-device copy,
+// still faster than the byte-wise kernels it replaces, and the results no longer depend on the alignment.
+int launch_amp_onset(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, float rssi_threshold, gj_amp_stats* d_amp,
+                     int noise_samples, int window, float factor, gj_onset* d_onset) {
+    if (!d_amp && !d_onset) return GJ_OK;
+    if (!d_onset) { noise_samples = 1; window = 1; factor = 1.f; }
+    if (!d_amp) rssi_threshold = -1.0f;                  // every sample a hit: the pass need not track the first
+    const bool aligned = (reinterpret_cast<uintptr_t>(d_iq) & 15) == 0;
+    ScanJob job;
+    int rc = scan_begin_impl(ctx, d_iq, nbytes, kScanTile, 0.f, 0, nullptr, rssi_threshold, d_amp, noise_samples, window, factor,
+                             d_onset, nullptr, job);
+    if (rc) return rc;
+    const size_t off_power = job.ws_bytes;
+    const size_t off_amp = off_power + align_up((job.nchunks + 1) * sizeof(float), 256);
+    const size_t off_copy = off_amp + 256;
+    rc = ensure_workspace(ctx, off_copy + (aligned ? 0 : align_up(nbytes, 256)));
+    if (rc) return rc;
+    if (!aligned && nbytes) {
+        GJ_HIP(ctx, hipMemcpyAsync(ctx->ws + off_copy, d_iq, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+        d_iq = ctx->ws + off_copy;
+    }
+    rc = scan_begin_impl(ctx, d_iq, nbytes, kScanTile, 0.f, 0, reinterpret_cast<float*>(ctx->ws + off_power), rssi_threshold,
+                         d_amp ? d_amp : reinterpret_cast<gj_amp_stats*>(ctx->ws + off_amp), noise_samples, window, factor, d_onset,
+                         nullptr, job);
+    if (rc) return rc;
+    job.ws = ctx->ws;
+    rc = scan_start(ctx, job);
+    if (!rc) rc = scan_range(ctx, job, 0, job.ntiles);
+    if (!rc) rc = scan_end(ctx, job, nullptr);
+    return rc;
+}
+
+int launch_amp_stats(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, float threshold, gj_amp_stats* d_out) {
+    return launch_amp_onset(ctx, d_iq, nbytes, threshold, d_out, 0, 0, 0.f, nullptr);
+}
+
+int launch_onset(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, int noise_samples, int window, float factor,
+                 gj_onset* d_out) {
+    return launch_amp_onset(ctx, d_iq, nbytes, 0.f, nullptr, noise_samples, window, factor, d_out);
+}
+
 int launch_stream_scan(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t chunk_bytes, float eps, int flags,
                        float* d_power, float rssi_threshold, gj_amp_stats* d_amp, int noise_samples, int window,
                        float factor, gj_onset* d_onset, const ScanExtra* extra) {
-    if (!scan_fusable(d_iq, nbytes, chunk_bytes)) {   // odd chunk sizes / unaligned captures: the separate passes
+    if (!scan_fusable(d_iq, nbytes, chunk_bytes)) {   // odd chunk sizes / unaligned captures: K1 alone, then the pass for K3 + K4
         int rc = launch_chunk_power(ctx, d_iq, nbytes, chunk_bytes, eps, flags, d_power);
-        if (!rc) rc = launch_amp_stats(ctx, d_iq, nbytes, rssi_threshold, d_amp);
-        if (!rc) rc = launch_onset(ctx, d_iq, nbytes, noise_samples, window, factor, d_onset);
+        if (!rc) rc = launch_amp_onset(ctx, d_iq, nbytes, rssi_threshold, d_amp, noise_samples, window, factor, d_onset);
         if (!rc && extra && extra->d_stats && gj_chunk_count(nbytes, chunk_bytes))
             rc = launch_power_threshold(ctx, d_power, gj_chunk_count(nbytes, chunk_bytes), extra->pct, extra->rise_db, extra->d_stats, extra->d_mask);
         if (!rc && extra && extra->d_slot)

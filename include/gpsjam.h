@@ -267,7 +267,11 @@ int gj_onset_u8(gj_ctx* ctx, const uint8_t* iq, size_t nbytes, int noise_samples
 /* K1 + K3 + K4 in ONE pass over the capture (the three are pure streaming reductions over
  * the same bytes): identical results to gj_chunk_power_dev, gj_amp_stats_dev and gj_onset_dev
  * called one after the other.  The single pass is used when chunk_bytes is a multiple of
- * 65536 and the capture is 16-byte aligned; otherwise the three passes run back to back. */
+ * 65536 and the capture is 16-byte aligned; otherwise K1 runs alone and the pass delivers K3 + K4.
+ * gj_amp_stats_dev and gj_onset_dev are themselves this pass (with the outputs nobody asked for
+ * dropped): neither depends on the chunk size, so a capture gives the same K3 / K4 bits through
+ * every entry point.  A capture that is not 16-byte aligned is first copied into the workspace
+ * (one device-to-device copy; any alignment is accepted). */
 int gj_stream_scan_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes,
                        size_t chunk_bytes, float eps, int flags, float* d_power,
                        float rssi_threshold, gj_amp_stats* d_amp,

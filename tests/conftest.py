@@ -29,7 +29,7 @@ SUITE_ORDER = [
     "test_gpu_random_sweep.py", "test_large_capture_gpu.py",
     # 2 -- next rows, later additions
     "test_acq_gpu.py", "test_local_gpu.py", "test_round2_gpu.py", "test_round3_gpu.py", "test_round4_gpu.py",
-    "test_round5_gpu.py",
+    "test_round5_gpu.py", "test_round6_gpu.py",
     # 3 -- several ranks' work in one process
     "test_sharded_gpu.py", "test_sharded_world8_gpu.py", "test_split_gpu.py", "test_split_random_gpu.py",
     # 4 -- child processes (launchers, two ranks on one GPU)

@@ -13,6 +13,7 @@ import pytest
 import gpsjam
 from gpsjam.synth import StreamSpec, generate
 from oracle import gpsjam_oracle as orc
+import exact_restatement as ex
 import golden_inputs as gi
 
 pytestmark = pytest.mark.gpu
@@ -405,6 +406,11 @@ def test_stream_scan_equals_separate_kernels(dev, nbytes, chunk, thr):
         np.testing.assert_allclose(out["fused"][1]["m"], avg, rtol=1e-6)
     z = orc.tdoa_unpack(even)
     assert out["fused"][2] == orc.tdoa_onset(z)
+    # the integer-exact restatement of the header's contract (tests/exact_restatement.py), independent of either entry point
+    assert out["fused"][2] == ex.onset(raw)["start"]
+    want = ex.amp_stats(raw, thr)
+    assert (out["fused"][1]["i"], out["fused"][1]["c"]) == (want["first"], want["count"])
+    np.testing.assert_allclose(out["fused"][1]["s"], want["sum"], rtol=2e-7)
 
 
 @pytest.mark.parametrize("tail_bytes,back", [(40000 + 346, 2500), (13 * 1024 + 712, 6000), (65536 - 1024 + 40, 3100),

@@ -15,6 +15,7 @@ import gpsjam
 from gpsjam import _ffi
 from gpsjam.synth import StreamSpec, generate
 from oracle import gpsjam_oracle as orc
+import exact_restatement as ex
 
 pytestmark = pytest.mark.gpu
 
@@ -80,16 +81,16 @@ def _separate(dev, raw, thr=0.0, chunk=65536, slice_samples=50000, noise=NOISE, 
     return out
 
 
-def _same(got, want, what, amp_exact=False):
+def _same(got, want, what, amp_exact=True):
     np.testing.assert_array_equal(got[0], want[0], err_msg=f"{what}: power map")
     if want[0].size:
         np.testing.assert_array_equal(got[1], want[1], err_msg=f"{what}: baseline / threshold / count")
         np.testing.assert_array_equal(got[2], want[2], err_msg=f"{what}: mask")
     a, b = np.frombuffer(got[3], _AMP)[0], np.frombuffer(want[3], _AMP)[0]
     assert (a["i"], a["c"]) == (b["i"], b["c"]), what
-    if amp_exact:
+    if amp_exact:                                       # since round 6 K3 alone IS the pass: same tiles, same order, same bits
         assert got[3] == want[3], what
-    else:                                               # K3 alone groups its float32 partial sums differently
+    else:
         np.testing.assert_allclose(a["s"], b["s"], rtol=1e-7)
     for f in ("start", "noise", "thr", "hit", "guard"):  # margin_before is a bound (gpsjam.h): checked on its own
         assert got[4][f] == want[4][f], (what, f, got[4], want[4])
@@ -118,6 +119,15 @@ def test_capture_scan_equals_the_separate_entry_points(dev, nbytes, chunk, thr, 
         big = 1 << 19 if nbytes > 10_000_000 else 140_000
         _same(_fused(dev, raw, thr, chunk, slice_samples=big), _separate(dev, raw, thr, chunk, slice_samples=big), f"{nbytes} bytes, long slice")
     even = raw[:2 * (nbytes // 2)]
+    # ... and what the header promises, restated with exact integers on the CPU (since round 6 the "separate" entry points
+    # are the same pass: two entry points agreeing with each other proves nothing on its own)
+    np.testing.assert_array_equal(got[0], ex.chunk_power(raw, chunk))
+    want_on = ex.onset(raw, NOISE, WINDOW, FACTOR)
+    for f in ("start", "guard", "noise", "thr", "hit"):
+        assert got[4][f] == want_on[f], (f, got[4], want_on)
+    want_amp, a = ex.amp_stats(raw, thr), np.frombuffer(got[3], _AMP)[0]
+    assert (a["i"], a["c"]) == (want_amp["first"], want_amp["count"])
+    np.testing.assert_allclose(a["s"], want_amp["sum"], rtol=2e-7)
     if nbytes <= 3_000_000:
         assert got[4]["start"] == orc.tdoa_onset(orc.tdoa_unpack(even))
         k, avg = orc.rssi_amp_stats(even, thr)
