@@ -143,7 +143,8 @@ int gj_create(int device_id, gj_ctx** out) {
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(GJ_ERR_HIP);
     ctx->stream = ctx->own_stream;
-    if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) return bail(GJ_ERR_HIP);
+    if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_switch, hipEventDisableTiming) != hipSuccess) return bail(GJ_ERR_HIP);
     // constant tables: W_4096^m, periodic Hann windows
     const size_t tables = align_up(kTwiddleTable * sizeof(cf) + kWindowFloats * sizeof(float) + 256, 256);
     const size_t bytes = tables + kSyncWords * sizeof(unsigned);   // the arrival counters start out (and stay) zero
@@ -180,6 +181,7 @@ int gj_destroy(gj_ctx* ctx) {
     if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->ev_switch) (void)hipEventDestroy(ctx->ev_switch);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->mu_ready) (void)pthread_mutex_destroy(&ctx->mu);
     delete ctx;
@@ -232,10 +234,26 @@ int gj_debug_counters(gj_ctx* ctx, int* lanes, int* lanes_busy, int* lanes_recla
     return GJ_OK;
 }
 
+// The new stream is ordered behind everything the context has queued on the old one (an event on the old stream, a wait
+// on the new): a context's kernels hand results between workgroups through arrival counters that are per CONTEXT
+// (ctx->d_sync), and its workspace is one arena -- two launches of one context must never be in flight on two streams
+// at once.  A stream that is being captured into a graph is left alone (recording into a capture from
+// outside it would end the capture): the pipelines switch streams at construction, before any capture.
 int gj_set_stream(gj_ctx* ctx, void* hip_stream, int external) {
     if (!ctx) return GJ_ERR_INVALID;
     Guard g(ctx);
-    ctx->stream = external ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    const hipStream_t to = external ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    if (to != ctx->stream && ctx->ev_switch) {
+        hipStreamCaptureStatus a = hipStreamCaptureStatusNone, b = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(ctx->stream, &a) == hipSuccess && hipStreamIsCapturing(to, &b) == hipSuccess &&
+            a == hipStreamCaptureStatusNone && b == hipStreamCaptureStatusNone) {
+            if (hipEventRecord(ctx->ev_switch, ctx->stream) != hipSuccess || hipStreamWaitEvent(to, ctx->ev_switch, 0) != hipSuccess)
+                return fail(ctx, GJ_ERR_HIP, "ordering the new stream behind the old one failed");
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    ctx->stream = to;
     return GJ_OK;
 }
 
@@ -253,8 +271,7 @@ int gj_set_unpack(gj_ctx* ctx, double offset, double scale) {
 int gj_set_fill_threads(gj_ctx* ctx, int n) {
     if (!ctx) return GJ_ERR_INVALID;
     if (n < 0 || n > 16) return fail(ctx, GJ_ERR_INVALID, "fill threads %d (0 = by capture size, 1..16)", n);
-    Guard g(ctx);
-    ctx->fill_threads = n;
+    ctx->fill_threads.store(n, std::memory_order_relaxed);
     return GJ_OK;
 }
 
@@ -427,9 +444,15 @@ int gj_welch_timed_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t c
     if (!ctx) return GJ_ERR_INVALID;
     if (!kernel_ms || !finalize_ms || (nbytes && (!d_iq || !d_psd))) return fail(ctx, GJ_ERR_INVALID, "null buffer");
     *kernel_ms = *finalize_ms = 0.f;
-    hipEvent_t mid = nullptr;
+    // events of the call's own: the context-wide pair belongs to gj_timer_*, and a second thread re-recording it between
+    // this call's lock section and its wait would time something else
+    hipEvent_t ev0 = nullptr, mid = nullptr, ev1 = nullptr;
     (void)hipSetDevice(ctx->device);
-    GJ_HIP(ctx, hipEventCreate(&mid));
+    if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&mid) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) {
+        for (hipEvent_t e : {ev0, mid, ev1})
+            if (e) (void)hipEventDestroy(e);
+        return fail(ctx, GJ_ERR_HIP, "hipEventCreate failed");
+    }
     int rc = GJ_OK;
     bool ran = false;
     {
@@ -440,20 +463,20 @@ int gj_welch_timed_dev(gj_ctx* ctx, const uint8_t* d_iq, size_t nbytes, size_t c
         if (!rc && job.rows) {
             rc = ensure_workspace(ctx, job.ws_bytes);
             job.partial = reinterpret_cast<float*>(ctx->ws);
-            if (!rc && hipEventRecord(ctx->ev_start, ctx->stream) != hipSuccess) rc = fail(ctx, GJ_ERR_HIP, "event");
+            if (!rc && hipEventRecord(ev0, ctx->stream) != hipSuccess) rc = fail(ctx, GJ_ERR_HIP, "event");
             if (!rc) rc = welch_range(ctx, job, d_iq, 0, job.rows);
             if (!rc && hipEventRecord(mid, ctx->stream) != hipSuccess) rc = fail(ctx, GJ_ERR_HIP, "event");
             if (!rc) rc = welch_end(ctx, job, flags, d_psd, d_psd_db);
-            if (!rc && hipEventRecord(ctx->ev_stop, ctx->stream) != hipSuccess) rc = fail(ctx, GJ_ERR_HIP, "event");
+            if (!rc && hipEventRecord(ev1, ctx->stream) != hipSuccess) rc = fail(ctx, GJ_ERR_HIP, "event");
             ran = !rc;
         }
     }
-    if (ran) rc = wait_event(ctx, ctx->ev_stop);
+    if (ran) rc = wait_event(ctx, ev1);
     if (ran && !rc) {
-        if (hipEventElapsedTime(kernel_ms, ctx->ev_start, mid) != hipSuccess || hipEventElapsedTime(finalize_ms, mid, ctx->ev_stop) != hipSuccess)
+        if (hipEventElapsedTime(kernel_ms, ev0, mid) != hipSuccess || hipEventElapsedTime(finalize_ms, mid, ev1) != hipSuccess)
             rc = fail(ctx, GJ_ERR_HIP, "hipEventElapsedTime failed");
     }
-    (void)hipEventDestroy(mid);
+    for (hipEvent_t e : {ev0, mid, ev1}) (void)hipEventDestroy(e);
     reap_retired(ctx);
     return rc;
 }

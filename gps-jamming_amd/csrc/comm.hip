@@ -105,8 +105,16 @@ void comm_detach_all(gj_ctx* ctx) {
         mine.swap(ctx->comms);
         for (gj_comm* c : mine) c->ctx = nullptr;
     }
+    for (gj_comm* c : mine) comm_quiesce(ctx, c);
+    // The calls in flight have returned -- but a collective that another thread enqueued a moment ago may still be
+    // QUEUED on the context's stream (gj_destroy synchronised before it came here; the hammering thread of
+    // tests/hip_stub kept going until the detach above).  RCCL's handle must outlive its queued work: drain the
+    // streams once more, with no lock held, before the communicators go (round 6, found under ASan with the stand-in).
+    if (!mine.empty()) {
+        if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+        if (ctx->stream != ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
+    }
     for (gj_comm* c : mine) {
-        comm_quiesce(ctx, c);
         ncclComm_t h = nullptr;
         {
             std::lock_guard<std::mutex> l(comm_mu());

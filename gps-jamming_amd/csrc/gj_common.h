@@ -4,6 +4,7 @@
 
 #include <pthread.h>
 
+#include <atomic>
 #include <cerrno>
 #include <cstdarg>
 #include <cstdio>
@@ -63,6 +64,7 @@ struct gj_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // gj_timer_*
+    hipEvent_t ev_switch = nullptr;                     // gj_set_stream: orders the new stream behind the old one
     // Robust + recursive: held only while work is ENQUEUED (never across a host wait, a file read or a staged
     // copy); if its owner dies inside a critical section the next locker gets EOWNERDEAD and carries on.
     pthread_mutex_t mu;
@@ -79,7 +81,7 @@ struct gj_ctx {
     std::vector<gj_lane*> lanes;
     std::vector<gj_comm*> comms;   // communicators created on this context (gj_destroy takes them down)
     int lanes_reclaimed = 0;
-    int fill_threads = 0;          // gj_set_fill_threads: 0 = by capture size
+    std::atomic<int> fill_threads{0};   // gj_set_fill_threads: 0 = by capture size.  Read once per staged copy, without the lock
     int inject_owner_alive = 0;    // gj_debug_inject: the next probes of a busy lane skip the owner check ("alive")
     // unpack convention (gj_set_unpack): sample = (u8 - offset) * scale; off2 = 2 * offset is an integer
     int off2 = 255;

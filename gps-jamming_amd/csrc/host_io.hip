@@ -288,21 +288,31 @@ int fill_threads_env() {
     }();
     return n;
 }
-int fill_threads(const gj_ctx* ctx, size_t nbytes) {
-    if (const int fixed = fill_threads_env()) return fixed;
-    if (ctx->fill_threads > 0) return ctx->fill_threads < kMaxFillThreads ? ctx->fill_threads : kMaxFillThreads;   // gj_set_fill_threads
-    size_t t = nbytes / (8u << 20);       // one thread per 8 MiB: four for a 10-s capture
-    if (t < 2) t = 2;
-    if (t > 8) t = 8;
-    return (int)t;
-}
-
-// Piece size of a staged copy of `nbytes`: about four pieces per fill thread, whole MiB, at most 16 MiB (reached from
-// 512 MiB up with eight threads: the GiB-class figures of profiles/r0*_ingest*.txt were measured with it).
-size_t piece_bytes(const gj_ctx* ctx, size_t nbytes) {
-    size_t p = align_up(nbytes / (4 * (size_t)fill_threads(ctx, nbytes)) + 1, kMinPiece);
-    if (p > kPinBytes) p = kPinBytes;
-    return p;
+// The shape of ONE staged copy -- fill threads, piece size, piece count -- decided once, at the start of the call, and
+// handed down.  Until round 6 every user re-derived it from ctx->fill_threads, which gj_set_fill_threads (and
+// gj_ingest_files, temporarily) could change in between: an ingest then sized its piece events for one piece count and
+// copied with another (ThreadSanitizer, tests/hip_stub: heap-use-after-free in staged_copy).
+//   `override_threads` > 0: this call's own setting (gj_ingest_files lowers it per file), else the context's, else by size.
+// Piece size: about four pieces per fill thread, whole MiB, at most 16 MiB (reached from 512 MiB up with eight threads:
+// the GiB-class figures of profiles/r0*_ingest*.txt were measured with it).
+struct CopyShape {
+    int nthreads = 1;
+    size_t piece_len = kMinPiece, npieces = 0;
+};
+CopyShape copy_shape(const gj_ctx* ctx, size_t nbytes, int override_threads = 0) {
+    int t = fill_threads_env();
+    if (!t) t = override_threads > 0 ? override_threads : ctx->fill_threads.load(std::memory_order_relaxed);   // gj_set_fill_threads
+    if (t <= 0) {
+        size_t by_size = nbytes / (8u << 20);       // one thread per 8 MiB: four for a 10-s capture
+        t = by_size < 2 ? 2 : (by_size > 8 ? 8 : (int)by_size);
+    }
+    if (t > kMaxFillThreads) t = kMaxFillThreads;
+    CopyShape c;
+    c.piece_len = align_up(nbytes / (4 * (size_t)t) + 1, kMinPiece);
+    if (c.piece_len > kPinBytes) c.piece_len = kPinBytes;
+    c.npieces = (nbytes + c.piece_len - 1) / c.piece_len;
+    c.nthreads = (int)(c.npieces < (size_t)t ? (c.npieces ? c.npieces : 1) : (size_t)t);
+    return c;
 }
 
 // the lane's bounce buffer k with room for `bytes` (grow-only; the lane's previous call has left its buffers)
@@ -332,12 +342,11 @@ struct NoMeanwhile {
     void operator()() const {}
 };
 template <typename Fill, typename Meanwhile = NoMeanwhile>
-int staged_copy(gj_ctx* ctx, gj_lane* L, hipStream_t stream, unsigned char* d_dst, size_t nbytes, Fill&& fill,
+int staged_copy(gj_ctx* ctx, gj_lane* L, hipStream_t stream, unsigned char* d_dst, size_t nbytes, const CopyShape& shape, Fill&& fill,
                 PieceSink* sink = nullptr, hipEvent_t* piece_events = nullptr, Meanwhile&& meanwhile = Meanwhile()) {
     if (nbytes == 0) return GJ_OK;
-    const size_t piece_len = piece_bytes(ctx, nbytes);
-    const size_t npieces = (nbytes + piece_len - 1) / piece_len;
-    const int nthreads = (int)(npieces < (size_t)fill_threads(ctx, nbytes) ? npieces : (size_t)fill_threads(ctx, nbytes));
+    const size_t piece_len = shape.piece_len, npieces = shape.npieces;
+    const int nthreads = shape.nthreads;
     for (int k = 0; k < 2 * nthreads; ++k) {   // two bounce buffers per fill thread, made (or grown) on first use
         const int prc = lane_pin(ctx, L, k, piece_len);
         if (prc) return prc;
@@ -369,11 +378,18 @@ int staged_copy(gj_ctx* ctx, gj_lane* L, hipStream_t stream, unsigned char* d_ds
         if (failed.load() && sink) sink->failed();   // the dispatcher must not wait for pieces that will never come
     };
     std::vector<std::thread> pool;
-    for (int t = sink ? 0 : 1; t < nthreads; ++t) pool.emplace_back(worker, t);
+    int started = sink ? 0 : 1;            // the calling thread is worker 0 unless it dispatches
+    try {
+        pool.reserve((size_t)nthreads);
+        for (; started < nthreads; ++started) pool.emplace_back(worker, started);
+    } catch (...) {                        // no more threads to be had (EAGAIN under a process limit): never out of an extern "C" call
+        failed.store(1);
+        if (sink) sink->failed();
+    }
     if (sink) {
         if (failed.load()) sink->failed();
         meanwhile();
-    } else {
+    } else if (!failed.load()) {
         worker(0);
     }
     for (auto& th : pool) th.join();
@@ -388,7 +404,7 @@ int copy_in(gj_ctx* ctx, gj_lane* L, hipStream_t s, unsigned char* d_dst, const 
         GJ_HIP(ctx, hipMemcpyAsync(d_dst, host, nbytes, hipMemcpyHostToDevice, s));
         return GJ_OK;
     }
-    return staged_copy(ctx, L, s, d_dst, nbytes, [host](unsigned char* dst, size_t off, size_t len) {
+    return staged_copy(ctx, L, s, d_dst, nbytes, copy_shape(ctx, nbytes), [host](unsigned char* dst, size_t off, size_t len) {
         memcpy(dst, host + off, len);
         return true;
     });
@@ -549,14 +565,14 @@ int gj_upload_file(gj_ctx* ctx, const char* path, size_t offset, size_t max_byte
     } else if (m != MAP_FAILED) {
         (void)madvise(m, nbytes + lead, MADV_SEQUENTIAL);
         const unsigned char* src = static_cast<const unsigned char*>(m) + lead;
-        rc = staged_copy(ctx, L, s, static_cast<unsigned char*>(p), nbytes, [src](unsigned char* dst, size_t off, size_t len) {
+        rc = staged_copy(ctx, L, s, static_cast<unsigned char*>(p), nbytes, copy_shape(ctx, nbytes), [src](unsigned char* dst, size_t off, size_t len) {
             memcpy(dst, src + off, len);
             return true;
         });
         (void)munmap(m, nbytes + lead);
     } else {
         (void)posix_fadvise(fd, 0, 0, POSIX_FADV_NOREUSE);   // regular file systems (Linux >= 6.3): no LRU promotion on read
-        rc = staged_copy(ctx, L, s, static_cast<unsigned char*>(p), nbytes, [fd, offset](unsigned char* dst, size_t off, size_t len) {
+        rc = staged_copy(ctx, L, s, static_cast<unsigned char*>(p), nbytes, copy_shape(ctx, nbytes), [fd, offset](unsigned char* dst, size_t off, size_t len) {
             size_t done = 0;
             while (done < len) {
                 const ssize_t k = pread(fd, dst + done, len - done, (off_t)(offset + off + done));
@@ -627,7 +643,7 @@ int lane_ingest_resources(gj_ctx* ctx, gj_lane* L, size_t npieces, size_t ws_byt
 
 template <typename Fill>
 int ingest_impl(gj_ctx* ctx, size_t nbytes, Fill&& fill, const gj_ingest_plan& plan, float* power, size_t power_cap, float* psd,
-                float* psd_db, size_t psd_cap_floats, gj_ingest_result* res, void** dptr) {
+                float* psd_db, size_t psd_cap_floats, gj_ingest_result* res, void** dptr, int fill_override = 0) {
     if (!res || !dptr) return fail(ctx, GJ_ERR_INVALID, "null argument");
     *dptr = nullptr;
     memset(res, 0, sizeof(*res));
@@ -685,8 +701,8 @@ int ingest_impl(gj_ctx* ctx, size_t nbytes, Fill&& fill, const gj_ingest_plan& p
         rc = welch_begin(ctx, nbytes, plan.chunk_samples, plan.nperseg, plan.fs, 0, wj);
         if (rc) return bail(rc);
     }
-    const size_t piece_len = piece_bytes(ctx, nbytes);
-    const size_t npieces = (nbytes + piece_len - 1) / piece_len;
+    const CopyShape shape = copy_shape(ctx, nbytes, fill_override);   // once: the piece events below and the copy must agree
+    const size_t piece_len = shape.piece_len, npieces = shape.npieces;
     const size_t ws_scan = fused ? sj.ws_bytes : 0;
     rc = lane_ingest_resources(ctx, L, npieces ? npieces : 1, ws_scan + (want_welch ? wj.ws_bytes : 0) + 256);
     if (rc) return bail(rc);
@@ -740,7 +756,7 @@ int ingest_impl(gj_ctx* ctx, size_t nbytes, Fill&& fill, const gj_ingest_plan& p
         IngestSink sink;
         sink.queued_flag = flags.data();
         int disp_rc = GJ_OK;
-        rc = staged_copy(ctx, L, L->copy_stream, d_cap, nbytes, fill, &sink, L->piece_ev, [&] {
+        rc = staged_copy(ctx, L, L->copy_stream, d_cap, nbytes, shape, fill, &sink, L->piece_ev, [&] {
             // dispatcher: the calling thread.  Holds no lock while it waits for a piece to be queued.
             for (size_t k = 0; k < npieces && !disp_rc; ++k) {
                 unsigned spins = 0;
@@ -818,8 +834,9 @@ int gj_ingest_u8(gj_ctx* ctx, const uint8_t* host, size_t nbytes, const gj_inges
     }, *plan, power, power_cap, psd, psd_db, psd_cap_floats, result, dptr);
 }
 
-int gj_ingest_file(gj_ctx* ctx, const char* path, size_t offset, size_t max_bytes, const gj_ingest_plan* plan, float* power,
-                   size_t power_cap, float* psd, float* psd_db, size_t psd_cap_floats, gj_ingest_result* result, void** dptr) {
+static int ingest_file_impl(gj_ctx* ctx, const char* path, size_t offset, size_t max_bytes, const gj_ingest_plan* plan, float* power,
+                            size_t power_cap, float* psd, float* psd_db, size_t psd_cap_floats, gj_ingest_result* result, void** dptr,
+                            int fill_override) {
     if (!ctx) return GJ_ERR_INVALID;
     if (!path || !plan) return fail(ctx, GJ_ERR_INVALID, "null argument");
     const int fd = open(path, O_RDONLY);
@@ -845,7 +862,7 @@ int gj_ingest_file(gj_ctx* ctx, const char* path, size_t offset, size_t max_byte
         rc = ingest_impl(ctx, nbytes, [src](unsigned char* dst, size_t off, size_t len) {
             memcpy(dst, src + off, len);
             return true;
-        }, *plan, power, power_cap, psd, psd_db, psd_cap_floats, result, dptr);
+        }, *plan, power, power_cap, psd, psd_db, psd_cap_floats, result, dptr, fill_override);
         (void)munmap(m, nbytes + lead);
     } else {
         (void)posix_fadvise(fd, 0, 0, POSIX_FADV_NOREUSE);
@@ -857,10 +874,15 @@ int gj_ingest_file(gj_ctx* ctx, const char* path, size_t offset, size_t max_byte
                 done += (size_t)k;
             }
             return true;
-        }, *plan, power, power_cap, psd, psd_db, psd_cap_floats, result, dptr);
+        }, *plan, power, power_cap, psd, psd_db, psd_cap_floats, result, dptr, fill_override);
     }
     close(fd);
     return rc;
+}
+
+int gj_ingest_file(gj_ctx* ctx, const char* path, size_t offset, size_t max_bytes, const gj_ingest_plan* plan, float* power,
+                   size_t power_cap, float* psd, float* psd_db, size_t psd_cap_floats, gj_ingest_result* result, void** dptr) {
+    return ingest_file_impl(ctx, path, offset, max_bytes, plan, power, power_cap, psd, psd_db, psd_cap_floats, result, dptr, 0);
 }
 
 // Several capture files at once: one host thread of the library's own per file (the caller's thread takes the first), a
@@ -877,27 +899,37 @@ int gj_ingest_files(gj_ctx* ctx, gj_ingest_job* jobs, int n_jobs, const gj_inges
         jobs[k].dptr = nullptr;
     }
     NoCancel nc;   // the joins below are cancellation points: a pending cancellation acts after the call
-    int old_fill = 0;
-    {
-        Guard g(ctx);
-        old_fill = ctx->fill_threads;
-        if (old_fill == 0 && n_jobs > 1) ctx->fill_threads = (8 / n_jobs) > 2 ? 8 / n_jobs : 2;
-    }
-    std::vector<std::string> msgs((size_t)n_jobs);
-    auto run = [&](int k) {
-        gj_ingest_job& j = jobs[k];
-        j.status = gj_ingest_file(ctx, j.path, j.offset, j.max_bytes, plan, j.power, j.power_cap, j.psd, j.psd_db, j.psd_cap_floats,
-                                  &j.result, &j.dptr);
-        if (j.status) msgs[(size_t)k] = last_error_buf();   // the message is per thread: bring it home
-    };
+    // fill threads per file for THIS call (the context's setting is left alone: two of these calls at once, or a
+    // gj_set_fill_threads meanwhile, used to end with the wrong value restored -- ADVICE r05)
+    const int fill_override = (ctx->fill_threads.load(std::memory_order_relaxed) == 0 && n_jobs > 1) ? ((8 / n_jobs) > 2 ? 8 / n_jobs : 2) : 0;
+    std::vector<std::string> msgs;
     std::vector<std::thread> pool;
-    for (int k = 1; k < n_jobs; ++k) pool.emplace_back(run, k);
-    run(0);
-    for (auto& t : pool) t.join();
-    {
-        Guard g(ctx);
-        ctx->fill_threads = old_fill;
+    std::atomic<int> next{0};
+    auto run_jobs = [&] {   // every thread takes the next file that nobody has started
+        for (int k = next.fetch_add(1); k < n_jobs; k = next.fetch_add(1)) {
+            gj_ingest_job& j = jobs[k];
+            j.status = ingest_file_impl(ctx, j.path, j.offset, j.max_bytes, plan, j.power, j.power_cap, j.psd, j.psd_db, j.psd_cap_floats,
+                                        &j.result, &j.dptr, fill_override);
+            if (j.status) msgs[(size_t)k] = last_error_buf();   // the message is per thread: bring it home
+        }
+    };
+    try {
+        msgs.resize((size_t)n_jobs);
+        // one thread per file, but never more than there are lanes: the rest would only spin in lane_checkout
+        const int extra = (n_jobs < kMaxLanes ? n_jobs : kMaxLanes) - 1;
+        pool.reserve((size_t)extra);
+        for (int k = 0; k < extra; ++k) pool.emplace_back(run_jobs);
+    } catch (...) {
+        // no memory / no more threads (EAGAIN under a process limit): the calling thread does what is left below;
+        // an exception must never leave an extern "C" entry point with joinable threads behind it (std::terminate)
     }
+    if (msgs.size() == (size_t)n_jobs) {
+        run_jobs();
+    } else {
+        for (int k = 0; k < n_jobs; ++k) jobs[k].status = GJ_ERR_NOMEM;
+    }
+    for (auto& t : pool) t.join();
+    if (msgs.size() != (size_t)n_jobs) return fail(ctx, GJ_ERR_NOMEM, "out of memory");
     for (int k = 0; k < n_jobs; ++k)
         if (jobs[k].status) return fail(ctx, jobs[k].status, "%s (file %d of %d: %s)", msgs[(size_t)k].c_str(), k, n_jobs, jobs[k].path);
     return GJ_OK;

@@ -57,9 +57,9 @@ struct Event {
 
 struct Stream {
     std::mutex m;
-    std::condition_variable cv_work, cv_idle;
+    std::condition_variable cv_work;
     std::deque<std::function<void()>> q;
-    bool stop = false, busy = false;
+    bool stop = false;
     std::thread th;
     Stream() : th([this] { run(); }) {}
     ~Stream() {
@@ -77,13 +77,10 @@ struct Stream {
             if (q.empty()) return;
             std::function<void()> f = std::move(q.front());
             q.pop_front();
-            busy = true;
             l.unlock();
             f();
             f = nullptr;
             l.lock();
-            busy = false;
-            if (q.empty()) cv_idle.notify_all();
         }
     }
     void push(std::function<void()> f) {
@@ -93,9 +90,12 @@ struct Stream {
         }
         cv_work.notify_one();
     }
+    // everything queued BEFORE this call has run (what hipStreamSynchronize promises): a marker goes in behind it and
+    // is waited for -- waiting for "queue empty" instead would never return beside a thread that keeps submitting
     void drain() {
-        std::unique_lock<std::mutex> l(m);
-        cv_idle.wait(l, [&] { return q.empty() && !busy; });
+        auto done = std::make_shared<Event>();
+        push([done] { done->complete(1); });
+        done->wait_for(1);
     }
 };
 
@@ -365,6 +365,11 @@ hipError_t hipStreamSynchronize(hipStream_t s) {
     auto st = rt().stream(s);
     if (!st) return err(hipErrorInvalidHandle);
     st->drain();
+    return hipSuccess;
+}
+hipError_t hipStreamIsCapturing(hipStream_t s, hipStreamCaptureStatus* st) {
+    if (!st || !rt().stream(s)) return err(hipErrorInvalidHandle);
+    *st = hipStreamCaptureStatusNone;   // the stand-in has no graphs
     return hipSuccess;
 }
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {

@@ -345,6 +345,7 @@ static int scenario_comm() {
         b.join();
     }
     CHECK(bad.load() == 0);
+    fprintf(stderr, "comm (a) two ranks: done\n");
     // (b) a collective that is INSIDE its RCCL call when gj_comm_destroy (variant 0) or gj_destroy of its context
     //     (variant 1) arrives: the stand-in holds the call at a gate, the destroyer must wait for it (in_flight), and the
     //     call must return GJ_OK on a communicator that is still alive
@@ -363,6 +364,7 @@ static int scenario_comm() {
             void *d_a = nullptr, *d_b = nullptr;
             OK(gj_malloc(ctx, 1024, &d_a));
             OK(gj_malloc(ctx, 1024, &d_b));
+            fprintf(stderr, "comm (b) variant %d rep %d\n", variant, rep);
             gate(1);
             std::atomic<int> rc_call{-99}, rc_destroy{-99};
             std::thread caller_t([&] { rc_call.store(rep & 1 ? gj_comm_gather_dev(c, d_a, 1024, d_b, 0) : gj_comm_allgather_dev(c, d_a, 1024, d_b)); });
@@ -391,6 +393,7 @@ static int scenario_comm() {
     // (c) gj_destroy of the context while another thread keeps STARTING collectives on its communicator (allowed: the
     //     handle outlives the context); the hammer is told to stop by the GJ_ERR_INVALID of the detached communicator
     for (int rep = 0; rep < 8; ++rep) {
+        fprintf(stderr, "comm (c) rep %d\n", rep);
         OK(gj_comm_unique_id(id));
         gj_ctx* ctx = nullptr;
         gj_comm* c = nullptr;
@@ -426,14 +429,24 @@ static int scenario_comm() {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// 5. killed callers: threads that end INSIDE the library at its wait sites (a raw exit system call: no unwinding,
-//    exactly what a hard kill leaves behind; tests/c_abandoned_caller.c does the same on the GPU), while other threads
-//    keep calling; the lanes come back through the sweep of a later check-out or of gj_debug_counters -- unlocked
-//    by the sweeping thread that took them over (lane_owner_take -> lane_recover -> lane_checkin)
+// 5. abandoned callers: threads that leave the library at one of its wait sites WITHOUT unwinding and then end -- the
+//    lane's owner token and (site 5) the context mutex still locked, the lane still marked busy: the state a killed
+//    caller leaves behind (tests/c_abandoned_caller.c produces it on the GPU with a raw exit system call; the
+//    sanitizer runtimes keep per-thread state that a raw exit corrupts -- ASan aborts in asan_thread.cpp -- so here
+//    the thread longjmps out of the hook to its start function and returns: no destructor runs, the kernel finds the
+//    robust mutexes held at thread exit exactly as after a kill).  Other threads keep calling; the lanes come back
+//    through the sweep of a later check-out or of gj_debug_counters -- unlocked by the sweeping thread that took them
+//    over (lane_owner_take -> lane_recover -> lane_checkin).
+//    SAN_LANES_PAUSE=1 (the ThreadSanitizer run): the live callers pause while a doomed thread dies and is joined.
+//    TSan models a mutex hand-over by its unlock; a dead owner never unlocks, so what it wrote to its lane looks
+//    unordered to the thread that inherits the mutex with EOWNERDEAD -- the kernel orders it (the robust list is walked
+//    at thread exit, before the futex wake), TSan cannot know.  With the pause the order also runs through the join.
 // ------------------------------------------------------------------------------------------------------------------
+#include <csetjmp>
 static thread_local int doomed_site = 0;
+static thread_local jmp_buf doomed_jb;
 static void dying_hook(void*, int site) {
-    if (doomed_site && site == doomed_site) syscall(SYS_exit, 0);
+    if (doomed_site && site == doomed_site) longjmp(doomed_jb, 1);
 }
 
 static int scenario_lanes() {
@@ -442,13 +455,19 @@ static int scenario_lanes() {
     OK(gj_debug_set_wait_hook(ctx, dying_hook, nullptr));
     const size_t big = 8u << 20;
     std::vector<uint8_t> cap = make_capture(big, 11);
-    std::atomic<int> bad{0}, stop{0};
+    std::atomic<int> bad{0}, stop{0}, pause{0}, paused{0};
+    const bool pausing = getenv("SAN_LANES_PAUSE") != nullptr;
     // live callers beside the dying ones
     std::vector<std::thread> live;
     for (int t = 0; t < 3; ++t)
         live.emplace_back([&, t] {
             std::vector<float> power(256);
             while (!stop.load()) {
+                if (pause.load()) {
+                    paused.fetch_add(1);
+                    while (pause.load()) usleep(50);
+                    paused.fetch_sub(1);
+                }
                 size_t n = 0;
                 float ms = 0.f;
                 if (gj_chunk_power_u8(ctx, cap.data(), (size_t)(1u << 20) + 2 * (size_t)t, 65536, 0.f, 0, power.data(), power.size(), &n, &ms) != GJ_OK) bad.fetch_add(1);
@@ -465,6 +484,7 @@ static int scenario_lanes() {
     auto doomed = [](void* p) -> void* {
         Doomed* d = static_cast<Doomed*>(p);
         doomed_site = d->site;
+        if (setjmp(doomed_jb)) return nullptr;    // came out of the hook: end the thread with everything still held
         if (d->site == 3) {                       // inside a staged upload, before its fill threads start
             void* dev = nullptr;
             (void)gj_upload(d->ctx, d->cap, d->big, &dev);
@@ -483,9 +503,14 @@ static int scenario_lanes() {
         Doomed d{ctx, cap.data(), big, sites[k % 3]};
         pthread_t t;
         void* ret = nullptr;
+        if (pausing) {
+            pause.store(1);
+            while (paused.load() < 3) usleep(50);
+        }
         CHECK(pthread_create(&t, nullptr, doomed, &d) == 0);
         CHECK(pthread_join(t, &ret) == 0);
         CHECK(ret != (void*)1);
+        pause.store(0);
         if (k % 6 == 5) OK(gj_debug_inject(ctx, GJ_INJECT_OWNER_ALIVE, 1));   // one probe answers "alive": the lane comes back a sweep later
     }
     stop.store(1);
