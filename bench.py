@@ -139,6 +139,19 @@ def main():
                     help="self-launched ranks that fail are NOT followed by one fresh --rendezvous-only run")
     ap.add_argument("--fail-rank", type=int, default=-1,
                     help="diagnostic (tests): this rank exits with status 3 once the process group has formed")
+    ap.add_argument("--no-probe", action="store_true",
+                    help="N > 1 over nccl: make RCCL the default group at once instead of probing it first in a child process per rank")
+    ap.add_argument("--inject-probe-failure", action="store_true",
+                    help="diagnostic (tests): the RCCL probe children exit with status 3, as if RCCL could not form a group")
+    ap.add_argument("--probe-fail", action="store_true", help=argparse.SUPPRESS)       # what --inject-probe-failure hands the child
+    ap.add_argument("--probe-bytes", type=int, default=0,
+                    help="--rendezvous-only: also all-gather this many bytes per rank over the group (the slot exchange's size)")
+    ap.add_argument("--probe-timeout", type=float, default=150.0, help="seconds one RCCL probe child may take")
+    ap.add_argument("--groups-only", action="store_true",
+                    help="diagnostic: form the process groups exactly as a run would (control group, RCCL probe, data group or "
+                         "fallback), all-gather one small row over the data group, print what carried it, and stop -- runs without a GPU")
+    ap.add_argument("--fallback-of", default=None,
+                    help="set by the launcher when this run replaces one whose RCCL group could not form: goes into the line")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -164,31 +177,24 @@ def main():
         local_rank = 0
     if args.rendezvous_only:
         raise SystemExit(rendezvous_only(args, torch, world, rank, local_rank))
-    torch.cuda.set_device(local_rank)
-    dist = None
     grouped = world > 1 or args.force_exchange     # a process group exists (of one, with --force-exchange)
     if args.force_exchange and world == 1 and "MASTER_ADDR" not in os.environ:
         import socket
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
-    if grouped:
-        import torch.distributed as dist
-        import datetime
-        limit = datetime.timedelta(seconds=300)   # a collective that never completes must end the run, not hang it
-        if args.backend == "nccl":
-            # one node: RCCL's bootstrap needs no outside interface (the container's hostname may not resolve) and
-            # there is no InfiniBand to probe; the data path is xGMI peer-to-peer either way
-            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-            os.environ.setdefault("NCCL_IB_DISABLE", "1")
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
-        else:
-            dist.init_process_group(backend=args.backend, timeout=limit)
+    # the groups are formed BEFORE this process touches the GPU: the RCCL probe runs in child processes (form_groups)
+    G = form_groups(args, torch, world, rank, local_rank) if grouped else Groups()
+    dist = G.dist
+    if args.groups_only:
+        raise SystemExit(groups_only(args, torch, G, world, rank))
+    torch.cuda.set_device(local_rank)
 
     if grouped and args.fail_rank == rank:
         print(f"[bench] rank {rank}: --fail-rank, leaving with status 3", file=sys.stderr, flush=True)
         os._exit(3)
 
+    status = 0
     dev = gpsjam.Device(local_rank)
     # one explicit HIP stream for everything in the step: the gpsjam kernels, torch's small
     # packing ops and the events that time the dominant kernel
@@ -196,7 +202,7 @@ def main():
     torch.cuda.set_stream(work_stream)
     dev.set_stream(work_stream.cuda_stream)
     if args.split:
-        run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank)
+        run_split(args, np, torch, gpsjam, G, dev, work_stream, world, rank)
         if grouped:
             dist.barrier()
             dist.destroy_process_group()
@@ -231,7 +237,7 @@ def main():
                            rank=rank, world_size=world, overlap=not args.no_overlap, aux_slots=aux,
                            transport=args.transport, exchange_always=args.force_exchange and world == 1,
                            pairs=only_pairs if world == 1 else None, side_priority=args.side_priority,
-                           pack_on_side=args.pack_on_side)
+                           pack_on_side=args.pack_on_side, group=G.data)
     torch.cuda.synchronize()
 
     def barrier():
@@ -249,6 +255,9 @@ def main():
     torch.cuda.synchronize()
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # N > 1: events on the SECOND stream around the exchange chain of every step (slot, slot all-gather, K5, pack, result
+    # gather) -- what the first multi-GPU curve needs to be read rank by rank (per_rank below)
+    ex = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps if grouped else 0)]
     t0 = time.perf_counter()
     gathered = None
     for k in range(args.steps):
@@ -257,9 +266,14 @@ def main():
         ev[k][0].record()
         stream.welch()                  # K2
         ev[k][1].record()
+        if ex:
+            ex[k][0].record(stream._side)
         stream.tdoa()                   # slot, slot all-gather, this rank's share of the pairs (second stream)
         gathered = stream.exchange(0)   # pack (after the join) + result gather, issued on the second stream
+        if ex:
+            ex[k][1].record(stream._side)
     torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0     # this rank's own steps, before it waits for the others
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -283,6 +297,8 @@ def main():
     side = stream._side
     solo_ms = timed(stream.welch, work_stream)
     scan_ms = timed(stream.stream_scan, side)
+    d_on1 = torch.zeros(4, dtype=torch.int64, device="cuda")
+    onset_alone_ms = timed(lambda: stream.dev_side.onset_dev(cap, nbytes, 200000, 1000, 50.0, d_on1), side)
     k5_ms = None
     if rank == 0 and stream.pairs:
         scratch = [torch.empty_like(t) for t in (stream.lags, stream.peaks, stream.margins)]
@@ -329,12 +345,14 @@ def main():
             print(f"[bench] reference operating point skipped: {e!r}", file=sys.stderr)
             ref_point = None
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if grouped:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = G.reduce(torch, elapsed, "max")
     welch_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
-    proof = exchange_proof(args, torch, dist if grouped else None, dev, stream.comm, world, rank)
+    per_rank = None
+    if grouped:
+        exchange_ms = sum(a.elapsed_time(b) for a, b in ex) / max(len(ex), 1)
+        per_rank = G.per_rank(torch, world, {"k2_ms": welch_ms, "scan_ms": scan_ms, "exchange_ms": exchange_ms,
+                                             "step_ms": local_elapsed / max(args.steps, 1) * 1e3})
+    proof = exchange_proof(args, torch, G, dev, stream.comm, world, rank)
 
     # CPU baseline: every rank times the oracle on a prefix of ITS capture at the same moment
     cpu = None
@@ -345,9 +363,7 @@ def main():
         barrier()
         cpu = cpu_baseline(np, cap, chunks, stream, gathered if rank == 0 else None, world, ref_point if rank == 0 else None)
         if world > 1:
-            r = torch.tensor([cpu["value"]], dtype=torch.float64, device="cuda")
-            dist.all_reduce(r, op=dist.ReduceOp.SUM)
-            cpu["value"] = float(r.item())
+            cpu["value"] = G.reduce(torch, cpu["value"], "sum")
             cpu["cores"] = world
             cpu["sample"] = f"{world} processes at once, one per capture, each: " + cpu["sample"]
 
@@ -371,9 +387,10 @@ def main():
                                            f"{world} antennas solved, dealt over the ranks; result vectors gathered to rank 0)"),
                        "capture_bytes_per_gpu": nbytes, "nperseg": NPERSEG, "chunk_samples": CHUNK_SAMPLES,
                        "xcorr_slice": SLICE, "xcorr_antennas": stream.n_ant, "xcorr_pairs": len(tdoa.pairs),
-                       "streams": world, "sharding": "one capture per GPU", "backend": args.backend if world > 1 else None,
-                       "transport": args.transport if world > 1 else None},
+                       "streams": world, "sharding": "one capture per GPU", "backend": G.backend if world > 1 else None,
+                       "transport": (G.label if args.transport == "torch" else args.transport) if world > 1 else None},
             **proof,
+            **G.line_fields(),
             "forced_exchange": bool(args.force_exchange and world == 1),
             "emulated_world": int(args.emulate_world) if world == 1 else 0, "side_priority": args.side_priority,
             "roofline": {"bound": "hbm", "kernel": "welch_kernel<4096> + welch_finalize_kernel",
@@ -405,6 +422,11 @@ def main():
                                      proof=proof, world=world, share_gpu=args.share_gpu),
             "host": host_info(),
         }
+        line["secondary"]["gj_onset_dev alone (K4 through the fused pass + tail since round 6; its own kernel chain took 0.62 ms), solo"] = {
+            "bound": "hbm", "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": onset_alone_ms,
+            "achieved": (nbytes / 1e9) / (onset_alone_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (nbytes / 1e9) / (onset_alone_ms / 1e3) / HBM_PEAK_GBS,
+            "onset_equals_the_step's": bool(int(d_on1[0].item()) == results[0].onset)}
         if k5_ms is not None:
             # ingest 2N B per antenna + 32 L B per transform (four-step floor), A + P transforms
             L, P = 2 * SLICE, len(stream.pairs)
@@ -464,20 +486,27 @@ def main():
                               "K5 at N = 50 000 (triangulateTDOA.py:26), 3 pairs"] = dep
         if cpu is not None:
             line["cpu_baseline"] = cpu
+        if per_rank is not None:
+            line["per_rank"] = per_rank
         if world == 1 and not args.no_end_to_end:
             try:                        # a secondary figure must never cost the primary line
                 line["end_to_end"] = end_to_end(np, dev, cap, nbytes)
             except Exception as e:      # e.g. no room for the scratch copy of the capture
                 line["end_to_end"] = {"error": repr(e)}
         emit(line)
+        # a run that replaces one whose RCCL group could not form counts only when it is right and really had a GPU per rank
+        if G.fallback_of and not (line["self_check"]["passed"] and (line["distinct_devices"] == world or args.share_gpu)):
+            status = 1
     if grouped:
         dist.barrier()
         dist.destroy_process_group()
     stream.close()
     dev.close()
+    if rank == 0 and status:
+        raise SystemExit(status)
 
 
-def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
+def run_split(args, np, torch, gpsjam, G, dev, work_stream, world, rank):
     """--split: the SAME total work at every N (strong scaling) -- `antennas` captures laid end to end and cut into
     N runs of 2-s units, one run per GPU (gpsjam.split): every GPU scans and transforms its run, one all-gather
     carries the parts' TDOA slots, the antenna pairs are dealt over the ranks, one gather brings the part vectors to
@@ -485,6 +514,7 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
     bit-identical to the unsplit run (tests/test_split_gpu.py)."""
     from gpsjam import split
     from gpsjam.synth import StreamSpec
+    dist = G.dist
     nbytes, A = args.capture_bytes, args.antennas
     nsamp = nbytes // 2
     specs = [stream_spec(StreamSpec, a, nsamp) for a in range(A)]
@@ -505,11 +535,11 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
         # all ranks' part vectors; what the other ranks would send was computed here, once, before the timed region
         st = split.emulated_rank(dev, [nbytes] * A, make_buffer, make_noise, emulated, args.emulate_rank, nperseg=NPERSEG,
                                   chunk_samples=CHUNK_SAMPLES, slice_samples=SLICE, overlap=not args.no_overlap,
-                                  exchange_always=args.force_exchange, pack_on_side=not args.pack_on_main)
+                                  exchange_always=args.force_exchange, pack_on_side=not args.pack_on_main, group=G.data)
     else:
         st = split.SplitStreams(dev, [nbytes] * A, make_buffer, make_noise, rank=rank, world_size=world, nperseg=NPERSEG,
                                 chunk_samples=CHUNK_SAMPLES, slice_samples=SLICE, overlap=not args.no_overlap,
-                                exchange_always=args.force_exchange and world == 1, pack_on_side=not args.pack_on_main)
+                                exchange_always=args.force_exchange and world == 1, pack_on_side=not args.pack_on_main, group=G.data)
     torch.cuda.synchronize()
 
     def barrier():
@@ -522,6 +552,8 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
     barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ex = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps if world > 1 else 0)]
+    ex_end = getattr(st, "_comb", None) or st._side      # rank 0's combine runs on a third stream
     t0 = time.perf_counter()
     got = None
     for k in range(args.steps):
@@ -529,17 +561,26 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
         ev[k][0].record()
         st.welch()
         ev[k][1].record()
+        if ex:
+            ex[k][0].record(st._side)
         st.tdoa()
         got = st.exchange(0)
+        if ex:
+            ex[k][1].record(ex_end)
     torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = G.reduce(torch, elapsed, "max") if world > 1 else elapsed
     welch_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+    per_rank = None
+    if world > 1:
+        # the split's exchange starts on the second stream and ends on rank 0's combine stream: start-to-end as the host
+        # sees the two events (both complete by now), not a single-stream interval
+        exchange_ms = sum(max(a.elapsed_time(b), 0.0) for a, b in ex) / max(len(ex), 1)
+        per_rank = G.per_rank(torch, world, {"k2_ms": welch_ms, "scan_ms": float("nan"), "exchange_ms": exchange_ms,
+                                             "step_ms": local_elapsed / max(args.steps, 1) * 1e3})
     own = sum(p.own_bytes for p in st.mine)
     # the second stream's chain (scan, slots, [all-gather], K5, [gather], combine) against K2, one step in isolation:
     # does the chain end inside K2 or does it stick out?
@@ -570,7 +611,7 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
                          "of the combine (pack on the first stream, then [gather] + assemble / statistics / pack on the "
                          "second).  In steady state step k's combine and step k+1's front chain share the second stream "
                          "under step k+1's K2: hidden when their sum fits into K2"}
-    proof = exchange_proof(args, torch, dist if (world > 1 or args.force_exchange) else None, dev, None, world, rank)
+    proof = exchange_proof(args, torch, G, dev, None, world, rank)
     if emulated and args.emulate_rank != 0:
         # a rank that only sends: no results arrive here; its step time is what the rehearsal is after
         emit({"metric": "Msamples/s uint8 I/Q through PSD+TDOA xcorr", "value": float(nsamp) * A * args.steps / elapsed / 1e6,
@@ -608,8 +649,9 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
                           if emulated else ""),
                        "own_bytes_rank0": own, "pairs_rank0": [list(p) for p in st.pairs],
                        "parts": [[p.antenna, p.part, p.parts, p.first_byte, p.own_bytes, p.rank] for p in st.parts],
-                       "backend": args.backend if world > 1 else None},
+                       "backend": G.backend if world > 1 else None, "transport": G.label if world > 1 else None},
             **proof,
+            **G.line_fields(),
             "forced_exchange": bool(args.force_exchange and world == 1),
             "roofline": {"bound": "hbm", "kernel": "welch_kernel<4096> + welch_finalize_kernel over rank 0's parts",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -623,6 +665,8 @@ def run_split(args, np, torch, gpsjam, dist, dev, work_stream, world, rank):
         }
         if chain is not None:
             line["second_stream_chain"] = chain
+        if per_rank is not None:
+            line["per_rank"] = per_rank
         emit(line)
     st.close()
 
@@ -651,7 +695,7 @@ def torch_device_identity(torch, index):
     return "/".join(bits)
 
 
-def exchange_proof(args, torch, dist, dev, comm, world, rank):
+def exchange_proof(args, torch, G, dev, comm, world, rank):
     """What the line claims about the exchange, read from the LIVE communicators instead of the command line, and the
     physical device of every rank, all-gathered as bytes through the same collective path the step uses
     (torch.distributed all-gather, or gj_comm_allgather_dev with --transport rccl).  A collective: every rank calls it.
@@ -659,6 +703,7 @@ def exchange_proof(args, torch, dist, dev, comm, world, rank):
       devices      one record per rank: pid, host, PCI bus id and uuid of the gpsjam context's GPU, torch's view
       rehearsal    true when the ranks did not have a GPU each over RCCL (--share-gpu, gloo, --emulate-world)"""
     import socket
+    dist = G.dist
     text = (f"rank={rank} pid={os.getpid()} host={socket.gethostname()} {dev.identity()} "
             f"torch={torch_device_identity(torch, torch.cuda.current_device())}")
     raw = text.encode()[:ID_BYTES].ljust(ID_BYTES, b" ")
@@ -671,10 +716,10 @@ def exchange_proof(args, torch, dist, dev, comm, world, rank):
         live_rank, rccl_ranks, live_dev = comm.live()
         via = f"gj_comm_allgather_dev (ncclCommCount {rccl_ranks}, ncclCommUserRank {live_rank}, ncclCommCuDevice {live_dev})"
     elif dist is not None and dist.is_initialized():
-        n = dist.get_world_size()
+        n = dist.get_world_size(G.data)
         rows = torch.zeros((n, ID_BYTES), dtype=torch.uint8, device="cuda")
-        dist.all_gather_into_tensor(rows.view(-1), mine)
-        backend = dist.get_backend()
+        dist.all_gather_into_tensor(rows.view(-1), mine, group=G.data)       # the group that carried the step's exchange
+        backend = dist.get_backend(G.data)
         rccl_ranks = n if backend == "nccl" else 0
         via = f"torch.distributed.all_gather_into_tensor over {backend} (get_world_size {n})"
     else:
@@ -685,6 +730,151 @@ def exchange_proof(args, torch, dist, dev, comm, world, rank):
     rehearsal = bool(args.share_gpu or args.emulate_world or (world > 1 and rccl_ranks != world))
     return {"rccl_ranks": rccl_ranks, "ranks_seen": len(devices), "devices": devices, "distinct_devices": distinct,
             "rehearsal": rehearsal, "identity_exchanged_via": via}
+
+
+class Groups:
+    """The process groups of one run.  `dist`: torch.distributed or None (single process, no group); `data`: the group
+    that carries the step's exchange (None = the default group); `backend` / `label`: what that group is made of."""
+
+    def __init__(self, dist=None, data=None, backend=None, label=None, fallback_of=None, probe=None):
+        self.dist, self.data, self.backend, self.label, self.fallback_of, self.probe = dist, data, backend, label, fallback_of, probe
+
+    def _device(self):
+        return "cuda" if self.dist.get_backend() == "nccl" else "cpu"       # of the DEFAULT group: control traffic
+
+    def reduce(self, torch, value, op):
+        """max / sum of one number over the ranks (control traffic: the default group)."""
+        if self.dist is None:
+            return float(value)
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self._device())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def per_rank(self, torch, world, figures):
+        """One small all-gather after the timed region: every rank's own figures, so that the first N > 1 curve can be read
+        rank by rank (which rank's K2 was slow, whose exchange stuck out) and not only as the max over ranks."""
+        names = sorted(figures)
+        mine = torch.tensor([float(figures[k]) for k in names], dtype=torch.float64, device=self._device())
+        rows = torch.zeros(world * len(names), dtype=torch.float64, device=self._device())
+        self.dist.all_gather_into_tensor(rows, mine)
+        rows = rows.view(world, len(names)).cpu()
+        out = {}
+        for j, k in enumerate(names):
+            col = [float(v) for v in rows[:, j].tolist()]
+            good = [v for v in col if v == v]
+            out[k] = {"min": min(good) if good else None, "max": max(good) if good else None, "by_rank": [v if v == v else None for v in col]}
+        out["what"] = ("k2_ms: average K2 launch as run (HIP events on its stream); scan_ms: the fused scan + tail alone, after the "
+                       "timed region; exchange_ms: second-stream events around slot -> slot all-gather -> K5 -> pack -> result "
+                       "gather of every step; step_ms: the rank's own wall time per step before it waits for the others")
+        return out
+
+    def line_fields(self):
+        if self.dist is None:
+            return {}
+        out = {"exchange_backend": self.backend, "control_backend": self.dist.get_backend()}
+        if self.probe is not None:
+            out["rccl_probe"] = self.probe
+        if self.fallback_of:
+            out["fallback"] = True
+            out["fallback_of"] = self.fallback_of
+        return out
+
+
+def rccl_probe(args, dist, world, rank, local_rank):
+    """Can N ranks form an RCCL group on this node and move a slot-sized message through it?  Asked in CHILD processes,
+    one per rank, before this process has touched the GPU: a rendezvous over a port of its own, an all-reduce, an
+    all-gather of 1 MiB per rank (`--rendezvous-only --probe-bytes`).  A child that raises, aborts (RCCL's watchdog
+    ends a process whose collective timed out) or hangs past --probe-timeout costs the child, not the rank -- the
+    ranks then agree over the control group and carry on over gloo, so that the first N > 1 run on a node yields a
+    labelled line whatever RCCL does (VERDICT r05 "next" 2).  Returns (ok on every rank, text)."""
+    import socket
+    import subprocess
+    port = [0]
+    if rank == 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port[0] = sk.getsockname()[1]
+    dist.broadcast_object_list(port, src=0)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_") and k != "TORCH_NCCL_ASYNC_ERROR_HANDLING"}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]), RANK=str(rank), WORLD_SIZE=str(world),
+               LOCAL_RANK=str(0 if args.share_gpu else local_rank))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--rendezvous-only", "--backend", "nccl",
+           "--no-diagnosis", "--probe-bytes", str(1 << 20)]
+    if args.share_gpu:
+        cmd.append("--share-gpu")
+    if args.inject_probe_failure:
+        cmd.append("--probe-fail")
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.probe_timeout)
+        rc, tail = r.returncode, (r.stderr or "").strip().splitlines()[-3:]
+    except subprocess.TimeoutExpired:
+        rc, tail = 124, [f"no answer within {args.probe_timeout:.0f} s"]
+    mine = {"rank": rank, "status": rc, "seconds": round(time.perf_counter() - t0, 1), "said": " | ".join(tail)[-300:] if rc else ""}
+    rows = [None] * world
+    dist.all_gather_object(rows, mine)
+    bad = [r for r in rows if r["status"] != 0]
+    ok = not bad
+    text = ("every rank's child formed the group and all-gathered 1 MiB" if ok else
+            f"RCCL probe failed on rank(s) {[r['rank'] for r in bad]}: status {bad[0]['status']}: {bad[0]['said']}")
+    print(f"[bench] rank {rank}: RCCL probe {'ok' if ok else 'FAILED'} ({mine['seconds']} s): {text}", file=sys.stderr, flush=True)
+    return ok, text, {"ok": ok, "seconds_max": max(r["seconds"] for r in rows), "statuses": [r["status"] for r in rows]}
+
+
+def form_groups(args, torch, world, rank, local_rank):
+    """The run's process groups.  N > 1 over nccl: a gloo group first (control: barriers, votes, the figures gathered
+    after the timed region -- it cannot fail on RCCL's account), the RCCL probe in child processes, then the exchange
+    group: RCCL when the probe passed on every rank, otherwise the gloo group itself, labelled as a fallback.  Nothing
+    here touches the GPU in this process."""
+    import datetime
+    import torch.distributed as dist
+    limit = datetime.timedelta(seconds=300)   # a collective that never completes must end the run, not hang it
+    if args.backend == "nccl":
+        # one node: RCCL's bootstrap needs no outside interface (the container's hostname may not resolve) and
+        # there is no InfiniBand to probe; the data path is xGMI peer-to-peer either way
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
+    if args.backend != "nccl" or world == 1 or args.no_probe:
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
+        else:
+            dist.init_process_group(backend=args.backend, timeout=limit)
+        label = args.backend + (" (fallback)" if args.fallback_of else "")
+        return Groups(dist, None, args.backend, label, args.fallback_of)
+    dist.init_process_group(backend="gloo", timeout=limit)
+    ok, text, probe = rccl_probe(args, dist, world, rank, local_rank)
+    if not ok:
+        return Groups(dist, None, "gloo", "gloo (fallback)", text, probe)
+    torch.cuda.set_device(local_rank)
+    try:
+        data = dist.new_group(backend="nccl", timeout=limit, device_id=torch.device("cuda", local_rank))
+    except TypeError:                          # a torch whose new_group does not take device_id
+        data = dist.new_group(backend="nccl", timeout=limit)
+    return Groups(dist, data, "nccl", "nccl", None, probe)
+
+
+def groups_only(args, torch, G, world, rank):
+    """--groups-only: the groups a run would use, one small row all-gathered over the exchange group, and the verdict as
+    rank 0's line.  Needs no GPU when the exchange group is gloo (which is what a machine without one ends up with)."""
+    dist = G.dist
+    if dist is None:
+        emit({"groups": "single process", "world": 1})
+        return 0
+    on_gpu = G.backend == "nccl"
+    mine = torch.full((64,), rank, dtype=torch.uint8, device="cuda" if on_gpu else "cpu")
+    rows = torch.zeros(world * 64, dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(rows, mine, group=G.data)
+    ok = rows.view(world, 64)[:, 0].cpu().tolist() == list(range(world))
+    per_rank = G.per_rank(torch, world, {"k2_ms": 1.0 + rank, "scan_ms": 0.25, "exchange_ms": 0.5 * (rank + 1), "step_ms": 2.0})
+    backend = dist.get_backend(G.data)
+    if rank == 0:
+        emit({"groups": "ok" if ok else "wrong rows", "world": world, "transport": G.label,
+              "rccl_ranks": world if backend == "nccl" else 0, "per_rank": per_rank, **G.line_fields()})
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def run_ranks(n, argv, limit_s, stdout=None):
@@ -737,9 +927,15 @@ def launch_ranks(n, argv, limit_s, args=None):
     forms, the failure is in the step" are told apart without a second manual run.  The status returned is the first
     run's."""
     import subprocess
-    status, _ = run_ranks(n, argv, limit_s)
+    # rank 0's line is held back until the run's status is known: a failed first run must not leave a line in front of
+    # the fallback run's
+    status, out = run_ranks(n, argv, limit_s, stdout=subprocess.PIPE)
     if status == 0 or args is None or args.no_diagnosis:
+        sys.stdout.write(out or "")
+        sys.stdout.flush()
         return status
+    if out:
+        print("[bench] output of the failed run (not passed on):\n" + out, file=sys.stderr, flush=True)
     probe = ["--gpus", str(n), "--backend", args.backend, "--rendezvous-only", "--no-diagnosis"]
     if args.share_gpu:
         probe.append("--share-gpu")
@@ -756,13 +952,38 @@ def launch_ranks(n, argv, limit_s, args=None):
               + (f", said {line}" if line else ", no line from rank 0") + f"): {n} ranks cannot form a {args.backend} "
               f"group on this node -- look at the launcher / RCCL messages above before anything in the DSP path",
               file=sys.stderr, flush=True)
-    return status
+    if args.backend != "nccl" or args.rendezvous_only:
+        return status
+    # Second line of defence (the ranks probe RCCL themselves before they use it: rccl_probe): the run over nccl ended
+    # non-zero all the same.  ONE more fresh child, every rank on its own GPU, the exchange host-staged over gloo; its
+    # line says so (transport "gloo (fallback)", rccl_ranks 0, fallback_of) and its status is 0 only if its self_check
+    # passes with a GPU per rank.  The per-rank compute -- what the scaling target measures; the exchange is <= 1 MiB
+    # + 164 KB per rank -- does not need RCCL to be timed.
+    why = (f"the run over nccl ended with status {status}; rendezvous-only diagnosis: "
+           + ("the group forms" if (d_status == 0 and line) else f"the group cannot form (status {d_status})"))
+    again, skip = [], 0
+    for a in argv:                              # the same command line, --backend replaced
+        if skip:
+            skip -= 1
+        elif a == "--backend":
+            skip = 1
+        elif not a.startswith("--backend="):
+            again.append(a)
+    again += ["--backend", "gloo", "--fallback-of", why, "--no-diagnosis"]
+    print(f"[bench] fallback: one fresh run of {n} ranks over gloo ({why})", file=sys.stderr, flush=True)
+    f_status, f_out = run_ranks(n, again, limit_s, stdout=subprocess.PIPE)
+    sys.stdout.write(f_out or "")
+    sys.stdout.flush()
+    return 0 if f_status == 0 else status
 
 
 def rendezvous_only(args, torch, world, rank, local_rank):
     """Form the process group, all-reduce one number, rank 0 prints what it saw: separates "the ranks
     cannot find each other / RCCL cannot start" from anything the DSP path does."""
     import datetime
+    if args.probe_fail:                         # --inject-probe-failure: as if RCCL could not form the group
+        print(f"[bench] probe rank {rank}: --probe-fail, leaving with status 3", file=sys.stderr, flush=True)
+        return 3
     if world == 1:
         emit({"rendezvous": "single process", "world": 1})
         return 0
@@ -784,6 +1005,11 @@ def rendezvous_only(args, torch, world, rank, local_rank):
     dist.all_gather_into_tensor(rows.view(-1), mine)
     seats = [parse_identity(bytes(r.tolist()).decode(errors="replace")) for r in rows.cpu()]
     ok = ok and [d.get("rank") for d in seats] == list(range(world))
+    if args.probe_bytes > 0:                    # a message of the slot exchange's size through the group's data path
+        big = torch.full((args.probe_bytes,), rank % 251, dtype=torch.uint8, device=t.device)
+        got = torch.zeros(world * args.probe_bytes, dtype=torch.uint8, device=t.device)
+        dist.all_gather_into_tensor(got, big)
+        ok = ok and got.view(world, -1)[:, -1].cpu().tolist() == [r % 251 for r in range(world)]
     if rank == 0:
         emit({"rendezvous": "ok" if ok else "wrong sum", "world": dist.get_world_size(), "backend": dist.get_backend(),
               "sum": float(t.item()), "seats": seats})

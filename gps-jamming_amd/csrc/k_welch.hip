@@ -599,6 +599,19 @@ int launch_welch_batch(gj_ctx* ctx, const uint8_t* const* d_iq, int n_captures, 
     if (job.rows == 0) return GJ_OK;
     WelchPlan pl;
     memcpy(&pl, job.plan, sizeof(pl));
+    {
+        // Measurement only (tools/k2_batch_sweep.py, profiles/r06_k2_batch_sweep.txt): force the workgroups per chunk of a
+        // batched launch.  Round 6 tried planning the split over ALL the batch's chunks (three 10-s captures: 25 per chunk
+        // = 750 workgroups of 40 steps instead of 76 per chunk = 2 280 of 13): K2 alone 4 % faster (122 against 127 us),
+        // the deployment step it is part of 11 % SLOWER (0.231 against 0.206 ms, interleaved on one box) -- few long
+        // workgroups keep the scan / tail / K5 kernels of the side chains waiting for a slot, many short ones let them in.
+        // The per-capture plan stays, and with it the byte-equality of a PSD across every arrangement.
+        static const long forced = [] { const char* e = getenv("GPSJAM_W_BATCH_SPLITS"); return e ? atol(e) : 0l; }();
+        if (forced > 0 && forced <= 256 && (size_t)forced * 2 * (size_t)pl.batch <= pl.g.nseg_full) {
+            pl.g.splits = (unsigned)forced;
+            job.ws_bytes = pl.rows * (size_t)forced * (size_t)kBlockPoints * sizeof(float);
+        }
+    }
     if ((unsigned long long)n_captures * pl.g.nchunks * pl.g.splits > 0x7fffffffull || (unsigned long long)n_captures * pl.g.nchunks > 65535ull)
         return fail(ctx, GJ_ERR_UNSUPPORTED, "too many chunks for one launch");
     WelchBatch batch;

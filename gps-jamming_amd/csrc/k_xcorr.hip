@@ -14,9 +14,46 @@
 // Tie rule of numpy.argmax (first maximum in 'full' order m = lag + N-1) is kept.
 #include "gj_common.h"
 
+// ---- build-time experiment knobs (defaults = the shipped configuration; tools/ab_build.sh flips them) ----
+#ifndef GJ_XC_NT
+#define GJ_XC_NT 0        // 1: the spectra between the launches are stored / loaded non-temporally (each is used once): -2 % at 2^19-sample slices, +2.5 % at the reference's 50 000 (profiles/r06_k5_variants.txt): off
+#endif
+#ifndef GJ_XC_SWIZZLE
+#define GJ_XC_SWIZZLE 0   // 1: column tiles are dealt so that one XCD walks a contiguous range of columns: no effect (same file): off
+#endif
+
 namespace gj {
 
 constexpr int kRow = 4096;   // L2: contiguous row length
+
+// the spectra that travel between K5's launches (Y after the forward columns, D after the rows)
+__device__ __forceinline__ void xc_store(cf* p, c2 v) {
+#if GJ_XC_NT
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(f2{v.x, v.y}, reinterpret_cast<f2*>(p));
+#else
+    *p = to_cf(v);
+#endif
+}
+__device__ __forceinline__ c2 xc_load(const cf* p) {
+#if GJ_XC_NT
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 t = __builtin_nontemporal_load(reinterpret_cast<const f2*>(p));
+    return make_c2(t.x, t.y);
+#else
+    return to_c2(*p);
+#endif
+}
+// column tile of workgroup x out of `tiles` (a multiple of 8 for every L >= 2^16): workgroups are dealt round-robin over
+// the eight XCDs, so with the swizzle XCD k walks tiles [k tiles/8, (k+1) tiles/8) in order
+__device__ __forceinline__ unsigned xc_tile(unsigned x, unsigned tiles) {
+#if GJ_XC_SWIZZLE
+    return (tiles & 7u) ? x : (x & 7u) * (tiles >> 3) + (x >> 3);
+#else
+    (void)tiles;
+    return x;
+#endif
+}
 
 struct XcParams {
     int off2;   // unpack convention: 2 * offset (255)
@@ -112,7 +149,8 @@ __global__ __launch_bounds__(kBlockThreads) void xc_cols_kernel(XcParams P, cons
     const int tid = threadIdx.x;
     const int b = tid % B, jl = tid / B;
     const int t = blockIdx.y;   // antenna (MODE 0) or pair (MODE 1)
-    const int n2 = blockIdx.x * B + b;
+    const unsigned tile = xc_tile(blockIdx.x, gridDim.x);
+    const int n2 = (int)tile * B + b;
     c2 v[16];
     if constexpr (MODE == 0) {
         long long eff;
@@ -142,7 +180,7 @@ __global__ __launch_bounds__(kBlockThreads) void xc_cols_kernel(XcParams P, cons
     } else {
         const cf* src = buf + (size_t)t * P.L;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) v[s] = to_c2(src[(unsigned)(jl + TF * s) * (unsigned)kRow + (unsigned)n2]);
+        for (int s = 0; s < 16; ++s) v[s] = xc_load(src + (unsigned)(jl + TF * s) * (unsigned)kRow + (unsigned)n2);
     }
     xc_passes<L1, 0>(v, lds, b * RS, jl, twtab);
     if constexpr (MODE == 0) {
@@ -153,7 +191,7 @@ __global__ __launch_bounds__(kBlockThreads) void xc_cols_kernel(XcParams P, cons
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const unsigned k1 = (unsigned)(jl + TF * s);
-            dst[k1 * (unsigned)kRow + (unsigned)n2] = to_cf(cmul(v[s], w));
+            xc_store(dst + k1 * (unsigned)kRow + (unsigned)n2, cmul(v[s], w));
             w = cmul(w, step);
         }
     } else {
@@ -280,9 +318,9 @@ __global__ __launch_bounds__(kBlockThreads) void xc_rows_pair_kernel(XcParams P,
     const cf* sj = spec + (size_t)P.pair_j[p] * P.L + (size_t)r * N;
     c2 vi[16], vj[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) vi[s] = to_c2(si[jl + TF * s]);
+    for (int s = 0; s < 16; ++s) vi[s] = xc_load(si + jl + TF * s);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) vj[s] = to_c2(sj[jl + TF * s]);
+    for (int s = 0; s < 16; ++s) vj[s] = xc_load(sj + jl + TF * s);
     xc_passes<N, 0>(vi, lds, 0, jl, twtab);
     xc_passes<N, 0>(vj, lds, 0, jl, twtab);
 #pragma unroll
@@ -296,7 +334,7 @@ __global__ __launch_bounds__(kBlockThreads) void xc_rows_pair_kernel(XcParams P,
     const c2 step = twiddle_big(((unsigned long long)r * TF) & (P.L - 1), P.L);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        dst[jl + TF * s] = to_cf(cmul(vi[s], w));
+        xc_store(dst + jl + TF * s, cmul(vi[s], w));
         w = cmul(w, step);
     }
 }

@@ -130,7 +130,7 @@ GJ_MAX_ANTENNAS = 16
 GJ_LAG_INVALID = -(1 << 31)
 GJ_SLOT_HEADER = 16
 GJ_COMM_ID_BYTES = 128
-GJ_VERSION = 140
+GJ_VERSION = 150
 
 _vp, _sz, _i, _f, _d = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double
 _pf, _psz = C.POINTER(C.c_float), C.POINTER(C.c_size_t)

@@ -251,25 +251,26 @@ def slot_fields(slot: torch.Tensor, n_samples: int):
 
 
 def gather_rows(row: torch.Tensor, rank: int, world_size: int, dst: int = 0,
-                out: Optional[torch.Tensor] = None, always: bool = False) -> Optional[torch.Tensor]:
+                out: Optional[torch.Tensor] = None, always: bool = False, group=None) -> Optional[torch.Tensor]:
     """Every rank's ``row`` on ``dst`` as one [world, len] tensor (rows in rank order); None on the
     other ranks.  One collective (torch.distributed.gather: RCCL on HIP tensors, gloo on CPU).
     ``always``: issue the collective even in a group of one (tests / bench.py --force-exchange: the RCCL
-    call path on a single GPU)."""
+    call path on a single GPU).  ``group``: the process group that carries the data path (None = the default group):
+    bench.py keeps a gloo group for control and votes and gives the exchange an RCCL group of its own."""
     if world_size == 1 and not always:
         return row.unsqueeze(0)
     import torch.distributed as dist
     if rank == dst:
         if out is None:
             out = torch.empty((world_size, row.numel()), dtype=row.dtype, device=row.device)
-        dist.gather(row, gather_list=[out[r] for r in range(world_size)], dst=dst)
+        dist.gather(row, gather_list=[out[r] for r in range(world_size)], dst=dst, group=group)
         return out
-    dist.gather(row, gather_list=None, dst=dst)
+    dist.gather(row, gather_list=None, dst=dst, group=group)
     return None
 
 
 def allgather_rows(row: torch.Tensor, world_size: int, out: Optional[torch.Tensor] = None,
-                   always: bool = False) -> torch.Tensor:
+                   always: bool = False, group=None) -> torch.Tensor:
     """Every rank's ``row`` on EVERY rank as one [world, len] tensor: ONE collective straight into the
     contiguous receive buffer (all_gather_into_tensor = ncclAllGather on HIP tensors; the list form of
     all_gather flattens and copies out once more).  ``always``: as in ``gather_rows``."""
@@ -279,7 +280,7 @@ def allgather_rows(row: torch.Tensor, world_size: int, out: Optional[torch.Tenso
     if out is None:
         out = torch.empty((world_size, row.numel()), dtype=row.dtype, device=row.device)
     assert out.is_contiguous() and out.shape == (world_size, row.numel()) and out.dtype == row.dtype
-    dist.all_gather_into_tensor(out.view(-1), row.contiguous().view(-1))   # flat form: accepted by nccl and gloo alike
+    dist.all_gather_into_tensor(out.view(-1), row.contiguous().view(-1), group=group)   # flat form: accepted by nccl and gloo alike
     return out
 
 
@@ -370,9 +371,10 @@ class AntennaStream:
                  factor: float = 50.0, rssi_threshold: float = 0.0, rank: int = 0, world_size: int = 1,
                  overlap: Optional[bool] = None, aux_slots: Optional[torch.Tensor] = None,
                  transport="torch", side_device=None, exchange_always: bool = False, pairs=None,
-                 side_priority: int = 0, pack_on_side: bool = False):
+                 side_priority: int = 0, pack_on_side: bool = False, group=None):
         assert capture.dtype == torch.uint8 and capture.is_contiguous()
         self.dev, self.cap = dev, capture
+        self.group = group                 # torch.distributed group of the exchange (None: the default group)
         # K2 is bound by VALU issue and leaves ~90 % of the HBM bandwidth idle, the fused scan is HBM
         # bound: with ``overlap`` the scan, threshold and TDOA kernels run on a second HIP
         # stream (own gpsjam context = own workspace) concurrently with K2 and join in pack().
@@ -528,7 +530,7 @@ class AntennaStream:
                 if self.comm is not None:
                     self.comm.allgather(self.my_slot, self.slot_bytes, self.slots)
                 else:
-                    allgather_rows(self.my_slot, self.world, out=self.slots[:self.world], always=self._always)
+                    allgather_rows(self.my_slot, self.world, out=self.slots[:self.world], always=self._always, group=self.group)
             if self.pairs:
                 dev.xcorr_slots_dev(self.slots, self.slot_bytes, self.n_ant, self.slice_samples, self.pairs,
                                     self.lags, self.peaks, self.margins)
@@ -579,7 +581,7 @@ class AntennaStream:
                     rows = self._gathered[k]
                     self.comm.gather(vec, vec.numel() * vec.element_size(), rows if self.is_root else None, 0)
                 else:
-                    rows = gather_rows(vec, self.rank, self.world, 0, out=self._gathered[k], always=self._always)
+                    rows = gather_rows(vec, self.rank, self.world, 0, out=self._gathered[k], always=self._always, group=self.group)
                 if self._done[k] is not None:
                     self._done[k].record(self._side)
         if not self.is_root:

@@ -273,8 +273,9 @@ class SplitStreams:
                  chunk_bytes: int = 65536, chunk_samples: int = 2048000, nperseg: int = 4096, fs: float = 2.048e6,
                  slice_samples: int = 1 << 19, noise_samples: int = 200000, window: int = 1000, factor: float = 50.0,
                  rssi_threshold: float = 0.0, overlap: Optional[bool] = None, device=None, exchange_always: bool = False,
-                 emulate: bool = False, pack_on_side: bool = True):
+                 emulate: bool = False, pack_on_side: bool = True, group=None):
         self.dev, self.rank, self.world = dev, rank, world_size
+        self.group = group                 # torch.distributed group of the exchange (None: the default group)
         # one rank of a world_size-rank plan alone on its GPU: no collective, local copies into the world-size buffers
         self.emulate = bool(emulate)
         # a process group of one: still issue the slot all-gather and the part gather (the collective path on one GPU)
@@ -459,11 +460,11 @@ class SplitStreams:
                 # issued as well, so that the RCCL call sits in the chain where N ranks have it
                 src = self.my_slots
                 if self._always:
-                    src = allgather_rows(self.my_slots.view(-1), 1, out=self._one_slots, always=True).view(self.pmax, -1)
+                    src = allgather_rows(self.my_slots.view(-1), 1, out=self._one_slots, always=True, group=self.group).view(self.pmax, -1)
                 self.all_slots[self.rank * self.pmax:(self.rank + 1) * self.pmax].copy_(src)
                 slots = self.all_slots
             elif self.world > 1 or self._always:
-                allgather_rows(self.my_slots.view(-1), self.world, out=self.all_slots.view(self.world, -1), always=self._always)
+                allgather_rows(self.my_slots.view(-1), self.world, out=self.all_slots.view(self.world, -1), always=self._always, group=self.group)
                 slots = self.all_slots
             else:
                 slots = self.my_slots
@@ -517,12 +518,12 @@ class SplitStreams:
             if self.emulate:
                 src = vec.view(-1)
                 if self._always:
-                    src = gather_rows(vec.view(-1), 0, 1, 0, out=self._one_vec, always=True)[0]
+                    src = gather_rows(vec.view(-1), 0, 1, 0, out=self._one_vec, always=True, group=self.group)[0]
                 rows = self._gathered[k]
                 if rows is not None:
                     rows[self.rank].copy_(src)
             elif self.world > 1 or self._always:
-                rows = gather_rows(vec.view(-1), self.rank, self.world, 0, out=self._gathered[k], always=self._always)
+                rows = gather_rows(vec.view(-1), self.rank, self.world, 0, out=self._gathered[k], always=self._always, group=self.group)
             else:
                 rows = vec.view(1, -1)
             if self.is_root:

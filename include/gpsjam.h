@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GJ_VERSION 140 /* 0.1.4: lane ownership by robust mutex (gj_debug_inject), gj_probe_busy_dev (was gj_debug_busy_dev), the scan's tail in one launch (gj_capture_scan_dev), K2 / packing of several captures in one launch (gj_welch_batch_dev, gj_pack_results_dev), gj_ingest_files, gj_set_fill_threads */
+#define GJ_VERSION 150 /* 0.1.5: no new entry points.  gj_amp_stats_* / gj_onset_* run the fused pass + tail (any alignment accepted; same bits as gj_capture_scan_dev); gj_set_stream orders the new stream behind the old one; gj_ingest_files leaves the context's fill-thread setting alone */
 
 typedef struct gj_ctx gj_ctx;
 

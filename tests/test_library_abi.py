@@ -25,7 +25,7 @@ def header_symbols():
 def test_library_exists_and_loads():
     assert os.path.exists(_ffi.LIB_PATH), "build with __graft_entry__.build()"
     lib = _ffi.load()
-    assert lib.gj_version() == _ffi.GJ_VERSION == 140
+    assert lib.gj_version() == _ffi.GJ_VERSION == 150
 
 
 def test_every_declared_symbol_is_exported_and_bound():

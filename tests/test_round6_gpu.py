@@ -150,3 +150,4 @@ def test_tail_threshold_with_a_rule_decided_last_chunk(dev, nbytes, chunk, flags
             b.free()
     for b in (buf, d_st2, d_mask2):
         b.free()
+
