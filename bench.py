@@ -412,7 +412,7 @@ def main():
                     "bound": "hbm", "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": scan_ms,
                     "achieved": (nbytes / 1e9) / (scan_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (nbytes / 1e9) / (scan_ms / 1e3) / HBM_PEAK_GBS,
-                    **family_traffic("profiles/r05_pmc_scan/summary.json", nbytes)},
+                    **family_traffic("profiles/r06_pmc_scan/summary.json", nbytes)},
             },
             "results": {"pairs": [list(p) for p in tdoa.pairs], "lags": tdoa.lags,
                         "lag_margins": [round(m, 4) for m in tdoa.margins], "onsets": onsets,
@@ -436,7 +436,7 @@ def main():
                 "bound": "hbm", "algorithmic_bytes_per_launch": k5_bytes, "avg_launch_ms": k5_ms,
                 "achieved": (k5_bytes / 1e9) / (k5_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (k5_bytes / 1e9) / (k5_ms / 1e3) / HBM_PEAK_GBS,
-                **family_traffic("profiles/r05_pmc_xcorr/summary.json", nbytes),
+                **family_traffic("profiles/r06_pmc_xcorr/summary.json", nbytes),
                 "note": "PMC: about half of the four-step floor reaches HBM -- the spectra are written through "
                         "(50 MB) and about a third of the reads miss L2 / Infinity Cache (56 MB)"}
         if acq_ms is not None:
@@ -470,7 +470,7 @@ def main():
                 return {"kernel_ms_avg": sum(ks) / len(ks), "kernel_ms_min": min(ks), "finalize_ms_avg": sum(fs_) / len(fs_),
                         "kernel_plus_finalize_ms_avg": (sum(ks) + sum(fs_)) / len(ks)}
             a4096, a1024 = ab_of(NPERSEG), ab_of(REF_NPERSEG)
-            v4096, v1024 = pmc_valu("profiles/r05_pmc_welch/summary.json"), pmc_valu("profiles/r05_pmc_welch1024/summary.json")
+            v4096, v1024 = pmc_valu("profiles/r06_pmc_welch/summary.json"), pmc_valu("profiles/r06_pmc_welch1024/summary.json")
             line["secondary"]["K2 at nperseg 4096 and 1024, interleaved A/B on this box, kernel and finalize apart"] = {
                 "what": "six rounds of (4096, 1024) back to back on one stream with nothing else in flight; HIP events around "
                         "welch_kernel<N> and around welch_finalize_kernel (gj_welch_timed_dev)",
@@ -1082,7 +1082,7 @@ def pmc_summary(nbytes):
     so the figures are the recorded ones, offered only for the capture size they were measured on, and
     flagged when the kernel sources have changed since."""
     out = {"traffic": None, "valu_insts": None, "source": "no PMC summary found", "matches_build": None}
-    for rel in ("profiles/r05_pmc_welch/summary.json", "profiles/r04_pmc_welch/summary.json", "profiles/r03_pmc_welch/summary.json"):
+    for rel in ("profiles/r06_pmc_welch/summary.json", "profiles/r05_pmc_welch/summary.json", "profiles/r04_pmc_welch/summary.json"):
         try:
             with open(os.path.join(REPO, rel)) as f:
                 js = json.load(f)
@@ -1179,7 +1179,7 @@ def welch_ref_traffic(nbytes):
     (tools/pmc_welch.sh <dir> 1024 + tools/pmc_summarize.py), stamped like the 4096-point one."""
     out = {"traffic": None, "traffic_unit": "HBM bytes per launch", "traffic_source": "no PMC summary found",
            "traffic_measured_on_this_source": None}
-    rel = "profiles/r05_pmc_welch1024/summary.json"
+    rel = "profiles/r06_pmc_welch1024/summary.json"
     try:
         with open(os.path.join(REPO, rel)) as f:
             js = json.load(f)
