@@ -423,11 +423,35 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
         }
         if constexpr (HS) { ws_prv = ws_cur; ws_cur = (ws_cur == 2) ? 0 : ws_cur + 1; }
     }
-    float* out = partial + ((size_t)wg * B + b) * N + jl;
+    if constexpr (B == 1) {
+        float* out = partial + (size_t)wg * N + jl;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        if constexpr (Cfg::pkacc) out[TF * s] = accp[s].x + accp[s].y;
-        else out[TF * s] = accs[s];
+        for (int s = 0; s < 16; ++s) {
+            if constexpr (Cfg::pkacc) out[TF * s] = accp[s].x + accp[s].y;
+            else out[TF * s] = accs[s];
+        }
+    } else {
+        // N < 4096: the workgroup's B transform groups each hold a spectrum.  They are added HERE, in group order, through
+        // the exchange buffer (its last use is behind every group: all of them run the same number of steps), and the
+        // workgroup writes ONE partial row (round 6).  Until then it wrote B rows: at nperseg 1024 four times the partial
+        // traffic of the 4096 kernel per sample and four times the rows for the finalize to add -- 304 per chunk on the
+        // reference's 10-s captures, a 12-us finalize behind a 160-us K2 (profiles/r06_deployment_timeline_graph.txt).
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lds0);
+        static_assert((size_t)SPAN * sizeof(cf) >= (size_t)kBlockPoints * sizeof(float), "the exchange buffer holds one spectrum per group");
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if constexpr (Cfg::pkacc) red[b * N + jl + TF * s] = accp[s].x + accp[s].y;
+            else red[b * N + jl + TF * s] = accs[s];
+        }
+        __syncthreads();
+        float* out = partial + (size_t)wg * N;
+        for (int k = tid; k < N; k += kBlockThreads) {
+            float t = red[k];
+#pragma unroll
+            for (int bb = 1; bb < B; ++bb) t += red[bb * N + k];
+            out[k] = t;
+        }
     }
 }
 
@@ -558,7 +582,7 @@ static bool welch_plan(gj_ctx* ctx, size_t nbytes, size_t chunk_samples, int npe
         if (cost < best * 0.999) { best = cost; want = sp; }
     }
     pl.g.splits = (unsigned)want;
-    pl.ws_bytes = pl.rows * want * (size_t)kBlockPoints * sizeof(float);
+    pl.ws_bytes = pl.rows * want * (size_t)nperseg * sizeof(float);   // one partial row per workgroup
     const double sw2 = 0.375 * nperseg;   // sum of the squared periodic Hann window
     const double norm2 = unpack_norm2(ctx);   // the kernel works on 2u - off2 = sample * (2 / scale): 65025 by default
     pl.scale_full = 1.0 / (fs * sw2 * norm2 * (double)pl.g.nseg_full);
@@ -609,7 +633,7 @@ int launch_welch_batch(gj_ctx* ctx, const uint8_t* const* d_iq, int n_captures, 
         static const long forced = [] { const char* e = getenv("GPSJAM_W_BATCH_SPLITS"); return e ? atol(e) : 0l; }();
         if (forced > 0 && forced <= 256 && (size_t)forced * 2 * (size_t)pl.batch <= pl.g.nseg_full) {
             pl.g.splits = (unsigned)forced;
-            job.ws_bytes = pl.rows * (size_t)forced * (size_t)kBlockPoints * sizeof(float);
+            job.ws_bytes = pl.rows * (size_t)forced * (size_t)nperseg * sizeof(float);
         }
     }
     if ((unsigned long long)n_captures * pl.g.nchunks * pl.g.splits > 0x7fffffffull || (unsigned long long)n_captures * pl.g.nchunks > 65535ull)
@@ -643,7 +667,7 @@ int launch_welch_batch(gj_ctx* ctx, const uint8_t* const* d_iq, int n_captures, 
     }
     GJ_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(welch_finalize_kernel, dim3((nperseg / 4 + 63) / 64, n * pl.g.nchunks), dim3(256), 0, ctx->stream, partial,
-                       nperseg, pl.g.splits * (unsigned)pl.batch, n * pl.g.nchunks, (float)pl.scale_full, (float)pl.scale_last,
+                       nperseg, pl.g.splits, n * pl.g.nchunks, (float)pl.scale_full, (float)pl.scale_last,
                        (flags & GJ_WELCH_SHIFT) ? 1 : 0, (float*)nullptr, (float*)nullptr, outs);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
@@ -699,11 +723,11 @@ int welch_end(gj_ctx* ctx, const WelchJob& job, int flags, float* d_psd, float* 
     const bool aligned = ((reinterpret_cast<uintptr_t>(d_psd) | reinterpret_cast<uintptr_t>(d_psd_db)) & 15) == 0;
     if (aligned)
         hipLaunchKernelGGL(welch_finalize_kernel, dim3((nperseg / 4 + 63) / 64, pl.g.nchunks), dim3(256), 0, ctx->stream,
-                           partial, nperseg, pl.g.splits * (unsigned)pl.batch, pl.g.nchunks, (float)pl.scale_full,
+                           partial, nperseg, pl.g.splits, pl.g.nchunks, (float)pl.scale_full,
                            (float)pl.scale_last, (flags & GJ_WELCH_SHIFT) ? 1 : 0, d_psd, d_psd_db);
     else
         hipLaunchKernelGGL(welch_finalize_scalar_kernel, dim3((nperseg + 63) / 64, pl.g.nchunks), dim3(256), 0,
-                           ctx->stream, partial, nperseg, pl.g.splits * (unsigned)pl.batch, pl.g.nchunks,
+                           ctx->stream, partial, nperseg, pl.g.splits, pl.g.nchunks,
                            (float)pl.scale_full, (float)pl.scale_last, (flags & GJ_WELCH_SHIFT) ? 1 : 0, d_psd, d_psd_db);
     GJ_LAUNCH_CHECK(ctx);
     return GJ_OK;
