@@ -733,14 +733,6 @@ int gj_pack_results_dev(gj_ctx* ctx, const gj_combine_capture* captures, int n_c
     return launch_pack_results(ctx, captures, n_captures, nperseg, d_pairs, d_lags, d_peaks, d_margins);
 }
 
-int gj_pack_pair_values_dev(gj_ctx* ctx, int n_pairs, const int32_t* d_lags, const float* d_peaks, const float* d_margins, double* d_pair_block) {
-    GJ_ENTER(ctx);
-    if (n_pairs < 0 || n_pairs > 4096) return fail(ctx, GJ_ERR_INVALID, "bad n_pairs");
-    if (n_pairs == 0) return GJ_OK;
-    if (!d_lags || !d_peaks || !d_margins || !d_pair_block) return fail(ctx, GJ_ERR_INVALID, "null buffer");
-    return launch_pack_pair_values(ctx, n_pairs, d_lags, d_peaks, d_margins, d_pair_block);
-}
-
 // the host-side validation of gj_combine_plan_create alone: touches no GPU, needs no context
 int gj_combine_plan_check(const gj_combine_copy* copies, int n_copies, const gj_combine_capture* captures, int n_captures,
                           size_t rows_bytes, const void* d_arena, size_t arena_bytes, int nperseg, int have_pairs) {

@@ -399,7 +399,6 @@ int launch_welch(gj_ctx*, const uint8_t*, size_t, size_t, int, double, int, floa
 size_t welch_workspace(gj_ctx*, size_t, size_t, int, size_t plan_bytes = 0);
 int launch_welch_batch(gj_ctx*, const uint8_t* const*, int, size_t, size_t, int, double, int, float* const*);
 int launch_pack_results(gj_ctx*, const gj_combine_capture*, int, int, const int32_t*, const int32_t*, const float*, const float*);
-int launch_pack_pair_values(gj_ctx*, int, const int32_t*, const float*, const float*, double*);
 int launch_xcorr(gj_ctx*, const uint8_t* const*, const size_t*, int, const int64_t* const*, size_t,
                  const int32_t*, int, int32_t*, float*, float*);
 int launch_tdoa_slot(gj_ctx*, const uint8_t*, size_t, const int64_t*, size_t, uint8_t*, long long sample0 = 0, size_t total_samples = 0);

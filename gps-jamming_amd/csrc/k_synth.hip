@@ -137,9 +137,6 @@ __device__ __forceinline__ void pack_result_body(size_t n_chunks, const float* _
             const int pr = (int)(q / GJ_RESULT_PAIR_FIELDS), fld = (int)(q % GJ_RESULT_PAIR_FIELDS);
             dst = pair0 + q;
             if (pr < n_pairs) {
-                // lags == nullptr: the solve's results are written by gj_pack_pair_values_dev behind K5 (these three
-                // words are left alone), so that this kernel need not wait for K5
-                if (fld >= 2 && !lags) continue;
                 switch (fld) {
                     case 0: v = (double)pairs[2 * pr]; break;
                     case 1: v = (double)pairs[2 * pr + 1]; break;
@@ -322,23 +319,6 @@ __global__ __launch_bounds__(1024) void pack_result_multi_kernel(PackBatch B, in
                      c.n_pairs, c.pair_cap, pairs, lags, peaks, margins, c.d_out, part);
 }
 
-// lag, peak and margin of the solved pairs into the pair block of a result vector (fields 2..4 of every record)
-__global__ __launch_bounds__(64) void pack_pair_values_kernel(int n_pairs, const int* __restrict__ lags, const float* __restrict__ peaks,
-                                                              const float* __restrict__ margins, double* __restrict__ block) {
-    for (int p = threadIdx.x; p < n_pairs; p += 64) {
-        double* r = block + (size_t)GJ_RESULT_PAIR_FIELDS * p;
-        r[2] = (double)lags[p];
-        r[3] = peaks[p];
-        r[4] = margins[p];
-    }
-}
-
-int launch_pack_pair_values(gj_ctx* ctx, int n_pairs, const int32_t* d_lags, const float* d_peaks, const float* d_margins, double* d_block) {
-    hipLaunchKernelGGL(pack_pair_values_kernel, dim3(1), dim3(64), 0, ctx->stream, n_pairs, d_lags, d_peaks, d_margins, d_block);
-    GJ_LAUNCH_CHECK(ctx);
-    return GJ_OK;
-}
-
 int launch_pack_results(gj_ctx* ctx, const gj_combine_capture* caps, int n_caps, int nperseg, const int32_t* d_pairs,
                         const int32_t* d_lags, const float* d_peaks, const float* d_margins) {
     if (n_caps < 1 || n_caps > GJ_MAX_ANTENNAS) return fail(ctx, GJ_ERR_INVALID, "n_captures must be 1..%d", GJ_MAX_ANTENNAS);
@@ -351,8 +331,7 @@ int launch_pack_results(gj_ctx* ctx, const gj_combine_capture* caps, int n_caps,
         if (!c.d_power || !c.d_stats || !c.d_amp || !c.d_onset || !c.d_psd || !c.d_out)
             return fail(ctx, GJ_ERR_INVALID, "capture %d: null buffer", a);
         if (c.n_pairs < 0 || c.pair_cap < 0 || c.n_pairs > c.pair_cap) return fail(ctx, GJ_ERR_INVALID, "capture %d: %d pairs, capacity %d", a, c.n_pairs, c.pair_cap);
-        // d_lags == nullptr: the pair values come from gj_pack_pair_values_dev (then peaks / margins are not read either)
-        if (c.n_pairs && (!d_pairs || (d_lags && (!d_peaks || !d_margins)))) return fail(ctx, GJ_ERR_INVALID, "null pair buffer");
+        if (c.n_pairs && (!d_pairs || !d_lags || !d_peaks || !d_margins)) return fail(ctx, GJ_ERR_INVALID, "null pair buffer");
         B.c[a] = c;
         if (c.n_chunks > max_chunks) max_chunks = (size_t)c.n_chunks;
         if (c.pair_cap > max_pair_cap) max_pair_cap = c.pair_cap;

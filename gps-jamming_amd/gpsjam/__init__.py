@@ -679,11 +679,6 @@ class Device:
         self._check(self._lib.gj_pack_results_dev(self._ctx, ca, len(captures), nperseg, _ptr(d_pairs) or None, _ptr(d_lags) or None,
                                                   _ptr(d_peaks) or None, _ptr(d_margins) or None))
 
-    def pack_pair_values_dev(self, n_pairs, d_lags, d_peaks, d_margins, d_pair_block):
-        """lag / peak / margin of the solved pairs into a result vector's pair block (gj_pack_pair_values_dev): the
-        counterpart of pack_result(s)_dev called with d_lags=None."""
-        self._check(self._lib.gj_pack_pair_values_dev(self._ctx, n_pairs, _ptr(d_lags), _ptr(d_peaks), _ptr(d_margins), _ptr(d_pair_block)))
-
     def welch_timed_dev(self, d_iq, nbytes, chunk_samples, nperseg, fs, d_psd, d_psd_db=None, shift=True):
         """welch_dev with events around the transform kernel and around the finalize launch; synchronises.
         Returns (kernel_ms, finalize_ms) (gj_welch_timed_dev)."""

@@ -209,7 +209,6 @@ SIGNATURES = {
     "gj_split_combine_dev": (_i, [_vp, _vp, _vp]),
     "gj_combine_plan_destroy": (_i, [_vp, _vp]),
     "gj_pack_results_dev": (_i, [_vp, C.POINTER(CombineCapture), _i, _i, _vp, _vp, _vp, _vp]),
-    "gj_pack_pair_values_dev": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "gj_combine_plan_check": (_i, [C.POINTER(CombineCopy), _i, C.POINTER(CombineCapture), _i, _sz, _vp, _sz, _i, _i]),
     "gj_acq_search_dev": (_i, [_vp, _vp, _sz, _sz, _i, _i, _vp, _i, _vp, _i, _i, _d, _f, _vp, _vp]),
     "gj_acq_workspace": (_sz, [_vp, _i, _i, _i, _i, _i]),

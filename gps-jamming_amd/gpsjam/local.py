@@ -28,7 +28,7 @@ import torch
 
 import logging
 
-from .sharded import HEADER, LAG_INVALID, StepResults, all_pairs, result_len
+from .sharded import LAG_INVALID, StepResults, all_pairs, result_len
 from .streams import stream_beside_checked
 
 _log = logging.getLogger("gpsjam.local")
@@ -86,7 +86,6 @@ class LocalAntennas:
         self._idx = 0
         self._ev_go = torch.cuda.Event()
         self._ev_side = [torch.cuda.Event() for _ in self._sides]
-        self._ev_tail0 = torch.cuda.Event()
         # one captured graph per result set (made at the second / third step); never on the legacy default stream
         self._graphs = [None, None] if (graph and self._main != torch.cuda.default_stream(d)) else None
         self._steps = 0
@@ -137,23 +136,12 @@ class LocalAntennas:
         for k in range(1, len(self._sides)):         # every slot is in place before the pairs are solved
             self._ev_side[k].record(self._sides[k][1])
             s0.wait_event(self._ev_side[k])
-        self._ev_tail0.record(s0)                    # side 0's own scans + tails (in front of K5)
         if self.pairs:
             sdev0.xcorr_slots_dev(self.slots, self.slot_bytes, self.n_ant, self.slice_samples, self.pairs, self.lags,
                                   self.peaks, self.margins)
-            # the solve's results go into antenna 0's vector from HERE, behind K5 on its own stream ...
-            block = out[0].data_ptr() + 8 * (HEADER + self.n_chunks[0] + self.nperseg)
-            sdev0.pack_pair_values_dev(len(self.pairs), self.lags, self.peaks, self.margins, block)
         self._ev_side[0].record(s0)
-        # ... and the vectors are packed on the main stream as soon as the PSD is there: they wait for the scans' tails
-        # (long done by then), not for K5.  Round 5 packed everything in one kernel behind BOTH K5 and the finalize, which
-        # end within a microsecond of each other on two hardware queues: the wait between the queues was 12-14 us of a
-        # 0.21-ms step (profiles/r06_deployment_timeline_*.txt).  The two kernels write disjoint words of the vector.
-        main.wait_event(self._ev_tail0)
-        for k in range(1, len(self._sides)):
-            main.wait_event(self._ev_side[k])
-        self.dev.pack_results_dev(self._pack_desc(out), self.nperseg, self.d_pairs, None, None, None)
-        main.wait_event(self._ev_side[0])            # the step ends on the main stream, behind both
+        main.wait_event(self._ev_side[0])
+        self.dev.pack_results_dev(self._pack_desc(out), self.nperseg, self.d_pairs, self.lags, self.peaks, self.margins)
 
     def _pack_desc(self, out: torch.Tensor):
         """The captures' descriptors for gj_pack_results_dev (one launch for every antenna's result vector); antenna 0

@@ -421,14 +421,6 @@ int gj_pack_result_dev(gj_ctx* ctx, size_t n_chunks, const float* d_power, const
 struct gj_combine_capture;
 int gj_pack_results_dev(gj_ctx* ctx, const struct gj_combine_capture* captures, int n_captures, int nperseg,
                         const int32_t* d_pairs, const int32_t* d_lags, const float* d_peaks, const float* d_margins);
-/* The solve's results on their own.  gj_pack_result_dev / gj_pack_results_dev with d_lags == NULL write {i, j} of every pair
- * record and leave {lag, peak, margin} alone; this call writes those three fields of n_pairs records at d_pair_block
- * (= d_out + GJ_RESULT_HEADER + n_chunks + nperseg of the vector that carries the pair table), on the stream K5 ran on.
- * The vectors' packing (which needs the PSD: the main stream) then does not wait for K5 (the second stream) and K5's
- * results do not wait for the PSD: on the reference's 10-s captures the wait between two hardware queues at that point
- * was 12 us of a 0.21-ms step (profiles/r06_deployment_timeline_*.txt). */
-int gj_pack_pair_values_dev(gj_ctx* ctx, int n_pairs, const int32_t* d_lags, const float* d_peaks, const float* d_margins,
-                            double* d_pair_block);
 
 /* ------------------------------------------------- one capture over several GPUs ------ */
 /* "fewer files than GPUs => split one file into contiguous chunk ranges aligned to
