@@ -67,7 +67,12 @@ int gj_create(int device_id, gj_ctx** out);
 int gj_destroy(gj_ctx* ctx);
 /* external != 0: run on the caller's HIP stream `hip_stream` (e.g.
  * torch.cuda.current_stream().cuda_stream; NULL then means the legacy default stream);
- * external == 0: back to the context's own non-blocking stream. */
+ * external == 0: back to the context's own non-blocking stream.
+ * ONE stream at a time per context: a context's kernels hand results between workgroups through arrival counters that
+ * belong to the context, and its workspace is one arena, so two launches of one context must never be in flight on two
+ * streams at once.  The switch itself sees to that -- the new stream is ordered behind everything the context has queued
+ * on the old one (an event + a wait; skipped while either stream is being captured into a graph) -- and a caller who
+ * wants two streams to run side by side uses two contexts (gpsjam/sharded.py, split.py, local.py do). */
 int gj_set_stream(gj_ctx* ctx, void* hip_stream, int external);
 int gj_synchronize(gj_ctx* ctx);
 /* Unpack convention of the uint8 samples on this context: sample = (u8 - offset) * scale.  The
