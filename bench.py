@@ -141,6 +141,9 @@ def main():
                     help="diagnostic (tests): this rank exits with status 3 once the process group has formed")
     ap.add_argument("--no-probe", action="store_true",
                     help="N > 1 over nccl: make RCCL the default group at once instead of probing it first in a child process per rank")
+    ap.add_argument("--mixed-groups", action="store_true",
+                    help="rehearsal, with --force-exchange at N = 1: form the groups as an N > 1 run does (gloo control group + an "
+                         "RCCL group of its own for the exchange) although there is one rank and nothing to probe")
     ap.add_argument("--inject-probe-failure", action="store_true",
                     help="diagnostic (tests): the RCCL probe children exit with status 3, as if RCCL could not form a group")
     ap.add_argument("--probe-fail", action="store_true", help=argparse.SUPPRESS)       # what --inject-probe-failure hands the child
@@ -835,7 +838,7 @@ def form_groups(args, torch, world, rank, local_rank):
         # there is no InfiniBand to probe; the data path is xGMI peer-to-peer either way
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         os.environ.setdefault("NCCL_IB_DISABLE", "1")
-    if args.backend != "nccl" or world == 1 or args.no_probe:
+    if args.backend != "nccl" or (world == 1 and not args.mixed_groups) or args.no_probe:
         if args.backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
@@ -844,7 +847,10 @@ def form_groups(args, torch, world, rank, local_rank):
         label = args.backend + (" (fallback)" if args.fallback_of else "")
         return Groups(dist, None, args.backend, label, args.fallback_of)
     dist.init_process_group(backend="gloo", timeout=limit)
-    ok, text, probe = rccl_probe(args, dist, world, rank, local_rank)
+    if world == 1:                             # --mixed-groups: one rank has nobody to probe with
+        ok, text, probe = True, "", None
+    else:
+        ok, text, probe = rccl_probe(args, dist, world, rank, local_rank)
     if not ok:
         return Groups(dist, None, "gloo", "gloo (fallback)", text, probe)
     torch.cuda.set_device(local_rank)

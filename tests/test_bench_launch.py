@@ -231,6 +231,32 @@ def test_collective_path_over_rccl_on_one_gpu():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
+def test_groups_of_an_n_gpu_run_on_one_gpu():
+    """`--gpus 1 --force-exchange --mixed-groups`: the groups exactly as N > 1 ranks form them -- gloo for control (barriers,
+    the MAX all-reduce of the step time, per_rank), an RCCL group of its own (`dist.new_group(backend="nccl", device_id=...)`)
+    handed to the pipeline for the slot all-gather and the result gather -- with the one rank a single GPU allows.  What a
+    first run on a real node would otherwise meet for the first time: the mixed-backend calls themselves."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--force-exchange", "--mixed-groups", "--steps", "3", "--warmup", "1",
+                        "--precondition", "2", "--no-cpu-baseline", "--no-end-to-end", "--no-reference-point",
+                        "--capture-bytes", str(1 << 28)], capture_output=True, text=True, env=_env(), timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["control_backend"] == "gloo" and line["exchange_backend"] == "nccl"
+    assert line["rccl_ranks"] == 1 and "over nccl" in line["identity_exchanged_via"] and line["rehearsal"] is False
+    assert line["self_check"]["passed"] is True, line["self_check"]
+    assert len(line["per_rank"]["k2_ms"]["by_rank"]) == 1 and line["per_rank"]["exchange_ms"]["max"] > 0
+    # and the split pipeline through the same groups
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--split", "--force-exchange", "--mixed-groups", "--steps", "2",
+                        "--warmup", "1", "--precondition", "2", "--capture-bytes", str(1 << 27)],
+                       capture_output=True, text=True, env=_env(), timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["control_backend"] == "gloo" and line["exchange_backend"] == "nccl" and line["rccl_ranks"] == 1
+    assert line["self_check"]["passed"] is True, line["self_check"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
 def test_per_rank_load_of_eight_antennas_on_one_gpu():
     """`--emulate-world 8 --force-exchange`: rank 0's share of an eight-antenna deployment (seven further slots, 4 of the
     28 pairs in one K5 launch, both collectives over the one-rank RCCL group) -- the lags must come out at the delays
