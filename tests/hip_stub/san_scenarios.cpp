@@ -577,9 +577,166 @@ static int scenario_alloc_failures(const char* tmpdir) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 7. every remaining entry point once, with valid arguments and a few invalid ones (ASan / UBSan over the host side of
+//    the plans: a part's view, the combine plan's bounds-by-division, the batched K2 and pack descriptors, K5 over slots,
+//    the acquisition search, the file upload) -- two threads at once so that TSan sees the same calls share a context
+// ------------------------------------------------------------------------------------------------------------------
+static int api_sweep_once(gj_ctx* ctx, const char* tmpdir, int who) {
+    const size_t unit = 8192000, nbytes = 2 * unit + 65536 * 3 + 100;     // two whole 2-s units + a ragged end
+    std::vector<uint8_t> cap = make_capture(nbytes, 40u + (unsigned)who);
+    void* d_cap = nullptr;
+    OK(gj_upload(ctx, cap.data(), nbytes, &d_cap));
+    const uint8_t* dc = static_cast<const uint8_t*>(d_cap);
+    char name[256];
+    int cus = 0;
+    uint64_t hbm = 0;
+    OK(gj_device_info(ctx, name, sizeof(name), &cus, &hbm));
+    OK(gj_device_identity(ctx, name, sizeof(name)));
+    CHECK(strstr(name, "pci=") != nullptr);
+    // a file upload with an offset that is not a page multiple
+    {
+        const std::string path = std::string(tmpdir) + "/sweep" + std::to_string(who) + ".bin";
+        FILE* f = fopen(path.c_str(), "wb");
+        CHECK(f && fwrite(cap.data(), 1, nbytes, f) == nbytes);
+        fclose(f);
+        void* d = nullptr;
+        size_t got = 0;
+        OK(gj_upload_file(ctx, path.c_str(), 4097, 5u << 20, &d, &got));
+        CHECK(got == (5u << 20));
+        OK(gj_free(ctx, d));
+        CHECK(gj_upload_file(ctx, (path + ".missing").c_str(), 0, 0, &d, &got) == GJ_ERR_INVALID);
+        unlink(path.c_str());
+    }
+    const size_t nch = gj_chunk_count(nbytes, 65536), rows = gj_welch_rows(nbytes, 2048000, 1024);
+    void *d_pow, *d_psd, *d_psd2, *d_amp, *d_on, *d_st, *d_mask, *d_hist, *d_slots, *d_l, *d_p, *d_m, *d_vec, *d_tiles, *d_amp_part, *d_pairs;
+    const size_t sb = gj_tdoa_slot_bytes(4096);
+    OK(gj_malloc(ctx, 4 * nch, &d_pow));
+    OK(gj_malloc(ctx, 4 * (rows + 1) * 1024, &d_psd));
+    OK(gj_malloc(ctx, 4 * (rows + 1) * 1024, &d_psd2));
+    OK(gj_malloc(ctx, 64, &d_amp));
+    OK(gj_malloc(ctx, 64, &d_on));
+    OK(gj_malloc(ctx, 64, &d_st));
+    OK(gj_malloc(ctx, nch, &d_mask));
+    OK(gj_malloc(ctx, 256 * 8, &d_hist));
+    OK(gj_malloc(ctx, 3 * sb, &d_slots));
+    OK(gj_malloc(ctx, 64, &d_l));
+    OK(gj_malloc(ctx, 64, &d_p));
+    OK(gj_malloc(ctx, 64, &d_m));
+    OK(gj_malloc(ctx, 64, &d_pairs));
+    const size_t vec_len = GJ_RESULT_HEADER + nch + 1024 + GJ_RESULT_PAIR_FIELDS * 3;
+    OK(gj_malloc(ctx, 8 * vec_len * 3, &d_vec));
+    OK(gj_malloc(ctx, 16 * (gj_amp_tile_count(nbytes) + 1), &d_tiles));
+    OK(gj_malloc(ctx, 64, &d_amp_part));
+    const int32_t pairs[6] = {0, 1, 0, 2, 1, 2};
+    OK(gj_memcpy_h2d(ctx, d_pairs, pairs, sizeof(pairs)));
+    OK(gj_timer_start(ctx));
+    OK(gj_chunk_power_dev(ctx, dc, nbytes, 65536, 0.f, 0, static_cast<float*>(d_pow)));
+    OK(gj_power_threshold_dev(ctx, static_cast<float*>(d_pow), nch, 5.f, 6.f, static_cast<float*>(d_st), static_cast<uint8_t*>(d_mask)));
+    OK(gj_amp_stats_dev(ctx, dc + 3, nbytes - 3, 0.2f, static_cast<gj_amp_stats*>(d_amp)));
+    OK(gj_onset_dev(ctx, dc, nbytes, 200000, 1000, 50.f, static_cast<gj_onset*>(d_on)));
+    OK(gj_byte_histogram_dev(ctx, dc, nbytes, 2048000, 1024, 100, static_cast<uint64_t*>(d_hist)));
+    float kms = 0.f, fms = 0.f;
+    OK(gj_welch_timed_dev(ctx, dc, nbytes, 2048000, 1024, 2.048e6, GJ_WELCH_SHIFT, static_cast<float*>(d_psd), nullptr, &kms, &fms));
+    {
+        const uint8_t* caps[3] = {dc, dc, dc};
+        float* out[3] = {static_cast<float*>(d_psd), static_cast<float*>(d_psd2), static_cast<float*>(d_psd)};
+        OK(gj_welch_batch_dev(ctx, caps, 2, nbytes, 2048000, 1024, 2.048e6, 0, out));
+        CHECK(gj_welch_batch_dev(ctx, caps, 17, nbytes, 2048000, 1024, 2.048e6, 0, out) == GJ_ERR_INVALID);
+    }
+    for (int a = 0; a < 3; ++a)
+        OK(gj_tdoa_slot_dev(ctx, dc, nbytes, &static_cast<gj_onset*>(d_on)->start_index, 4096, static_cast<uint8_t*>(d_slots) + a * sb));
+    OK(gj_xcorr_slots_dev(ctx, static_cast<uint8_t*>(d_slots), sb, 3, 4096, pairs, 3, static_cast<int32_t*>(d_l), static_cast<float*>(d_p),
+                          static_cast<float*>(d_m)));
+    CHECK(gj_xcorr_slots_dev(ctx, static_cast<uint8_t*>(d_slots), sb, 3, 4096, pairs, 0, static_cast<int32_t*>(d_l), static_cast<float*>(d_p),
+                             static_cast<float*>(d_m)) == GJ_ERR_INVALID);
+    OK(gj_pack_result_dev(ctx, nch, static_cast<float*>(d_pow), static_cast<float*>(d_st), static_cast<gj_amp_stats*>(d_amp),
+                          static_cast<gj_onset*>(d_on), static_cast<float*>(d_psd), rows, 1024, 0, 3, 3, static_cast<int32_t*>(d_pairs),
+                          static_cast<int32_t*>(d_l), static_cast<float*>(d_p), static_cast<float*>(d_m), static_cast<double*>(d_vec)));
+    {
+        gj_combine_capture c[3];
+        memset(c, 0, sizeof(c));
+        for (int a = 0; a < 3; ++a) {
+            c[a].n_chunks = nch; c[a].rows = rows; c[a].antenna = a; c[a].n_pairs = a == 0 ? 3 : 0; c[a].pair_cap = 3;
+            c[a].d_power = static_cast<float*>(d_pow); c[a].d_stats = static_cast<float*>(d_st); c[a].d_amp = static_cast<gj_amp_stats*>(d_amp);
+            c[a].d_onset = static_cast<gj_onset*>(d_on); c[a].d_psd = static_cast<float*>(d_psd);
+            c[a].d_out = static_cast<double*>(d_vec) + a * vec_len;
+        }
+        OK(gj_pack_results_dev(ctx, c, 3, 1024, static_cast<int32_t*>(d_pairs), static_cast<int32_t*>(d_l), static_cast<float*>(d_p), static_cast<float*>(d_m)));
+        c[1].n_pairs = 4;
+        CHECK(gj_pack_results_dev(ctx, c, 3, 1024, static_cast<int32_t*>(d_pairs), static_cast<int32_t*>(d_l), static_cast<float*>(d_p), static_cast<float*>(d_m)) == GJ_ERR_INVALID);
+        // the combine plan's validation: one good list, then counts and strides chosen to wrap 64-bit products
+        c[1].n_pairs = 0;
+        for (int a = 0; a < 3; ++a) { c[a].n_tiles = gj_amp_tile_count(nbytes); c[a].total_bytes = nbytes; c[a].n_parts = 1;
+            c[a].d_tiles = d_tiles; c[a].d_amp_parts = static_cast<gj_amp_part*>(d_amp_part); c[a].d_onset_parts = static_cast<gj_onset*>(d_on); }
+        // (arena = d_vec only: the descriptors above point outside it, which the check must say)
+        gj_combine_copy cp[2];
+        memset(cp, 0, sizeof(cp));
+        cp[0].src_byte = 0; cp[0].dst = (uint64_t)(uintptr_t)d_vec; cp[0].count = 16; cp[0].src_stride = 8; cp[0].kind = GJ_COPY_F64;
+        cp[1] = cp[0];
+        CHECK(gj_combine_plan_check(cp, 2, c, 3, 4096, d_vec, 8 * vec_len * 3, 1024, 1) != GJ_OK);       // arrays outside the arena
+        cp[1].count = ~0ull / 8 + 2;                                                                       // count * 8 wraps
+        CHECK(gj_combine_plan_check(cp, 2, c, 3, 4096, d_vec, 8 * vec_len * 3, 1024, 1) != GJ_OK);
+        cp[1].count = 4; cp[1].src_stride = 0xffffffffu; cp[1].src_byte = ~0ull - 8;                       // offset + stride wraps
+        CHECK(gj_combine_plan_check(cp, 2, c, 3, 4096, d_vec, 8 * vec_len * 3, 1024, 1) != GJ_OK);
+        CHECK(gj_combine_plan_check(cp, 0, c, 3, 4096, d_vec, 8 * vec_len * 3, 1024, 1) == GJ_ERR_INVALID);
+    }
+    {   // a part of a split capture: its own range is the second 2-s unit, one tile of halo in front
+        gj_part_view v;
+        memset(&v, 0, sizeof(v));
+        v.d_buf = dc + unit - 65536; v.buf_first_byte = unit - 65536; v.buf_bytes = nbytes - (unit - 65536);
+        v.own_first_byte = unit; v.own_bytes = unit; v.total_bytes = nbytes; v.d_noise = dc;
+        gj_scan_extra x;
+        memset(&x, 0, sizeof(x));
+        x.pct = 5.f; x.rise_db = 6.f; x.d_slot = static_cast<uint8_t*>(d_slots); x.slice_samples = 4096;
+        OK(gj_part_capture_scan_dev(ctx, &v, 65536, 0.f, 0, static_cast<float*>(d_pow), 0.f, d_tiles, static_cast<gj_amp_part*>(d_amp_part), 200000,
+                                    1000, 50.f, static_cast<gj_onset*>(d_on), &x));
+        OK(gj_part_scan_dev(ctx, &v, 65536, 0.f, 0, static_cast<float*>(d_pow), 0.f, d_tiles, static_cast<gj_amp_part*>(d_amp_part), 200000, 1000,
+                            50.f, static_cast<gj_onset*>(d_on)));
+        CHECK(gj_part_welch_workspace(ctx, &v, 2048000, 1024) > 0);
+        OK(gj_part_welch_dev(ctx, &v, 2048000, 1024, 2.048e6, 0, static_cast<float*>(d_psd), nullptr));
+        OK(gj_part_slot_dev(ctx, &v, &static_cast<gj_onset*>(d_on)->start_index, 4096, static_cast<uint8_t*>(d_slots)));
+        v.own_first_byte = unit + 2;                       // not on a chunk boundary
+        CHECK(gj_part_scan_dev(ctx, &v, 65536, 0.f, 0, static_cast<float*>(d_pow), 0.f, d_tiles, static_cast<gj_amp_part*>(d_amp_part), 200000, 1000,
+                               50.f, static_cast<gj_onset*>(d_on)) == GJ_ERR_UNSUPPORTED);
+        OK(gj_amp_combine_dev(ctx, d_tiles, gj_amp_tile_count(nbytes), static_cast<gj_amp_part*>(d_amp_part), 1, nbytes, static_cast<gj_amp_stats*>(d_amp)));
+        OK(gj_onset_combine_dev(ctx, static_cast<gj_onset*>(d_on), 1, static_cast<gj_onset*>(d_on)));
+    }
+    {
+        gj_synth_params sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.key_noise = 1; sp.key_common = 2; sp.jam_start = 100; sp.jam_end = 200; sp.noise_k = 100; sp.jam_k = 50;
+        void* d_syn = nullptr;
+        OK(gj_malloc(ctx, 2 << 20, &d_syn));
+        OK(gj_synth_u8_dev(ctx, &sp, 0, 1 << 20, static_cast<uint8_t*>(d_syn)));
+        OK(gj_free(ctx, d_syn));
+    }
+    OK(gj_probe_busy_dev(ctx, 0.1f));
+    CHECK(gj_probe_busy_dev(ctx, 1000.f) == GJ_ERR_INVALID);
+    float ms = 0.f;
+    OK(gj_timer_stop(ctx, &ms));
+    OK(gj_synchronize(ctx));
+    for (void* p : {d_pow, d_psd, d_psd2, d_amp, d_on, d_st, d_mask, d_hist, d_slots, d_l, d_p, d_m, d_vec, d_tiles, d_amp_part, d_pairs, d_cap}) OK(gj_free(ctx, p));
+    return 0;
+}
+
+static int scenario_api_sweep(const char* tmpdir) {
+    gj_ctx* ctx = nullptr;
+    OK(gj_create(0, &ctx));
+    std::atomic<int> bad{0};
+    std::thread a([&] { if (api_sweep_once(ctx, tmpdir, 0)) bad.fetch_add(1); });
+    std::thread b([&] { if (api_sweep_once(ctx, tmpdir, 1)) bad.fetch_add(1); });
+    a.join();
+    b.join();
+    CHECK(bad.load() == 0);
+    OK(gj_destroy(ctx));
+    CHECK(hip_stub_live_allocations() == 0);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) {
-        fprintf(stderr, "usage: %s threads|ingest_files|workspace|comm|lanes|alloc_failures [tmpdir]\n", argv[0]);
+        fprintf(stderr, "usage: %s threads|ingest_files|workspace|comm|lanes|alloc_failures|api_sweep [tmpdir]\n", argv[0]);
         return 2;
     }
     const std::string s = argv[1];
@@ -591,6 +748,7 @@ int main(int argc, char** argv) {
     else if (s == "comm") rc = scenario_comm();
     else if (s == "lanes") rc = scenario_lanes();
     else if (s == "alloc_failures") rc = scenario_alloc_failures(tmp);
+    else if (s == "api_sweep") rc = scenario_api_sweep(tmp);
     else fprintf(stderr, "unknown scenario %s\n", s.c_str());
     if (rc == 0) printf("%s: ok (%llu launches, %llu copies through the stand-in runtime)\n", s.c_str(), hip_stub_launches(), hip_stub_copies());
     return rc;

@@ -16,7 +16,7 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 STUB = os.path.join(HERE, "hip_stub")
-SCENARIOS = ["threads", "ingest_files", "workspace", "comm", "lanes", "alloc_failures"]
+SCENARIOS = ["threads", "ingest_files", "workspace", "comm", "lanes", "alloc_failures", "api_sweep"]
 REPORT_MARKS = ("WARNING: ThreadSanitizer", "ERROR: AddressSanitizer", "ERROR: LeakSanitizer", "runtime error:", "CHECK failed")
 
 
