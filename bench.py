@@ -1352,12 +1352,17 @@ def end_to_end(np, dev, cap, nbytes):
         return bool(np.array_equal(a[0], b[0]) and a[1].tobytes() == b[1].tobytes() and a[2].sum == b[2].sum
                     and a[2].first_index == b[2].first_index and bytes(a[3]) == bytes(b[3]))
 
+    def best(fn, source, n=3):
+        """the fastest of n runs (a single wall-clock sample of a 25-ms call varies by +-25 % from run to run)"""
+        runs = [fn(source) for _ in range(n)]
+        return min(runs, key=lambda r: r[1])
+
     run(host)                                               # lanes, pinned buffers, workspaces at their final size, code paths warm
     run_overlapped(host)
-    up, tot, ref = run(host)
+    up, tot, ref = best(run, host)
     out["host_buffer_upload_then_run"] = {"upload_ms": up * 1e3, "total_ms": tot * 1e3, "upload_GBps": nbytes / up / 1e9,
                                           "msamples_per_s": nbytes / 2 / tot / 1e6}
-    up, tot, got = run_overlapped(host)
+    up, tot, got = best(run_overlapped, host)
     out["host_buffer"] = {"upload_ms": up * 1e3, "total_ms": tot * 1e3, "upload_GBps": nbytes / up / 1e9,
                           "msamples_per_s": nbytes / 2 / tot / 1e6, "overlapped": True,
                           "identical_to_upload_then_run": same(got, ref)}
@@ -1374,10 +1379,10 @@ def end_to_end(np, dev, cap, nbytes):
     path = os.path.join(d, f"gpsjam_bench_{os.getpid()}.bin")
     try:
         host.tofile(path)
-        up, tot, _ = run(path)
+        up, tot, _ = best(run, path)
         out["file_upload_then_run"] = {"upload_ms": up * 1e3, "total_ms": tot * 1e3, "upload_GBps": nbytes / up / 1e9,
                                        "msamples_per_s": nbytes / 2 / tot / 1e6}
-        up, tot, got = run_overlapped(path)
+        up, tot, got = best(run_overlapped, path)
         out["file"] = {"upload_ms": up * 1e3, "total_ms": tot * 1e3, "upload_GBps": nbytes / up / 1e9,
                        "msamples_per_s": nbytes / 2 / tot / 1e6, "where": d + (" (tmpfs)" if d == "/dev/shm" else " (disk-backed, page-cache resident)"), "overlapped": True,
                        "identical_to_upload_then_run": same(got, ref)}
@@ -1386,7 +1391,7 @@ def end_to_end(np, dev, cap, nbytes):
             os.remove(path)
         except OSError:
             pass
-    out["what"] = ("one H2D per capture, K1 power map + K2 Welch 4096 + K3 amp stats + K4 onset and the D2H of their results, "
+    out["what"] = ("best of three; one H2D per capture, K1 power map + K2 Welch 4096 + K3 amp stats + K4 onset and the D2H of their results, "
                    "wall clock.  host_buffer / file: gj_ingest_* -- the kernels run on the pieces that have landed (16 MiB each at this size) while the "
                    "rest uploads; *_upload_then_run: gpsjam.Capture, then the four calls (round 2's order)")
     out["uploads"] = gpsjam.Capture.uploads
