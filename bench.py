@@ -328,7 +328,12 @@ def main():
     # the reference's own operating point, in the driver-run line: K2 at nperseg 1024 on the same capture, and the
     # three-antenna 10-s deployment (N = 1 only; secondary figures must never cost the primary line)
     ref_point = None
-    if rank == 0 and world == 1 and not args.no_reference_point:
+    # Not beside a live RCCL process group (--force-exchange): the deployment step is captured into a HIP graph, its side
+    # streams come from torch's stream pool -- and so does the process group's internal stream.  When the two coincide,
+    # the group's watchdog thread, polling the end event of a collective it has not yet seen complete (it looks every
+    # 100 ms), asks about an event whose stream is being captured: hipErrorCapturedEvent, and torch ends the process
+    # (seen once in ~15 runs of the short --force-exchange rehearsal, round 6).  gpsjam/local.py says the same to its users.
+    if rank == 0 and world == 1 and not grouped and not args.no_reference_point:
         try:
             psd_ref = torch.empty((dev.welch_rows(nbytes, CHUNK_SAMPLES, REF_NPERSEG), REF_NPERSEG), dtype=torch.float32, device="cuda")
             dev.reserve(max(dev.welch_workspace(nbytes, CHUNK_SAMPLES, REF_NPERSEG), dev.welch_workspace(nbytes, CHUNK_SAMPLES, NPERSEG)))

@@ -162,7 +162,11 @@ class LocalAntennas:
 
     def _capture(self, k: int):
         """The step for result set k as ONE HIP graph (stream capture on the main stream; the side streams join the
-        capture through the events).  Round 4: ~45 launches per step, 0.37-0.38 ms launched one by one against 0.345-0.352 ms
+        capture through the events).
+        Beside a live torch.distributed NCCL (= RCCL) process group: let its outstanding collectives complete AND its
+        watchdog notice (it polls every 100 ms) before the first captured step, or construct with ``graph=False`` -- the
+        side streams come from torch's stream pool like the group's internal stream, and HIP refuses a query of an event
+        whose stream is being captured (hipErrorCapturedEvent ends the process from the watchdog thread).  Round 4: ~45 launches per step, 0.37-0.38 ms launched one by one against 0.345-0.352 ms
         replayed (the runtime's graph executor starts the branches one after the other: profiles/r04_deployment.txt).
         Round 5: twelve launches per step (one K2 + finalize, two per capture on the side, three for K5, one pack), 0.22 ms
         eager against 0.20-0.21 ms replayed (profiles/r05_deployment_timeline_*.txt).  Everything in a step is capturable --
