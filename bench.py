@@ -406,6 +406,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic"], "traffic_unit": "HBM bytes per launch",
                          "traffic_source": pmc["source"], "traffic_measured_on_this_source": pmc["matches_build"],
                          "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": welch_ms,
+                         # as-run K2 scatters from launch to launch (what runs beside it, clocks): the spread of THIS sample
+                         "launch_ms_spread": (lambda v: {"min": v[0], "median": v[len(v) // 2], "max": v[-1], "launches": len(v)})(
+                             sorted(a.elapsed_time(b) for a, b in ev)) if ev else None,
                          "overlap": bool(stream.overlap),
                          "solo": {"avg_launch_ms": solo_ms, "achieved": (nbytes / 1e9) / (solo_ms / 1e3),
                                   "frac": (nbytes / 1e9) / (solo_ms / 1e3) / HBM_PEAK_GBS},
