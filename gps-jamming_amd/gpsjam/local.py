@@ -163,10 +163,11 @@ class LocalAntennas:
     def _capture(self, k: int):
         """The step for result set k as ONE HIP graph (stream capture on the main stream; the side streams join the
         capture through the events).
-        Beside a live torch.distributed NCCL (= RCCL) process group: let its outstanding collectives complete AND its
-        watchdog notice (it polls every 100 ms) before the first captured step, or construct with ``graph=False`` -- the
-        side streams come from torch's stream pool like the group's internal stream, and HIP refuses a query of an event
-        whose stream is being captured (hipErrorCapturedEvent ends the process from the watchdog thread).  Round 4: ~45 launches per step, 0.37-0.38 ms launched one by one against 0.345-0.352 ms
+        Beside a live torch.distributed NCCL (= RCCL) process group the capture first lets the group's outstanding
+        collectives complete AND its watchdog notice (it polls every 100 ms): the side streams come from torch's stream
+        pool like the group's internal stream, and HIP refuses a query of an event whose stream is being captured
+        (hipErrorCapturedEvent, raised in the watchdog thread, ends the process).  Collectives issued from ANOTHER thread
+        while a step is being captured are not covered: construct with ``graph=False`` then.  Round 4: ~45 launches per step, 0.37-0.38 ms launched one by one against 0.345-0.352 ms
         replayed (the runtime's graph executor starts the branches one after the other: profiles/r04_deployment.txt).
         Round 5: twelve launches per step (one K2 + finalize, two per capture on the side, three for K5, one pack), 0.22 ms
         eager against 0.20-0.21 ms replayed (profiles/r05_deployment_timeline_*.txt).  Everything in a step is capturable --
@@ -174,6 +175,13 @@ class LocalAntennas:
         eager (same kernels)."""
         try:
             torch.cuda.synchronize()
+            try:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized() and "nccl" in str(dist.get_backend()):
+                    import time
+                    time.sleep(0.15)             # one watchdog period: no collective's end event is left to be queried
+            except Exception:                    # noqa: BLE001 -- a torch without distributed support
+                pass
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=self._main, capture_error_mode="thread_local"):
                 self._enqueue(self._final[k])
