@@ -177,7 +177,8 @@ class LocalAntennas:
             torch.cuda.synchronize()
             try:
                 import torch.distributed as dist
-                if dist.is_available() and dist.is_initialized() and "nccl" in str(dist.get_backend()):
+                from torch.distributed import distributed_c10d as _c10d
+                if dist.is_available() and dist.is_initialized() and any("nccl" in str(v[0]).lower() for v in _c10d._world.pg_map.values()):
                     import time
                     time.sleep(0.15)             # one watchdog period: no collective's end event is left to be queried
             except Exception:                    # noqa: BLE001 -- a torch without distributed support
