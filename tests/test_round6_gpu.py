@@ -151,3 +151,39 @@ def test_tail_threshold_with_a_rule_decided_last_chunk(dev, nbytes, chunk, flags
     for b in (buf, d_st2, d_mask2):
         b.free()
 
+
+
+# ----------------------------------------------------------------------------- seeded sweep of K3 / K4 alone
+@pytest.mark.parametrize("case", list(range(16)))
+def test_sweep_k3_k4_alone(dev, case):
+    """Sizes, alignments, thresholds, noise spans, windows and burst positions nobody hand-picked: gj_amp_stats_dev and
+    gj_onset_dev on a pointer at a random offset into a buffer, against the exact restatement (bit for bit) and the oracle
+    (index exact, mean 1e-6)."""
+    r = np.random.RandomState(6000 + case)
+    off = int(r.choice([0, 0, 16, 2, 6, 1, 7, 30, 65536, 65538]))
+    nbytes = int(r.randint(3, 40)) * 65536 + int(r.choice([0, 1, 2, 254, 1023, 24691, 65535]))
+    noise = int(r.choice([1, 511, 512, 20_000, 100_000, 200_000]))
+    window = int(r.choice([1, 8, 256, 1000, 1001, 4096]))
+    thr = float(r.choice([0.0, 0.05, 0.2, 0.6, 1.5]))
+    ns = nbytes // 2
+    jam = int(ns * r.uniform(0.3, 0.9)) if r.rand() < 0.8 else 1 << 40
+    raw = generate(StreamSpec(seed=7000 + case, jam_start=jam, jam_end=1 << 40, jam_sigma=float(r.uniform(40, 90))), (nbytes + off) // 2 + 1)
+    raw = raw[:nbytes + off]
+    buf = dev.alloc(nbytes + off + 16).upload(raw)
+    piece = raw[off:off + nbytes]
+    amp_b, on_b = _alone(dev, buf.ptr + off, nbytes, thr, noise=noise, window=window)
+    _check_exact(amp_b, on_b, piece, thr, noise=noise, window=window)
+    even = piece[:2 * ns]
+    got_on = np.frombuffer(on_b, ONSET_T)[0]
+    if window <= 1001 or ns <= 600_000:                       # the oracle's np.convolve is O(n * window)
+        want = orc.tdoa_onset(orc.tdoa_unpack(even), noise, window, FACTOR)
+        # exact integers here, float32 sums there: identical unless the decision fell inside the rounding band, which the
+        # record says (guard_index != start_index or a margin below 1e-6)
+        if got_on["guard"] == got_on["start"] and (got_on["start"] < 0 or got_on["hit"] >= 1e-6):
+            assert got_on["start"] == want, (got_on, want)
+    k, avg = orc.rssi_amp_stats(even, thr)
+    a = np.frombuffer(amp_b, AMP_T)[0]
+    assert a["i"] == (-1 if k is None else k)
+    if k is not None:
+        np.testing.assert_allclose(a["m"], avg, rtol=1e-6)
+    buf.free()
