@@ -45,6 +45,10 @@
 //   N = 4096  1.328 -> 1.257 ms   2048  1.348 -> 1.320   1024  1.284 -> 1.211   512  1.242 -> 1.142
 //   N = 256   1.001 -> 0.960      128   1.055 -> 1.042   64    1.278 -> 1.207   32   2.160 -> 2.119
 //   N = 16    1.669 -> 1.707 (stays in the two-workgroup shape)
+// (Figures of rounds 2-5.  Below 4096 they INCLUDED a finalize that added B = 4096 / N partial rows per workgroup -- at 16
+// points 256 of them, a launch longer than the transform.  With one partial row per workgroup (round 6) K2 + finalize
+// per GiB is 0.43 / 0.63 / 0.68 / 0.73 / 0.76 / 0.94 / 0.99 / 1.15 / 1.09 ms at 16 / 32 / ... / 4096 points
+// (profiles/r06_k2_all_sizes.txt); the two-against-three-workgroup comparison itself has not been repeated.)
 // (512..2048 fit 168 VGPRs only since the exchange addresses are written as base + constant,
 // fft_core.h lds_scatter/lds_gather: 236-246 -> 192-206 VGPRs in the two-workgroup shape.)
 #define GJ_W_OCC3_MASK 0x1FE0u
@@ -67,6 +71,13 @@
 // workgroup barrier, as for the larger sizes.  The second form is built as libgpsjam_hip_barrier.so (Makefile) and
 // tests/test_round5_gpu.py compares the two byte for byte: the fence path must never depend on a barrier it removed.
 #define GJ_W_WAVEFENCE 1
+#endif
+#ifndef GJ_W_WIDELOAD
+// 1: transforms of 16 and 32 points fetch their segment with 16-byte loads (2 or 4 of them) and pick the thread's sixteen
+// samples out of the registers, instead of sixteen 2-byte loads at a 2 TF-byte stride.  Measured per GiB, interleaved on
+// one box (profiles/r06_k2_small_sizes.txt): N = 32 0.95 -> 0.64 ms, N = 16 0.449 -> 0.441; the same for 64 points needs a
+// run-time choice between register pairs, spills, and is three times SLOWER (0.70 -> 2.29 ms): 64 keeps the narrow loads.
+#define GJ_W_WIDELOAD 1
 #endif
 #ifndef GJ_W_XPOSE
 #define GJ_W_XPOSE 1     // 1: N = 4096 uses the bank-conflict-free exchange schedule (fft_core.h X4096)
@@ -279,10 +290,29 @@ __global__ __launch_bounds__(kBlockThreads, WelchCfg<N>::min_waves) void welch_k
     // one SGPR pair + one VGPR + immediates
     const uint8_t* chunk8 = iq + (size_t)c * g.chunk_samples * 2;
     auto load_step = [&](unsigned (&dst)[16], unsigned seg_idx) {
-        const unsigned byte0 = (seg_idx * (unsigned)(N / 2) + (unsigned)jl0) * 2u;
+        if constexpr (GJ_W_WIDELOAD != 0 && TF <= 2) {
+            // the whole segment (2 N bytes) in 16-byte loads; sample jl0 + TF s is one half of dword (jl0 + TF s) / 2.
+            // The segment is only 2-byte aligned in general: global memory takes unaligned vector loads.
+            struct __attribute__((packed, aligned(2))) Vec16 { unsigned x, y, z, w; };
+            constexpr int NV = 2 * N / 16;
+            const Vec16* src = reinterpret_cast<const Vec16*>(chunk8 + seg_idx * (unsigned)N);
+            unsigned w[4 * NV];
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
-            dst[s] = (*reinterpret_cast<const uint16_t*>(chunk8 + (byte0 + 2u * TF * s)));
+            for (int v = 0; v < NV; ++v) {
+                const Vec16 g = src[v];
+                w[4 * v] = g.x; w[4 * v + 1] = g.y; w[4 * v + 2] = g.z; w[4 * v + 3] = g.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                if constexpr (TF == 1) dst[s] = (s & 1) ? (w[s >> 1] >> 16) : (w[s >> 1] & 0xffffu);
+                else dst[s] = (w[s] >> (16u * (unsigned)jl0)) & 0xffffu;
+            }
+        } else {
+            const unsigned byte0 = (seg_idx * (unsigned)(N / 2) + (unsigned)jl0) * 2u;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                dst[s] = (*reinterpret_cast<const uint16_t*>(chunk8 + (byte0 + 2u * TF * s)));
+        }
     };
     // samples s0 .. s0+7 of segment seg_idx (one half segment)
     auto load_half = [&](unsigned (&dst)[8], unsigned seg_idx, int s0) {
