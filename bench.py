@@ -448,8 +448,9 @@ def main():
                 "achieved": (k5_bytes / 1e9) / (k5_ms / 1e3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (k5_bytes / 1e9) / (k5_ms / 1e3) / HBM_PEAK_GBS,
                 **family_traffic("profiles/r06_pmc_xcorr/summary.json", nbytes),
-                "note": "PMC: about half of the four-step floor reaches HBM -- the spectra are written through "
-                        "(50 MB) and about a third of the reads miss L2 / Infinity Cache (56 MB)"}
+                "note": "PMC: FETCH_SIZE / WRITE_SIZE count the L2's requests to the fabric, Infinity-Cache hits included "
+                        "(MI355X_MICROARCH.md): 49 MB written = the two sets of spectra once each, 55 MB fetched = what the two "
+                        "consuming launches need -- the floor of a three-launch four-step transform, not HBM traffic"}
         if acq_ms is not None:
             n_prn, n_freq, intg, acq_nsamp = acq_shape
             n_fft = intg * n_freq * (1 + n_prn) + n_prn
